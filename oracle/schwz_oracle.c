@@ -1,0 +1,1128 @@
+/*
+ * schwz_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE ONLY, see schwz_oracle.h).
+ *
+ * Plain-C restatement of the Restricted Additive Schwarz outer iteration of
+ * pratikvn/schwarz-lib.  Each function cites the reference file:line it follows
+ * (paths relative to the reference checkout).  "parity unpinned" by the
+ * reference's own tests (it has none); pinned by tests/golden/ instead.
+ *
+ * Deliberate deviations from the letter of the reference, all documented in
+ * SURVEY.md section 0:
+ *   F8  two-sided receive is waited for before it is scattered;
+ *   F9  x0 = 0 and the CG warm start is 0 (the reference relies on fresh pages);
+ *   the CG / Jacobi / triangular solves / LL^T owned by Ginkgo and CHOLMOD are
+ *   restated from the textbook algorithms.
+ */
+#include "schwz_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* below this length a parallel region costs more than the loop */
+#define OMP_MIN_N 32768
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void *xmalloc(size_t bytes)
+{
+    void *p = malloc(bytes ? bytes : 1);
+    if (!p) {
+        fprintf(stderr, "schwz_oracle: out of memory (%zu bytes)\n", bytes);
+        abort();
+    }
+    return p;
+}
+static void *xcalloc(size_t n, size_t sz)
+{
+    void *p = calloc(n ? n : 1, sz);
+    if (!p) {
+        fprintf(stderr, "schwz_oracle: out of memory\n");
+        abort();
+    }
+    return p;
+}
+
+void schwz_or_free(void *p) { free(p); }
+
+/* ======================================================================== */
+/* problem generation                                                        */
+/* ======================================================================== */
+
+/* source/initialization.cpp:214-265.  Stencil map iterates in key order
+ * {-n,-1,0,+1,+n} (:227-230); entries (kn,kn-1) and (kn-1,kn) are excluded
+ * (:231-239), i.e. no wrap-around between grid lines. */
+int64_t schwz_or_laplacian2d(int n, or_idx *row_ptr, or_idx *col, double *val)
+{
+    const int64_t N = (int64_t)n * n;
+    const int64_t ofs[5] = {-(int64_t)n, -1, 0, 1, n};
+    const double sv[5] = {-1.0, -1.0, 4.0, -1.0, -1.0};
+    int64_t pos = 0;
+    row_ptr[0] = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        for (int k = 0; k < 5; ++k) {
+            int64_t c = i + ofs[k];
+            if (c < 0 || c >= N) continue;
+            if (k == 1 && i % n == 0) continue;       /* (kn, kn-1) */
+            if (k == 3 && (i + 1) % n == 0) continue; /* (kn-1, kn) */
+            if (col) {
+                col[pos] = (or_idx)c;
+                val[pos] = sv[k];
+            }
+            ++pos;
+        }
+        row_ptr[i + 1] = (or_idx)pos;
+    }
+    return pos;
+}
+
+int64_t schwz_or_laplacian3d(int nx, int ny, int nz, or_idx *row_ptr,
+                             or_idx *col, double *val)
+{
+    const int64_t N = (int64_t)nx * ny * nz;
+    const int64_t sxy = (int64_t)nx * ny;
+    int64_t pos = 0;
+    row_ptr[0] = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        int64_t x = i % nx, y = (i / nx) % ny, z = i / sxy;
+#define EMIT(cond, c, v)              \
+    if (cond) {                       \
+        if (col) {                    \
+            col[pos] = (or_idx)(c);   \
+            val[pos] = (v);           \
+        }                             \
+        ++pos;                        \
+    }
+        EMIT(z > 0, i - sxy, -1.0)
+        EMIT(y > 0, i - nx, -1.0)
+        EMIT(x > 0, i - 1, -1.0)
+        EMIT(1, i, 6.0)
+        EMIT(x < nx - 1, i + 1, -1.0)
+        EMIT(y < ny - 1, i + nx, -1.0)
+        EMIT(z < nz - 1, i + sxy, -1.0)
+#undef EMIT
+        row_ptr[i + 1] = (or_idx)pos;
+    }
+    return pos;
+}
+
+/* source/schwarz_base.cpp:169 */
+void schwz_or_rhs_ones(int64_t n, double *rhs)
+{
+    for (int64_t i = 0; i < n; ++i) rhs[i] = 1.0;
+}
+
+/* ======================================================================== */
+/* partitioning                                                              */
+/* ======================================================================== */
+
+/* source/restricted_schwarz.cpp:84,97-102 */
+void schwz_or_first_rows_regular(int64_t N, int P, or_idx *first_row)
+{
+    int64_t nb = (N + P - 1) / P;
+    first_row[0] = 0;
+    for (int p = 0; p < P; ++p) {
+        int64_t sz = N - first_row[p];
+        if (sz > nb) sz = nb;
+        first_row[p + 1] = (or_idx)(first_row[p] + sz);
+    }
+}
+
+/* include/partition_tools.hpp:76-94 */
+int schwz_or_partition_regular2d(int n1d, int P, uint32_t *part)
+{
+    int64_t n = (int64_t)n1d * n1d;
+    int sq_n = (int)sqrt((double)n);
+    int sq_p = (int)sqrt((double)P);
+    if (sq_p * sq_p != P || sq_n % sq_p != 0) return -1; /* SURVEY F10 */
+    int b = sq_n / sq_p;
+    for (int j1 = 0; j1 < sq_p; ++j1) {
+        int64_t offset2 = (int64_t)j1 * sq_p * b * b;
+        for (int j2 = 0; j2 < sq_p; ++j2) {
+            uint32_t id = (uint32_t)(sq_p * j1 + j2);
+            int64_t offset1 = (int64_t)j2 * sq_n / sq_p;
+            for (int i1 = 0; i1 < b; ++i1)
+                for (int i2 = 0; i2 < b; ++i2)
+                    part[offset2 + offset1 + (int64_t)i1 * sq_n + i2] = id;
+        }
+    }
+    return 0;
+}
+
+/* source/restricted_schwarz.cpp:105-152 */
+void schwz_or_apply_partition(int64_t N, int P, const uint32_t *part,
+                              const or_idx *rp, const or_idx *col,
+                              const double *val, or_idx *perm, or_idx *iperm,
+                              or_idx *first_row, or_idx *out_rp,
+                              or_idx *out_col, double *out_val)
+{
+    or_idx *cnt = (or_idx *)xcalloc((size_t)P + 1, sizeof(or_idx));
+    for (int64_t i = 0; i < N; ++i) cnt[part[i]]++;
+    first_row[0] = 0;
+    for (int p = 0; p < P; ++p) first_row[p + 1] = first_row[p] + cnt[p];
+    for (int64_t i = 0; i < N; ++i) {
+        perm[first_row[part[i]]] = (or_idx)i;
+        first_row[part[i]]++;
+    }
+    for (int p = P; p > 0; --p) first_row[p] = first_row[p - 1];
+    first_row[0] = 0;
+    for (int64_t i = 0; i < N; ++i) iperm[perm[i]] = (or_idx)i;
+    int64_t nnz = 0;
+    out_rp[0] = 0;
+    for (int64_t row = 0; row < N; ++row) {
+        for (or_idx j = rp[perm[row]]; j < rp[perm[row] + 1]; ++j) {
+            out_col[nnz] = iperm[col[j]];
+            out_val[nnz] = val[j];
+            ++nnz;
+        }
+        out_rp[row + 1] = (or_idx)nnz;
+    }
+    free(cnt);
+}
+
+/* ======================================================================== */
+/* subdomain index sets and matrices                                         */
+/* ======================================================================== */
+
+struct or_subdomain {
+    int64_t N;
+    int P, me, overlap;
+    or_idx *first_row;        /* P+1 */
+    or_idx *global_to_local;  /* N, 1-based, 0 = not local */
+    or_idx *local_to_global;  /* local_size_x + halo */
+    or_idx local_size, local_size_x, overlap_size, halo_size;
+    or_idx *l_rp, *l_col;
+    double *l_val;
+    int64_t nnz_local;
+    or_idx *i_rp, *i_col; /* interface, GLOBAL column ids */
+    double *i_val;
+    int64_t nnz_interface;
+    int n_in, n_out;
+    int *nbr_in, *nbr_out;
+    or_idx **get; /* [k][0]=count, then global ids */
+    or_idx **put;
+    int64_t num_recv, num_send;
+};
+
+static int cmp_pair(const void *a, const void *b)
+{
+    or_idx x = *(const or_idx *)a, y = *(const or_idx *)b;
+    return (x > y) - (x < y);
+}
+
+/* sort_by_column_index on one CSR row (Ginkgo semantics: ascending columns) */
+static void sort_row(or_idx *col, double *val, or_idx len)
+{
+    /* insertion sort; rows are short */
+    for (or_idx i = 1; i < len; ++i) {
+        or_idx c = col[i];
+        double v = val[i];
+        or_idx j = i;
+        while (j > 0 && col[j - 1] > c) {
+            col[j] = col[j - 1];
+            val[j] = val[j - 1];
+            --j;
+        }
+        col[j] = c;
+        val[j] = v;
+    }
+}
+
+/* source/restricted_schwarz.cpp:155-304 (A.1 steps 2-6) and :336-371 (A.2). */
+or_subdomain *schwz_or_subdomain_setup(int64_t N, const or_idx *rp,
+                                       const or_idx *col, const double *val,
+                                       int P, int me, int overlap,
+                                       const or_idx *first_row)
+{
+    or_subdomain *sd = (or_subdomain *)xcalloc(1, sizeof(*sd));
+    sd->N = N;
+    sd->P = P;
+    sd->me = me;
+    sd->overlap = overlap;
+    sd->first_row = (or_idx *)xmalloc(sizeof(or_idx) * (size_t)(P + 1));
+    memcpy(sd->first_row, first_row, sizeof(or_idx) * (size_t)(P + 1));
+    or_idx *g2l = (or_idx *)xcalloc((size_t)N, sizeof(or_idx));
+    or_idx *l2g = (or_idx *)xcalloc((size_t)N, sizeof(or_idx));
+    sd->global_to_local = g2l;
+
+    /* :155-164 interior */
+    or_idx num = 0;
+    for (or_idx i = first_row[me]; i < first_row[me + 1]; ++i) {
+        g2l[i] = 1 + num;
+        l2g[num] = i;
+        ++num;
+    }
+    sd->local_size = num;
+    /* :166-180 overlap-1 BFS layers, discovery order */
+    or_idx old = 0;
+    for (int k = 1; k < overlap; ++k) {
+        or_idx now = num;
+        for (or_idx i = old; i < now; ++i) {
+            for (or_idx j = rp[l2g[i]]; j < rp[l2g[i] + 1]; ++j) {
+                if (g2l[col[j]] == 0) {
+                    l2g[num] = col[j];
+                    g2l[col[j]] = 1 + num;
+                    ++num;
+                }
+            }
+        }
+        old = now;
+    }
+    sd->local_size_x = num;
+    sd->overlap_size = num - sd->local_size;
+
+    /* :194-219 count */
+    int64_t nnz_l = 0, nnz_i = 0;
+    for (or_idx i = first_row[me]; i < first_row[me + 1]; ++i)
+        for (or_idx j = rp[i]; j < rp[i + 1]; ++j)
+            if (g2l[col[j]] != 0) ++nnz_l; /* else "invalid edge": dropped */
+    for (or_idx k = 0; k < sd->overlap_size; ++k) {
+        or_idx g = l2g[sd->local_size + k];
+        for (or_idx j = rp[g]; j < rp[g + 1]; ++j) {
+            if (g2l[col[j]] != 0)
+                ++nnz_l;
+            else
+                ++nnz_i;
+        }
+    }
+    sd->nnz_local = nnz_l;
+    sd->nnz_interface = nnz_i;
+    const or_idx n = sd->local_size_x;
+    sd->l_rp = (or_idx *)xcalloc((size_t)n + 1, sizeof(or_idx));
+    sd->l_col = (or_idx *)xmalloc(sizeof(or_idx) * (size_t)nnz_l);
+    sd->l_val = (double *)xmalloc(sizeof(double) * (size_t)nnz_l);
+    sd->i_rp = (or_idx *)xcalloc((size_t)n + 1, sizeof(or_idx));
+    sd->i_col = (or_idx *)xmalloc(sizeof(or_idx) * (size_t)nnz_i);
+    sd->i_val = (double *)xmalloc(sizeof(double) * (size_t)nnz_i);
+
+    /* :245-284 fill */
+    or_idx r = 0;
+    int64_t pl = 0, pi = 0;
+    for (or_idx i = first_row[me]; i < first_row[me + 1]; ++i) {
+        for (or_idx j = rp[i]; j < rp[i + 1]; ++j) {
+            if (g2l[col[j]] != 0) {
+                sd->l_col[pl] = g2l[col[j]] - 1;
+                sd->l_val[pl] = val[j];
+                ++pl;
+            }
+        }
+        sd->l_rp[r + 1] = (or_idx)pl;
+        sd->i_rp[r + 1] = (or_idx)pi;
+        ++r;
+    }
+    for (or_idx k = 0; k < sd->overlap_size; ++k) {
+        or_idx g = l2g[sd->local_size + k];
+        for (or_idx j = rp[g]; j < rp[g + 1]; ++j) {
+            if (g2l[col[j]] != 0) {
+                sd->l_col[pl] = g2l[col[j]] - 1;
+                sd->l_val[pl] = val[j];
+                ++pl;
+            } else {
+                sd->i_col[pi] = col[j];
+                sd->i_val[pi] = val[j];
+                ++pi;
+            }
+        }
+        sd->l_rp[r + 1] = (or_idx)pl;
+        sd->i_rp[r + 1] = (or_idx)pi;
+        ++r;
+    }
+    /* :285-295 halo marking: one more BFS step from the last layer */
+    {
+        or_idx now = num;
+        for (or_idx i = old; i < now; ++i) {
+            for (or_idx j = rp[l2g[i]]; j < rp[l2g[i] + 1]; ++j) {
+                if (g2l[col[j]] == 0) {
+                    l2g[num] = col[j];
+                    g2l[col[j]] = 1 + num;
+                    ++num;
+                }
+            }
+        }
+    }
+    sd->halo_size = num - sd->local_size_x;
+    sd->local_to_global = (or_idx *)xmalloc(sizeof(or_idx) * (size_t)(num ? num : 1));
+    memcpy(sd->local_to_global, l2g, sizeof(or_idx) * (size_t)num);
+    free(l2g);
+    /* :297-298 sort_by_column_index */
+    for (or_idx i = 0; i < n; ++i) {
+        sort_row(sd->l_col + sd->l_rp[i], sd->l_val + sd->l_rp[i],
+                 sd->l_rp[i + 1] - sd->l_rp[i]);
+        sort_row(sd->i_col + sd->i_rp[i], sd->i_val + sd->i_rp[i],
+                 sd->i_rp[i + 1] - sd->i_rp[i]);
+    }
+
+    /* :336-371 get lists: every mapped global id owned by p, ascending */
+    sd->nbr_in = (int *)xcalloc((size_t)P, sizeof(int));
+    sd->nbr_out = (int *)xcalloc((size_t)P, sizeof(int));
+    sd->get = (or_idx **)xcalloc((size_t)P, sizeof(or_idx *));
+    sd->put = (or_idx **)xcalloc((size_t)P, sizeof(or_idx *));
+    sd->n_in = 0;
+    sd->n_out = 0;
+    for (int p = 0; p < P; ++p) {
+        if (p == me) continue;
+        or_idx count = 0;
+        for (or_idx i = first_row[p]; i < first_row[p + 1]; ++i)
+            if (g2l[i] != 0) ++count;
+        if (count > 0) {
+            or_idx *lst = (or_idx *)xmalloc(sizeof(or_idx) * (size_t)(1 + count));
+            lst[0] = 0;
+            for (or_idx i = first_row[p]; i < first_row[p + 1]; ++i)
+                if (g2l[i] != 0) lst[1 + lst[0]++] = i;
+            sd->get[sd->n_in] = lst;
+            sd->nbr_in[sd->n_in] = p;
+            sd->n_in++;
+            sd->num_recv += count;
+        }
+    }
+    (void)cmp_pair;
+    return sd;
+}
+
+void schwz_or_sd_add_put_list(or_subdomain *sd, int p, or_idx count,
+                              const or_idx *ids)
+{
+    if (count <= 0) return;
+    or_idx *lst = (or_idx *)xmalloc(sizeof(or_idx) * (size_t)(1 + count));
+    lst[0] = count;
+    memcpy(lst + 1, ids, sizeof(or_idx) * (size_t)count);
+    sd->put[sd->n_out] = lst;
+    sd->nbr_out[sd->n_out] = p;
+    sd->n_out++;
+    sd->num_send += count;
+}
+
+void schwz_or_subdomain_free(or_subdomain *sd)
+{
+    if (!sd) return;
+    for (int k = 0; k < sd->n_in; ++k) free(sd->get[k]);
+    for (int k = 0; k < sd->n_out; ++k) free(sd->put[k]);
+    free(sd->get);
+    free(sd->put);
+    free(sd->nbr_in);
+    free(sd->nbr_out);
+    free(sd->first_row);
+    free(sd->global_to_local);
+    free(sd->local_to_global);
+    free(sd->l_rp);
+    free(sd->l_col);
+    free(sd->l_val);
+    free(sd->i_rp);
+    free(sd->i_col);
+    free(sd->i_val);
+    free(sd);
+}
+
+void schwz_or_subdomain_sizes(const or_subdomain *sd, int64_t *s)
+{
+    s[0] = sd->local_size;
+    s[1] = sd->local_size_x;
+    s[2] = sd->overlap_size;
+    s[3] = sd->halo_size;
+    s[4] = sd->nnz_local;
+    s[5] = sd->nnz_interface;
+    s[6] = sd->n_in;
+    s[7] = sd->n_out;
+    s[8] = sd->num_recv;
+    s[9] = sd->num_send;
+}
+const or_idx *schwz_or_sd_local_to_global(const or_subdomain *sd) { return sd->local_to_global; }
+const or_idx *schwz_or_sd_local_rp(const or_subdomain *sd) { return sd->l_rp; }
+const or_idx *schwz_or_sd_local_col(const or_subdomain *sd) { return sd->l_col; }
+const double *schwz_or_sd_local_val(const or_subdomain *sd) { return sd->l_val; }
+const or_idx *schwz_or_sd_iface_rp(const or_subdomain *sd) { return sd->i_rp; }
+const or_idx *schwz_or_sd_iface_col(const or_subdomain *sd) { return sd->i_col; }
+const double *schwz_or_sd_iface_val(const or_subdomain *sd) { return sd->i_val; }
+int schwz_or_sd_get_list(const or_subdomain *sd, int k, or_idx *count, const or_idx **ids)
+{
+    if (k < 0 || k >= sd->n_in) return -1;
+    *count = sd->get[k][0];
+    *ids = sd->get[k] + 1;
+    return sd->nbr_in[k];
+}
+int schwz_or_sd_put_list(const or_subdomain *sd, int k, or_idx *count, const or_idx **ids)
+{
+    if (k < 0 || k >= sd->n_out) return -1;
+    *count = sd->put[k][0];
+    *ids = sd->put[k] + 1;
+    return sd->nbr_out[k];
+}
+
+/* ======================================================================== */
+/* kernels                                                                   */
+/* ======================================================================== */
+
+/* Csr::apply(alpha, x, beta, y): call sites restricted_schwarz.cpp:1014-1015,
+ * solve.cpp:834-835, :1079-1080 */
+void schwz_or_spmv(int64_t nrows, const or_idx *rp, const or_idx *col,
+                   const double *val, double alpha, const double *x,
+                   double beta, double *y)
+{
+#pragma omp parallel for schedule(static) if (nrows > OMP_MIN_N)
+    for (int64_t i = 0; i < nrows; ++i) {
+        double s = 0.0;
+        for (or_idx j = rp[i]; j < rp[i + 1]; ++j) s += val[j] * x[col[j]];
+        y[i] = (beta == 0.0) ? alpha * s : alpha * s + beta * y[i];
+    }
+}
+
+/* include/gather.hpp:83-113 */
+void schwz_or_gather(int64_t n, const or_idx *idx, const double *from,
+                     double *into, int op)
+{
+    switch (op) {
+    case 1:
+        for (int64_t i = 0; i < n; ++i) into[i] = from[idx[i]];
+        break;
+    case 0:
+        for (int64_t i = 0; i < n; ++i) into[i] = from[idx[i]] + into[i];
+        break;
+    case 2:
+        for (int64_t i = 0; i < n; ++i) into[i] = from[idx[i]] - into[i];
+        break;
+    case 3:
+        for (int64_t i = 0; i < n; ++i) into[i] = (from[idx[i]] + into[i]) / 2;
+        break;
+    default:
+        break;
+    }
+}
+
+/* include/scatter.hpp:83-113 */
+void schwz_or_scatter(int64_t n, const or_idx *idx, const double *from,
+                      double *into, int op)
+{
+    switch (op) {
+    case 1:
+        for (int64_t i = 0; i < n; ++i) into[idx[i]] = from[i];
+        break;
+    case 0:
+        for (int64_t i = 0; i < n; ++i) into[idx[i]] = from[i] + into[idx[i]];
+        break;
+    case 2:
+        for (int64_t i = 0; i < n; ++i) into[idx[i]] = from[i] - into[idx[i]];
+        break;
+    case 3:
+        for (int64_t i = 0; i < n; ++i) into[idx[i]] = (from[i] + into[idx[i]]) / 2;
+        break;
+    default:
+        break;
+    }
+}
+
+static double dot(int64_t n, const double *a, const double *b)
+{
+    double s = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : s) if (n > OMP_MIN_N)
+    for (int64_t i = 0; i < n; ++i) s += a[i] * b[i];
+    return s;
+}
+
+/* Preconditioned CG, the published algorithm (Ginkgo's solver::Cg is absent
+ * from the reference tree; factory and criteria at solve.cpp:456-478,571-652):
+ *   r = b - A x ; stop when ||r|| <= rtol*||r_initial|| or after max_iters
+ *   updates (stop::Combined of Iteration and ResidualNormReduction).
+ * precond: OR_PRECOND_NONE or OR_PRECOND_JACOBI (= block-Jacobi with
+ * max_block_size 1, solve.cpp:575-589). */
+int schwz_or_pcg(int64_t n, const or_idx *rp, const or_idx *col,
+                 const double *val, const double *b, double *x, int precond,
+                 double rtol, int max_iters, double *final_resnorm)
+{
+    double *r = (double *)xmalloc(sizeof(double) * (size_t)n);
+    double *z = (double *)xmalloc(sizeof(double) * (size_t)n);
+    double *p = (double *)xmalloc(sizeof(double) * (size_t)n);
+    double *q = (double *)xmalloc(sizeof(double) * (size_t)n);
+    double *dinv = NULL;
+    if (precond == OR_PRECOND_JACOBI) {
+        dinv = (double *)xmalloc(sizeof(double) * (size_t)n);
+        for (int64_t i = 0; i < n; ++i) {
+            double d = 1.0;
+            for (or_idx j = rp[i]; j < rp[i + 1]; ++j)
+                if (col[j] == i) d = val[j];
+            dinv[i] = 1.0 / d;
+        }
+    }
+    memcpy(r, b, sizeof(double) * (size_t)n);
+    schwz_or_spmv(n, rp, col, val, -1.0, x, 1.0, r);
+    double rr = dot(n, r, r);
+    const double r0 = sqrt(rr);
+    double rho = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : rho) if (n > OMP_MIN_N)
+    for (int64_t i = 0; i < n; ++i) {
+        z[i] = dinv ? dinv[i] * r[i] : r[i];
+        p[i] = z[i];
+        rho += r[i] * z[i];
+    }
+    int it = 0;
+    for (; it < max_iters; ++it) {
+        if (sqrt(rr) <= rtol * r0) break;
+        schwz_or_spmv(n, rp, col, val, 1.0, p, 0.0, q);
+        double pq = dot(n, p, q);
+        double alpha = rho / pq;
+        double rho_new = 0.0, rr_new = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : rho_new, rr_new) if (n > OMP_MIN_N)
+        for (int64_t i = 0; i < n; ++i) {
+            x[i] += alpha * p[i];
+            r[i] -= alpha * q[i];
+            z[i] = dinv ? dinv[i] * r[i] : r[i];
+            rho_new += r[i] * z[i];
+            rr_new += r[i] * r[i];
+        }
+        double beta = rho_new / rho;
+#pragma omp parallel for schedule(static) if (n > OMP_MIN_N)
+        for (int64_t i = 0; i < n; ++i) p[i] = z[i] + beta * p[i];
+        rho = rho_new;
+        rr = rr_new;
+    }
+    if (final_resnorm) *final_resnorm = sqrt(rr);
+    free(r);
+    free(z);
+    free(p);
+    free(q);
+    free(dinv);
+    return it;
+}
+
+/* ---- sparse LL^T (stands in for CHOLMOD simplicial LL^T, solve.cpp:92-143) -- */
+
+/* reverse Cuthill-McKee on the pattern of A (fill-reducing ordering; CHOLMOD
+ * would pick AMD -- the solution does not depend on the choice). */
+static void rcm_order(int64_t n, const or_idx *rp, const or_idx *col, or_idx *perm)
+{
+    or_idx *deg = (or_idx *)xmalloc(sizeof(or_idx) * (size_t)n);
+    char *seen = (char *)xcalloc((size_t)n, 1);
+    or_idx *nb = (or_idx *)xmalloc(sizeof(or_idx) * (size_t)n);
+    for (int64_t i = 0; i < n; ++i) deg[i] = rp[i + 1] - rp[i];
+    int64_t head = 0, tail = 0;
+    while (tail < n) {
+        /* unseen node of minimum degree starts a component */
+        or_idx s = -1;
+        for (int64_t i = 0; i < n; ++i)
+            if (!seen[i] && (s < 0 || deg[i] < deg[s])) s = (or_idx)i;
+        seen[s] = 1;
+        perm[tail++] = s;
+        while (head < tail) {
+            or_idx u = perm[head++];
+            or_idx cnt = 0;
+            for (or_idx j = rp[u]; j < rp[u + 1]; ++j) {
+                or_idx v = col[j];
+                if (v != u && !seen[v]) {
+                    seen[v] = 1;
+                    nb[cnt++] = v;
+                }
+            }
+            /* ascending degree, ties by index (insertion sort) */
+            for (or_idx a = 1; a < cnt; ++a) {
+                or_idx v = nb[a];
+                or_idx b2 = a;
+                while (b2 > 0 && (deg[nb[b2 - 1]] > deg[v] ||
+                                  (deg[nb[b2 - 1]] == deg[v] && nb[b2 - 1] > v))) {
+                    nb[b2] = nb[b2 - 1];
+                    --b2;
+                }
+                nb[b2] = v;
+            }
+            for (or_idx a = 0; a < cnt; ++a) perm[tail++] = nb[a];
+        }
+    }
+    for (int64_t i = 0; i < n / 2; ++i) {
+        or_idx t = perm[i];
+        perm[i] = perm[n - 1 - i];
+        perm[n - 1 - i] = t;
+    }
+    free(deg);
+    free(seen);
+    free(nb);
+}
+
+/* Up-looking Cholesky with an elimination tree.  Identity
+ * A(perm,perm) = L L^T; U = L^T is produced as the CSC arrays of L
+ * reinterpreted as CSR (solve.cpp:288-298), L as its transpose (:300-304). */
+int schwz_or_cholesky(int64_t n, const or_idx *rp, const or_idx *col,
+                      const double *val, int natural, or_idx **l_rp_o,
+                      or_idx **l_col_o, double **l_val_o, or_idx **u_rp_o,
+                      or_idx **u_col_o, double **u_val_o, or_idx **perm_o)
+{
+    or_idx *perm = (or_idx *)xmalloc(sizeof(or_idx) * (size_t)n);
+    or_idx *iperm = (or_idx *)xmalloc(sizeof(or_idx) * (size_t)n);
+    if (natural)
+        for (int64_t i = 0; i < n; ++i) perm[i] = (or_idx)i;
+    else
+        rcm_order(n, rp, col, perm);
+    for (int64_t i = 0; i < n; ++i) iperm[perm[i]] = (or_idx)i;
+
+    /* B = strictly-lower + diag part of A(perm,perm), row k sorted ascending */
+    or_idx *b_rp = (or_idx *)xcalloc((size_t)n + 1, sizeof(or_idx));
+    for (int64_t k = 0; k < n; ++k) {
+        or_idx cnt = 0;
+        for (or_idx j = rp[perm[k]]; j < rp[perm[k] + 1]; ++j)
+            if (iperm[col[j]] <= k) ++cnt;
+        b_rp[k + 1] = b_rp[k] + cnt;
+    }
+    or_idx *b_col = (or_idx *)xmalloc(sizeof(or_idx) * (size_t)b_rp[n]);
+    double *b_val = (double *)xmalloc(sizeof(double) * (size_t)b_rp[n]);
+    for (int64_t k = 0; k < n; ++k) {
+        or_idx pos = b_rp[k];
+        for (or_idx j = rp[perm[k]]; j < rp[perm[k] + 1]; ++j) {
+            if (iperm[col[j]] <= k) {
+                b_col[pos] = iperm[col[j]];
+                b_val[pos] = val[j];
+                ++pos;
+            }
+        }
+        sort_row(b_col + b_rp[k], b_val + b_rp[k], b_rp[k + 1] - b_rp[k]);
+    }
+    /* elimination tree */
+    or_idx *parent = (or_idx *)xmalloc(sizeof(or_idx) * (size_t)n);
+    or_idx *anc = (or_idx *)xmalloc(sizeof(or_idx) * (size_t)n);
+    for (int64_t k = 0; k < n; ++k) {
+        parent[k] = -1;
+        anc[k] = -1;
+        for (or_idx j = b_rp[k]; j < b_rp[k + 1]; ++j) {
+            or_idx i = b_col[j];
+            while (i != -1 && i < k) {
+                or_idx nx = anc[i];
+                anc[i] = (or_idx)k;
+                if (nx == -1) parent[i] = (or_idx)k;
+                i = nx;
+            }
+        }
+    }
+    /* symbolic: column counts through row reaches */
+    or_idx *mark = (or_idx *)xmalloc(sizeof(or_idx) * (size_t)n);
+    or_idx *cc = (or_idx *)xcalloc((size_t)n + 1, sizeof(or_idx));
+    for (int64_t k = 0; k < n; ++k) mark[k] = -1;
+    for (int64_t k = 0; k < n; ++k) {
+        mark[k] = (or_idx)k;
+        cc[k]++; /* diagonal */
+        for (or_idx j = b_rp[k]; j < b_rp[k + 1]; ++j) {
+            or_idx i = b_col[j];
+            while (i != -1 && i < k && mark[i] != k) {
+                mark[i] = (or_idx)k;
+                cc[i]++;
+                i = parent[i];
+            }
+        }
+    }
+    or_idx *cp = (or_idx *)xmalloc(sizeof(or_idx) * ((size_t)n + 1)); /* CSC ptr of L */
+    cp[0] = 0;
+    for (int64_t k = 0; k < n; ++k) cp[k + 1] = cp[k] + cc[k];
+    const int64_t lnz = cp[n];
+    or_idx *ci = (or_idx *)xmalloc(sizeof(or_idx) * (size_t)lnz);
+    double *cx = (double *)xmalloc(sizeof(double) * (size_t)lnz);
+    or_idx *fill = (or_idx *)xmalloc(sizeof(or_idx) * (size_t)n); /* next free slot */
+    for (int64_t k = 0; k < n; ++k) fill[k] = cp[k];
+    double *x = (double *)xcalloc((size_t)n, sizeof(double));
+    or_idx *stack = (or_idx *)xmalloc(sizeof(or_idx) * (size_t)n);
+    or_idx *path = (or_idx *)xmalloc(sizeof(or_idx) * (size_t)n);
+    for (int64_t k = 0; k < n; ++k) mark[k] = -1;
+    int status = 0;
+    for (int64_t k = 0; k < n; ++k) {
+        /* reach of row k in topological order (stack filled from the top) */
+        or_idx top = (or_idx)n;
+        mark[k] = (or_idx)k;
+        double d = 0.0;
+        for (or_idx j = b_rp[k]; j < b_rp[k + 1]; ++j) {
+            or_idx i = b_col[j];
+            if (i == k) {
+                d = b_val[j];
+                continue;
+            }
+            x[i] = b_val[j];
+            or_idx len = 0;
+            while (mark[i] != k) {
+                path[len++] = i;
+                mark[i] = (or_idx)k;
+                i = parent[i];
+            }
+            while (len > 0) stack[--top] = path[--len];
+        }
+        for (or_idx t = top; t < n; ++t) {
+            or_idx i = stack[t];
+            double lki = x[i] / cx[cp[i]]; /* L(i,i) is first in column i */
+            x[i] = 0.0;
+            for (or_idx pz = cp[i] + 1; pz < fill[i]; ++pz) x[ci[pz]] -= cx[pz] * lki;
+            d -= lki * lki;
+            ci[fill[i]] = (or_idx)k;
+            cx[fill[i]] = lki;
+            fill[i]++;
+        }
+        if (d <= 0.0) {
+            status = -1; /* not SPD */
+            d = 1.0;
+        }
+        ci[fill[k]] = (or_idx)k;
+        cx[fill[k]] = sqrt(d);
+        fill[k]++;
+    }
+    /* U (CSR) = CSC of L; L (CSR) = transpose */
+    or_idx *l_rp = (or_idx *)xcalloc((size_t)n + 1, sizeof(or_idx));
+    or_idx *l_col = (or_idx *)xmalloc(sizeof(or_idx) * (size_t)lnz);
+    double *l_val = (double *)xmalloc(sizeof(double) * (size_t)lnz);
+    for (int64_t pz = 0; pz < lnz; ++pz) l_rp[ci[pz] + 1]++;
+    for (int64_t k = 0; k < n; ++k) l_rp[k + 1] += l_rp[k];
+    for (int64_t k = 0; k < n; ++k) fill[k] = l_rp[k];
+    for (int64_t c = 0; c < n; ++c) {
+        for (or_idx pz = cp[c]; pz < cp[c + 1]; ++pz) {
+            or_idx row = ci[pz];
+            l_col[fill[row]] = (or_idx)c;
+            l_val[fill[row]] = cx[pz];
+            fill[row]++;
+        }
+    }
+    *l_rp_o = l_rp;
+    *l_col_o = l_col;
+    *l_val_o = l_val;
+    *u_rp_o = cp;
+    *u_col_o = ci;
+    *u_val_o = cx;
+    *perm_o = perm;
+    free(iperm);
+    free(b_rp);
+    free(b_col);
+    free(b_val);
+    free(parent);
+    free(anc);
+    free(mark);
+    free(cc);
+    free(fill);
+    free(x);
+    free(stack);
+    free(path);
+    return status;
+}
+
+/* solve.cpp:709-720 + solver_tools.hpp:69-87:
+ *   perm_sol = b[perm]  (Permutation row_permute: out[i] = in[perm[i]])
+ *   L t = perm_sol ; U perm_sol = t ; y[perm[i]] = perm_sol[i] */
+void schwz_or_direct_solve(int64_t n, const or_idx *l_rp, const or_idx *l_col,
+                           const double *l_val, const or_idx *u_rp,
+                           const or_idx *u_col, const double *u_val,
+                           const or_idx *perm, const double *b, double *y,
+                           double *w)
+{
+    double *ps = w, *t = w + n;
+    for (int64_t i = 0; i < n; ++i) ps[i] = b[perm[i]];
+    for (int64_t i = 0; i < n; ++i) { /* lower, diagonal last in row */
+        double s = ps[i];
+        or_idx e = l_rp[i + 1] - 1;
+        for (or_idx j = l_rp[i]; j < e; ++j) s -= l_val[j] * t[l_col[j]];
+        t[i] = s / l_val[e];
+    }
+    for (int64_t i = n - 1; i >= 0; --i) { /* upper, diagonal first in row */
+        double s = t[i];
+        for (or_idx j = u_rp[i] + 1; j < u_rp[i + 1]; ++j) s -= u_val[j] * ps[u_col[j]];
+        ps[i] = s / u_val[u_rp[i]];
+    }
+    for (int64_t i = 0; i < n; ++i) y[perm[i]] = ps[i];
+}
+
+/* ======================================================================== */
+/* per-subdomain state and the five loop steps                               */
+/* ======================================================================== */
+
+struct or_state {
+    or_subdomain *sd;
+    or_settings s;
+    double *global_solution; /* N (schwarz_base.cpp:340-341), zero (F9) */
+    double *local_rhs;       /* local_size_x (initialization.cpp:349-355) */
+    double *local_solution;  /* local_size_x */
+    double *init_guess;      /* local_size_x, zero (F9) */
+    double *work;            /* 2*local_size_x (schwarz_base.cpp:349-350) */
+    int64_t *send_off, *recv_off;
+    /* direct path */
+    or_idx *l_rp, *l_col, *u_rp, *u_col, *perm;
+    double *l_val, *u_val;
+    int last_inner;
+};
+
+or_state *schwz_or_state_create(or_subdomain *sd, const double *rhs, const or_settings *s)
+{
+    or_state *st = (or_state *)xcalloc(1, sizeof(*st));
+    st->sd = sd;
+    st->s = *s;
+    const or_idx n = sd->local_size_x;
+    st->global_solution = (double *)xcalloc((size_t)sd->N, sizeof(double));
+    st->local_rhs = (double *)xmalloc(sizeof(double) * (size_t)(n ? n : 1));
+    st->local_solution = (double *)xcalloc((size_t)n, sizeof(double));
+    st->init_guess = (double *)xcalloc((size_t)n, sizeof(double));
+    st->work = (double *)xcalloc((size_t)2 * n, sizeof(double));
+    /* extract_local_vector (solver_tools.hpp:102-116): contiguous interior,
+     * then gather over overlap_row */
+    memcpy(st->local_rhs, rhs + sd->first_row[sd->me], sizeof(double) * (size_t)sd->local_size);
+    schwz_or_gather(sd->overlap_size, sd->local_to_global + sd->local_size, rhs,
+                    st->local_rhs + sd->local_size, 1);
+    if (s->local_solver == OR_SOLVER_DIRECT) {
+        if (schwz_or_cholesky(n, sd->l_rp, sd->l_col, sd->l_val, s->natural_factor_ordering,
+                              &st->l_rp, &st->l_col, &st->l_val, &st->u_rp, &st->u_col,
+                              &st->u_val, &st->perm) != 0) {
+            fprintf(stderr, "schwz_oracle: local matrix not SPD\n");
+        }
+    }
+    return st;
+}
+
+void schwz_or_state_free(or_state *st)
+{
+    if (!st) return;
+    free(st->global_solution);
+    free(st->local_rhs);
+    free(st->local_solution);
+    free(st->init_guess);
+    free(st->work);
+    free(st->l_rp);
+    free(st->l_col);
+    free(st->l_val);
+    free(st->u_rp);
+    free(st->u_col);
+    free(st->u_val);
+    free(st->perm);
+    free(st);
+}
+
+double *schwz_or_state_global_solution(or_state *st) { return st->global_solution; }
+double *schwz_or_state_local_solution(or_state *st) { return st->local_solution; }
+const double *schwz_or_state_local_rhs(or_state *st) { return st->local_rhs; }
+int schwz_or_state_factors(or_state *st, const or_idx **l_rp, const or_idx **l_col,
+                           const double **l_val, const or_idx **u_rp, const or_idx **u_col,
+                           const double **u_val, const or_idx **perm)
+{
+    if (!st->l_rp) return -1;
+    *l_rp = st->l_rp;
+    *l_col = st->l_col;
+    *l_val = st->l_val;
+    *u_rp = st->u_rp;
+    *u_col = st->u_col;
+    *u_val = st->u_val;
+    *perm = st->perm;
+    return 0;
+}
+
+/* restricted_schwarz.cpp:884-911: send[i] = global_solution[global_put[k][1+i]] */
+void schwz_or_pack(or_state *st, int k, double *send)
+{
+    const or_idx *lst = st->sd->put[k];
+    schwz_or_gather(lst[0], lst + 1, st->global_solution, send, 1);
+}
+
+/* restricted_schwarz.cpp:950-962: global_solution[global_get[k][1+i]] = recv[i] */
+void schwz_or_unpack(or_state *st, int k, const double *recv)
+{
+    const or_idx *lst = st->sd->get[k];
+    schwz_or_scatter(lst[0], lst + 1, recv, st->global_solution, 1);
+}
+
+/* restricted_schwarz.cpp:992-1017: local_solution = local_rhs - A_Gamma * x~.
+ * The interface matrix keeps GLOBAL column ids and is applied to
+ * global_solution (:1008-1015). */
+void schwz_or_update_boundary(or_state *st)
+{
+    or_subdomain *sd = st->sd;
+    const or_idx n = sd->local_size_x;
+    memcpy(st->local_solution, st->local_rhs, sizeof(double) * (size_t)n);
+    if (sd->P > 1 && st->s.overlap > 0 && sd->nnz_interface > 0)
+        schwz_or_spmv(n, sd->i_rp, sd->i_col, sd->i_val, -1.0, st->global_solution, 1.0,
+                      st->local_solution);
+}
+
+/* solve.cpp:796-856: r = b~ - A_loc [x~_int ; x~_ovl], returns ||r||_2 */
+double schwz_or_local_residual(or_state *st)
+{
+    or_subdomain *sd = st->sd;
+    const or_idx n = sd->local_size_x;
+    double *local_b = st->work, *local_x = st->work + n;
+    memcpy(local_b, st->local_solution, sizeof(double) * (size_t)n);
+    memcpy(local_x, st->global_solution + sd->first_row[sd->me],
+           sizeof(double) * (size_t)sd->local_size);
+    schwz_or_gather(sd->overlap_size, sd->local_to_global + sd->local_size,
+                    st->global_solution, local_x + sd->local_size, 1);
+    schwz_or_spmv(n, sd->l_rp, sd->l_col, sd->l_val, -1.0, local_x, 1.0, local_b);
+    return sqrt(dot(n, local_b, local_b));
+}
+
+/* solve.cpp:667-792 */
+int schwz_or_local_solve(or_state *st)
+{
+    or_subdomain *sd = st->sd;
+    const or_idx n = sd->local_size_x;
+    if (st->s.local_solver == OR_SOLVER_DIRECT) {
+        /* :709-720 ; result lands in local_solution */
+        double *tmp = (double *)xmalloc(sizeof(double) * (size_t)(n ? n : 1));
+        schwz_or_direct_solve(n, st->l_rp, st->l_col, st->l_val, st->u_rp, st->u_col,
+                              st->u_val, st->perm, st->local_solution, tmp, st->work);
+        memcpy(st->local_solution, tmp, sizeof(double) * (size_t)n);
+        free(tmp);
+        st->last_inner = 0;
+        return 0;
+    }
+    /* :721-781 : solver->apply(rhs=local_solution, x=init_guess) with the
+     * warm start kept across outer iterations; local_solution <- init_guess */
+    int maxit = st->s.local_max_iters == -1 ? (int)n : st->s.local_max_iters;
+    int it = schwz_or_pcg(n, sd->l_rp, sd->l_col, sd->l_val, st->local_solution,
+                          st->init_guess, st->s.precond, st->s.local_tol, maxit, NULL);
+    memcpy(st->local_solution, st->init_guess, sizeof(double) * (size_t)n);
+    st->last_inner = it;
+    return it;
+}
+
+/* communicate.cpp:65-94 (solution_based branch, :91-93) */
+void schwz_or_restrict(or_state *st)
+{
+    or_subdomain *sd = st->sd;
+    memcpy(st->global_solution + sd->first_row[sd->me], st->local_solution,
+           sizeof(double) * (size_t)sd->local_size);
+}
+
+/* ======================================================================== */
+/* whole run, all subdomains in lockstep                                     */
+/* ======================================================================== */
+
+/* schwarz_base.cpp:387-452 with solve.cpp:959-1005 (check_convergence) and
+ * solve.cpp:860-955 (check_global_convergence).  Returns 0, or -1 on
+ * divergence (the reference calls std::exit(-1), schwarz_base.cpp:424-428). */
+int schwz_or_ras_run(int64_t N, const or_idx *rp, const or_idx *col,
+                     const double *val, const double *rhs, int P,
+                     const or_idx *first_row, const or_settings *s,
+                     double *solution, double *hist_global, double *hist_local,
+                     int32_t *hist_inner, or_result *res)
+{
+#ifdef _OPENMP
+    if (s->num_threads > 0) omp_set_num_threads(s->num_threads);
+#endif
+    double t_setup = now_s();
+    or_subdomain **sd = (or_subdomain **)xcalloc((size_t)P, sizeof(*sd));
+    or_state **st = (or_state **)xcalloc((size_t)P, sizeof(*st));
+    for (int p = 0; p < P; ++p)
+        sd[p] = schwz_or_subdomain_setup(N, rp, col, val, P, p, s->overlap, first_row);
+    /* handshake restricted_schwarz.cpp:400-472: q's get list for p => p's put list for q */
+    for (int p = 0; p < P; ++p)
+        for (int q = 0; q < P; ++q) {
+            if (q == p) continue;
+            for (int k = 0; k < sd[q]->n_in; ++k)
+                if (sd[q]->nbr_in[k] == p)
+                    schwz_or_sd_add_put_list(sd[p], q, sd[q]->get[k][0], sd[q]->get[k] + 1);
+        }
+    for (int p = 0; p < P; ++p) st[p] = schwz_or_state_create(sd[p], rhs, s);
+    int64_t maxbuf = 1;
+    for (int p = 0; p < P; ++p)
+        for (int k = 0; k < sd[p]->n_out; ++k)
+            if (sd[p]->put[k][0] > maxbuf) maxbuf = sd[p]->put[k][0];
+    /* one message buffer per (sender, receiver) pair so that all sends of an
+     * iteration are gathered before any scatter (message semantics) */
+    double **msg = (double **)xcalloc((size_t)P * P, sizeof(double *));
+    for (int p = 0; p < P; ++p)
+        for (int k = 0; k < sd[p]->n_out; ++k)
+            msg[(size_t)p * P + sd[p]->nbr_out[k]] =
+                (double *)xmalloc(sizeof(double) * (size_t)sd[p]->put[k][0]);
+    res->setup_s = now_s() - t_setup;
+
+    double *lres = (double *)xcalloc((size_t)P, sizeof(double));
+    double *lres0 = (double *)xmalloc(sizeof(double) * (size_t)P);
+    char *flag = (char *)xcalloc((size_t)P, 1);
+    for (int p = 0; p < P; ++p) lres0[p] = -1.0;
+    double gres = 0.0, gres0 = -1.0;
+    int num_converged = 0, iter = 0, rc = 0;
+    const double tol = s->tol;
+    double t0 = now_s();
+    for (; iter < s->max_iters; ++iter) {
+        /* 0 exchange (one-sided mode skips iteration 0, restricted_schwarz.cpp:725) */
+        if (!(s->enable_onesided && iter == 0)) {
+            for (int p = 0; p < P; ++p)
+                for (int k = 0; k < sd[p]->n_out; ++k)
+                    schwz_or_pack(st[p], k, msg[(size_t)p * P + sd[p]->nbr_out[k]]);
+            for (int p = 0; p < P; ++p)
+                for (int k = 0; k < sd[p]->n_in; ++k)
+                    schwz_or_unpack(st[p], k, msg[(size_t)sd[p]->nbr_in[k] * P + p]);
+        }
+        /* 1 update boundary */
+        for (int p = 0; p < P; ++p) schwz_or_update_boundary(st[p]);
+        /* 2 convergence */
+        int nan_seen = 0;
+        for (int p = 0; p < P; ++p) {
+            lres[p] = -1.0;
+            if (tol >= 0.0) {
+                lres[p] = schwz_or_local_residual(st[p]);
+                if (lres0[p] < 0.0) lres0[p] = lres[p];
+            }
+            if (isnan(lres[p])) nan_seen = 1;
+            if (hist_local) hist_local[(size_t)iter * P + p] = lres[p];
+        }
+        if (nan_seen) {
+            rc = -1;
+            break;
+        }
+        int iter_cond = s->global_check_iter_offset
+                            ? ((iter > s->max_iters * 0.05) || s->max_iters < 1000)
+                            : 1;
+        if (tol > 0.0 && iter_cond) {
+            if (s->enable_global_check && !s->enable_onesided) {
+                /* solve.cpp:890-911: G = SUM of local norms (F12) */
+                gres = 0.0;
+                for (int p = 0; p < P; ++p) gres += lres[p];
+                if (gres0 < 0.0) gres0 = gres;
+                num_converged = (gres / gres0 <= tol) ? P : 0;
+            } else if (s->enable_onesided) {
+                /* solve.cpp:913-915 local test + monotone flags
+                 * (conv_tools.hpp:249-251), zero propagation delay */
+                num_converged = 0;
+                for (int p = 0; p < P; ++p) {
+                    if (lres[p] / lres0[p] <= tol) flag[p] = 1;
+                    num_converged += flag[p];
+                }
+            } else {
+                num_converged = 0; /* F11: never converges on this branch */
+            }
+        }
+        if (hist_global) hist_global[iter] = gres;
+        if (isnan(gres) || gres > 1e12) {
+            rc = -1;
+            break;
+        }
+        if (num_converged == P) break;
+        /* 3 local solve, 4 restrict */
+        for (int p = 0; p < P; ++p) {
+            int it = schwz_or_local_solve(st[p]);
+            if (hist_inner) hist_inner[(size_t)iter * P + p] = it;
+            schwz_or_restrict(st[p]);
+        }
+    }
+    res->elapsed_s = now_s() - t0;
+    res->iter_count = iter;
+    res->converged = (num_converged == P);
+    /* solve.cpp:1025-1085: assemble interiors, ||b||, ||x||, ||b - A x|| */
+    for (int p = 0; p < P; ++p)
+        memcpy(solution + first_row[p], st[p]->global_solution + first_row[p],
+               sizeof(double) * (size_t)sd[p]->local_size);
+    {
+        double *r = (double *)xmalloc(sizeof(double) * (size_t)N);
+        memcpy(r, rhs, sizeof(double) * (size_t)N);
+        res->rhs_norm = sqrt(dot(N, rhs, rhs));
+        res->sol_norm = sqrt(dot(N, solution, solution));
+        schwz_or_spmv(N, rp, col, val, -1.0, solution, 1.0, r);
+        res->residual_norm = sqrt(dot(N, r, r));
+        free(r);
+    }
+    for (int i = 0; i < P * P; ++i) free(msg[i]);
+    free(msg);
+    for (int p = 0; p < P; ++p) {
+        schwz_or_state_free(st[p]);
+        schwz_or_subdomain_free(sd[p]);
+    }
+    free(sd);
+    free(st);
+    free(lres);
+    free(lres0);
+    free(flag);
+    (void)maxbuf;
+    return rc;
+}
