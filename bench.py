@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- RAS iterations/sec of the MI355X hot path on the 3-D Poisson problem.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one outer iteration of SchwarzBase::run (schwarz_base.cpp:387-452):
+halo exchange -> boundary update -> convergence check (local residual SpMV +
+all-gather of the norms) -> local solve -> restricted write-back, at the
+fixed-work operating point of SURVEY 8(d)(i): CG + scalar Jacobi, exactly
+`--inner` CG iterations per local solve (local_tol = 0).
+
+N = 1 : BASELINE.json configs[1], 3-D Poisson 256^3, one subdomain on one GPU.
+N > 1 : weak scaling with the same 16.8 M rows per GPU: grid 512 x 512 x 64N,
+        z-slab partition (regular), overlap 2, RCCL halo exchange; N = 8 is
+        BASELINE.json configs[2] (512^3, 8 subdomains).
+value = N * (outer iterations / s): subdomain-iterations per second, whole job.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "schwarz-lib_amd"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--inner", type=int, default=10, help="CG iterations per local solve")
+    ap.add_argument("--size", type=int, default=256, help="1-GPU grid edge (256 = configs[1])")
+    ap.add_argument("--spmv-variant", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ttr", action="store_true", help="skip the time-to-residual run")
+    ap.add_argument("--cpu-iters", type=int, default=3, help="outer iterations of the CPU sample")
+    return ap.parse_args()
+
+
+def make_solver(schwz, comm, shape, inner, tol, max_iters, local_tol, variant, quiet=True):
+    s = schwz.Settings(laplacian_dim=3, laplacian_shape=shape, overlap=2,
+                       partition=schwz.PARTITION_REGULAR, spmv_variant=variant)
+    s.convergence_settings.enable_global_check = True
+    m = schwz.Metadata(tolerance=tol, max_iters=max_iters, local_precond="block-jacobi",
+                       precond_max_block_size=1, local_solver_tolerance=local_tol,
+                       local_max_iters=inner, num_subdomains=comm.size)
+    solver = schwz.SolverRAS(s, m, comm=comm, quiet=quiet)
+    solver.initialize()
+    return solver, m
+
+
+def cpu_baseline(shape, inner, iters):
+    """The oracle (CPU restatement, kind 'port') on a bounded sample of the same
+    workload: the same grid and settings, `iters` outer iterations."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import oracle as O
+    cores = os.cpu_count() or 1
+    rp, col, val = O.laplacian3d(*shape)
+    N = len(rp) - 1
+    st = O.make_settings(max_iters=iters, tol=1e-30, precond=O.PRECOND_JACOBI, local_tol=0.0,
+                         local_max_iters=inner, num_threads=cores)
+    r = O.ras_run(rp, col, val, np.ones(N), 1, O.first_rows_regular(N, 1), st, history=False)
+    return dict(value=r["iter_count"] / r["elapsed_s"], unit="subdomain-iter/s", cores=cores,
+                kind="port",
+                sample="%d outer iterations of the same %dx%dx%d workload (1 subdomain, %d CG "
+                       "iterations each), OpenMP oracle, %.1f s" %
+                       (r["iter_count"], shape[0], shape[1], shape[2], inner, r["elapsed_s"]))
+
+
+def main():
+    a = parse()
+    import torch
+    import schwz_amd as schwz
+    N = a.gpus
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if N > 1 or world > 1:
+        import torch.distributed as dist
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        comm = schwz.TorchDistComm(device=torch.device("cuda", local_rank))
+        comm.device_index = local_rank
+        assert comm.size == N, "--gpus must equal the launched world size"
+        shape = (512, 512, 64 * N)
+        workload = "3D Poisson 512x512x%d, %d z-slab subdomains (16.8M rows/GPU), overlap 2" % (64 * N, N)
+    else:
+        comm = schwz.InProcessComm(1)
+        shape = (a.size, a.size, a.size)
+        workload = "3D Poisson %d^3, 1 subdomain on 1 MI355X (BASELINE configs[1])" % a.size
+    rank = comm.rank
+
+    t_setup = time.perf_counter()
+    solver, m = make_solver(schwz, comm, shape, a.inner, 1e-30, a.warmup + a.steps + 2, 0.0,
+                            a.spmv_variant)
+    setup_s = time.perf_counter() - t_setup
+    sd = solver.subdomains[comm.local_ranks[0]]
+    solver.begin_run()
+    for _ in range(a.warmup):
+        solver.step()
+    torch.cuda.synchronize()
+    comm.barrier()
+    schwz.capi.check(schwz.capi.lib.schwz_profile_begin(a.steps * a.inner + 8))
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        solver.step()
+    torch.cuda.synchronize()
+    comm.barrier()
+    elapsed = time.perf_counter() - t0
+    import ctypes
+    tot_ms, launches = ctypes.c_double(0.0), ctypes.c_int64(0)
+    schwz.capi.check(schwz.capi.lib.schwz_profile_end(ctypes.byref(tot_ms), ctypes.byref(launches)))
+    if N > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    iters_per_s = a.steps / elapsed
+    alg_spmv = sd.algorithmic_bytes(0)
+    avg_ms = tot_ms.value / max(launches.value, 1)
+    achieved = alg_spmv / (avg_ms * 1e-3) / 1e9 if launches.value else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            key = "%dx%dx%d" % shape
+            traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    hist = m.post_process_data["global_residual_vector_out"]
+    line = {
+        "metric": "RAS iterations/sec (3D Poisson; subdomain-iterations aggregated over GPUs)",
+        "value": N * iters_per_s,
+        "unit": "subdomain-iter/s",
+        "n_gpus": N,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": 1e3 * elapsed / a.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic (7-point Dirichlet Laplacian generated in place, rhs = 1, x0 = 0)",
+        "config": {"workload": workload, "inner_cg_iters": a.inner, "precond": "jacobi",
+                   "local_tol": 0.0, "overlap": 2, "partition": "regular",
+                   "rows_per_gpu": sd.local_size_x, "nnz_per_gpu": sd.nnz_local,
+                   "spmv_variant": a.spmv_variant},
+        "ras_iters_per_s": iters_per_s,
+        "setup_s": setup_s,
+        "residual_reduction_in_timed_steps": (sum(h[-1] for h in hist) / sum(h[0] for h in hist))
+        if hist and hist[0] else None,
+        "roofline": {"kernel": "spmv_tiled_kernel<kSpmvDot> (q = A p, fused p.q)", "bound": "hbm",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": alg_spmv, "launches": launches.value,
+                     "avg_launch_ms": avg_ms},
+    }
+    # time-to-residual(1e-6) at the authors' inexact setting (SURVEY 8d ii)
+    if not a.no_ttr:
+        del solver
+        torch.cuda.empty_cache()
+        s2, m2 = make_solver(schwz, comm, shape, 70, 1e-6, 2000, 0.1, a.spmv_variant)
+        out = s2.run(gather_solution=False)
+        line["time_to_residual_1e-6_s"] = out["elapsed"]
+        line["time_to_residual_iters"] = out["iter_count"]
+        line["time_to_residual_converged"] = out["converged"]
+        line["true_relative_residual"] = out["residual_norm"] / out["rhs_norm"]
+        del s2
+    if rank == 0 and N == 1 and not a.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(shape, a.inner, a.cpu_iters)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if N > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

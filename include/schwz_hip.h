@@ -1,0 +1,285 @@
+/*
+ * schwz_hip.h -- C ABI of libschwz_hip.so, the MI355X (gfx950) implementation of
+ * the Restricted Additive Schwarz hot path of pratikvn/schwarz-lib.
+ *
+ * Every entry point names the reference interface it replaces (paths relative
+ * to the reference checkout).  The reference itself is a C++ template library
+ * over Ginkgo types (no FFI); this header is the boundary a host layer binds:
+ * the C++ mirror of SolverRAS/SchwarzBase (schwarz-lib_amd/host/), the Python
+ * host used by bench.py/tests (schwarz-lib_amd/schwz_amd/), or the binding
+ * sketched in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / Ginkgo types.
+ *   - `d_` pointers are device (HBM) pointers, `h_` pointers are host pointers.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *     All device entry points are asynchronous on `stream` unless noted.
+ *   - values are fp64 (bench_ras.cpp:204 fixes BenchRas<double,int>), local
+ *     indices int32, global row ids int64 (1024^3 rows fit int32, global nnz
+ *     does not -- SURVEY F7).
+ *   - return value: SCHWZ_OK or an error code; schwz_last_error() holds the
+ *     message (the reference throws the Error hierarchy of
+ *     include/exception.hpp:42-210; the host mirrors re-throw from the code).
+ *   - there is NO CPU fallback: device entry points fail with SCHWZ_ERR_HIP
+ *     when no GPU is present.
+ */
+#ifndef SCHWZ_HIP_H
+#define SCHWZ_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t schwz_idx;
+typedef void *schwz_stream;
+
+enum schwz_status {
+    SCHWZ_OK = 0,
+    SCHWZ_ERR_INVALID = 1,         /* BadDimension / bad argument */
+    SCHWZ_ERR_HIP = 2,             /* CudaError equivalent (exception.hpp:133-152) */
+    SCHWZ_ERR_NOT_IMPLEMENTED = 3, /* NotImplemented (exception.hpp:81-96) */
+    SCHWZ_ERR_NOT_SPD = 4,         /* factorization failed */
+    SCHWZ_ERR_IO = 5,              /* matrix file missing (initialization.cpp:266-271) */
+    SCHWZ_ERR_DIVERGED = 6         /* NaN / >1e12 residual (schwarz_base.cpp:424-428) */
+};
+
+/* include/collective_common.hpp:36 */
+enum schwz_op { SCHWZ_OP_ADD = 0, SCHWZ_OP_COPY = 1, SCHWZ_OP_DIFF = 2, SCHWZ_OP_AVG = 3 };
+
+/* Settings::local_solver_settings (include/settings.hpp) as used by
+ * Solve::local_solve (source/solve.cpp:667-792) */
+enum schwz_local_solver { SCHWZ_SOLVER_ITERATIVE = 0, SCHWZ_SOLVER_DIRECT = 1 };
+/* metadata.local_precond (source/solve.cpp:486-652): "null" and
+ * "block-jacobi" with precond_max_block_size = 1 */
+enum schwz_precond { SCHWZ_PRECOND_NONE = 0, SCHWZ_PRECOND_JACOBI = 1 };
+
+const char *schwz_last_error(void);
+const char *schwz_version(void);
+/* number of visible HIP devices (0 on a CPU-only host; never fails) */
+int schwz_device_count(void);
+/* device_guard (include/device_guard.hpp:47-101): bind the calling thread */
+int schwz_set_device(int device);
+
+/* ------------------------------------------------------------------------ */
+/* 1. Stand-alone device kernels                                             */
+/* ------------------------------------------------------------------------ */
+
+/* Gather: into[i] = op(into[i], from[idx[i]])
+ * replaces gather_kernel + gather_{,add_,diff_,avg_}values
+ * (source/gather_kernel.cu:46-109, include/gather.hpp:70-142). */
+int schwz_gather(int64_t n, const schwz_idx *d_idx, const double *d_from,
+                 double *d_into, int op, schwz_stream stream);
+
+/* Scatter: into[idx[i]] = op(into[idx[i]], from[i])
+ * replaces scatter_kernel + launchers (source/scatter_kernel.cu:43-107,
+ * include/scatter.hpp:70-143).  avg follows the CPU definition (y+x)/2. */
+int schwz_scatter(int64_t n, const schwz_idx *d_idx, const double *d_from,
+                  double *d_into, int op, schwz_stream stream);
+
+/* CSR matrix resident in HBM, with the row-tile table the SpMV kernel needs.
+ * Replaces gko::matrix::Csr<double,int> on the device executor. */
+typedef struct schwz_csr schwz_csr;
+int schwz_csr_create(int64_t nrows, int64_t ncols, const schwz_idx *h_row_ptr,
+                     const schwz_idx *h_col, const double *h_val, schwz_csr **out);
+void schwz_csr_destroy(schwz_csr *A);
+int64_t schwz_csr_nnz(const schwz_csr *A);
+
+/* y = alpha*A*x + beta*y : gko Csr::apply(alpha,x,beta,y), call sites
+ * source/restricted_schwarz.cpp:1014-1015, source/solve.cpp:834-835,1079-1080.
+ * variant: 0 = default (LDS-staged row tiles), 1 = one-row-per-lane baseline. */
+int schwz_csr_spmv(const schwz_csr *A, double alpha, const double *d_x,
+                   double beta, double *d_y, int variant, schwz_stream stream);
+
+/* Preconditioned CG on A x = b, device resident (no per-iteration host sync).
+ * Replaces gko::solver::Cg + stop::Combined(Iteration, ResidualNormReduction)
+ * as configured in source/solve.cpp:456-478,571-652 and applied by
+ * SolverTools::solve_iterative_ginkgo (include/solver_tools.hpp:91-98).
+ * x is the warm start on entry.  rtol<=0 runs exactly max_iters updates.
+ * h_iters / h_resnorm (may be NULL) are written after an internal stream
+ * sync only when requested. */
+typedef struct schwz_pcg schwz_pcg;
+int schwz_pcg_create(const schwz_csr *A, int precond, schwz_pcg **out);
+void schwz_pcg_destroy(schwz_pcg *s);
+int schwz_pcg_solve(schwz_pcg *s, const double *d_b, double *d_x, double rtol,
+                    int max_iters, int *h_iters, double *h_resnorm,
+                    schwz_stream stream);
+
+/* Profiling hooks for bench.py's roofline leg: between begin and end, every
+ * launch of the dominant kernel (the CSR SpMV inside schwz_pcg_solve) is
+ * bracketed by a HIP event pair on its launch stream; end synchronises and
+ * returns the summed kernel time and the launch count.  Replaces nothing in
+ * the reference (its MEASURE_ELAPSED_FUNC_TIME, include/settings.hpp:508-523,
+ * times host calls without a device sync). */
+int schwz_profile_begin(int capacity);
+int schwz_profile_end(double *h_total_ms, int64_t *h_launches);
+
+/* Sparse triangular solves y = P^T L^-T L^-1 P b.
+ * Replaces gko::solver::LowerTrs/UpperTrs + Permutation::apply as used by
+ * Solve::local_solve (source/solve.cpp:709-720) and
+ * SolverTools::solve_direct_ginkgo (include/solver_tools.hpp:69-87); also the
+ * intent of the dead CusparseWrappers (include/cusparse_helpers.hpp:200-212).
+ * L: CSR lower, diagonal last in each row; U = L^T: CSR upper, diagonal first. */
+typedef struct schwz_trs schwz_trs;
+int schwz_trs_create(int64_t n, const schwz_idx *h_l_rp, const schwz_idx *h_l_col,
+                     const double *h_l_val, const schwz_idx *h_u_rp,
+                     const schwz_idx *h_u_col, const double *h_u_val,
+                     const schwz_idx *h_perm, schwz_trs **out);
+void schwz_trs_destroy(schwz_trs *t);
+int schwz_trs_solve(schwz_trs *t, const double *d_b, double *d_y, schwz_stream stream);
+
+/* ------------------------------------------------------------------------ */
+/* 2. Host-side setup (no GPU needed)                                        */
+/* ------------------------------------------------------------------------ */
+
+/* Global problem description: either an explicit CSR or an analytic stencil
+ * whose rows are produced on demand, so that no rank ever holds a global
+ * matrix (the reference replicates it, source/schwarz_base.cpp:142-147). */
+typedef struct schwz_problem schwz_problem;
+
+/* Initialize::setup_global_matrix, Laplacian branch
+ * (source/initialization.cpp:214-265): dim=2 is the reference's 5-point
+ * stencil on an nx*nx grid; dim=3 is the 7-point extension on nx*ny*nz. */
+int schwz_problem_laplacian(int dim, int64_t nx, int64_t ny, int64_t nz,
+                            schwz_problem **out);
+/* explicit CSR with int64 row_ptr (copied) */
+int schwz_problem_from_csr(int64_t N, const int64_t *h_row_ptr,
+                           const schwz_idx *h_col, const double *h_val,
+                           schwz_problem **out);
+/* Matrix-Market file branch (initialization.cpp:204-213): gko::read +
+ * sort_by_column_index */
+int schwz_problem_from_matrix_market(const char *path, schwz_problem **out);
+void schwz_problem_destroy(schwz_problem *p);
+int64_t schwz_problem_size(const schwz_problem *p);
+int64_t schwz_problem_nnz(const schwz_problem *p);
+/* copy one row out (count returned through *n; cols ascending) */
+int schwz_problem_row(const schwz_problem *p, int64_t row, int *n,
+                      int64_t *cols, double *vals, int capacity);
+/* Apply a partition vector: A <- A(perm,perm) with perm grouping rows by
+ * part id, stable within a part (source/restricted_schwarz.cpp:105-152).
+ * h_perm (new->old, length N) and first_row (P+1) are outputs. */
+int schwz_problem_permute(const schwz_problem *p, int P, const uint32_t *h_part,
+                          int64_t *h_perm, int64_t *h_first_row,
+                          schwz_problem **out);
+
+/* contiguous row blocks (source/restricted_schwarz.cpp:84,97-102) */
+int schwz_partition_regular(int64_t N, int P, int64_t *h_first_row);
+/* PartitionTools::PartitionRegular2D (include/partition_tools.hpp:70-106) */
+int schwz_partition_regular2d(int64_t n1d, int P, uint32_t *h_part);
+/* graph partition standing in for PartitionTools::PartitionMetis
+ * (include/partition_tools.hpp:110-202; METIS itself is absent): recursive
+ * BFS-level bisection of the matrix graph. */
+int schwz_partition_graph(const schwz_problem *p, int P, uint32_t *h_part);
+
+/* Subdomain: index sets, local/interface matrices, comm lists, device state.
+ * SolverRAS::setup_local_matrices (source/restricted_schwarz.cpp:56-304) and
+ * setup_comm_buffers (:308-604). */
+typedef struct schwz_subdomain schwz_subdomain;
+
+int schwz_subdomain_setup(const schwz_problem *p, int P, int me, int overlap,
+                          const int64_t *h_first_row, schwz_subdomain **out);
+void schwz_subdomain_destroy(schwz_subdomain *sd);
+
+/* sizes[0]=local_size [1]=local_size_x [2]=overlap_size [3]=halo_size
+ * [4]=nnz_local [5]=nnz_interface [6]=num_neighbors_in [7]=num_neighbors_out
+ * [8]=num_recv [9]=num_send  (Metadata fields, include/settings.hpp:318-496) */
+int schwz_subdomain_sizes(const schwz_subdomain *sd, int64_t *sizes10);
+/* local id -> global id, length local_size_x + halo_size */
+int schwz_subdomain_local_to_global(const schwz_subdomain *sd, int64_t *h_out);
+/* local_matrix / interface_matrix on the host (interface columns are
+ * returned as GLOBAL ids, like the reference stores them) */
+int schwz_subdomain_local_matrix(const schwz_subdomain *sd, schwz_idx *h_rp,
+                                 schwz_idx *h_col, double *h_val);
+int schwz_subdomain_interface_matrix(const schwz_subdomain *sd, schwz_idx *h_rp,
+                                     int64_t *h_col_global, double *h_val);
+/* comm_struct.neighbors_in / global_get (include/communicate.hpp:67-224):
+ * k-th in-neighbour; ids ascending global */
+int schwz_subdomain_get_list(const schwz_subdomain *sd, int k, int *rank,
+                             int64_t *count, int64_t *h_ids /* may be NULL */);
+/* the index handshake of restricted_schwarz.cpp:400-472: neighbour p's get
+ * list for me is my put list for p.  Add in ascending p. */
+int schwz_subdomain_add_put_list(schwz_subdomain *sd, int p, int64_t count,
+                                 const int64_t *h_ids);
+int schwz_subdomain_put_list(const schwz_subdomain *sd, int k, int *rank,
+                             int64_t *count, int64_t *h_ids /* may be NULL */);
+/* offsets of neighbour k inside the packed send / recv buffers (prefix sums in
+ * neighbour order, restricted_schwarz.cpp:870,909,913,940) */
+int schwz_subdomain_send_offset(const schwz_subdomain *sd, int k, int64_t *offset);
+int schwz_subdomain_recv_offset(const schwz_subdomain *sd, int k, int64_t *offset);
+
+/* Host sparse LL^T of the local matrix, standing in for CHOLMOD simplicial
+ * LL^T (Solve::compute_local_factors, source/solve.cpp:75-143): identity
+ * A(perm,perm) = L L^T.  Outputs are malloc'd; free with schwz_free. */
+int schwz_cholesky(int64_t n, const schwz_idx *h_rp, const schwz_idx *h_col,
+                   const double *h_val, int natural_ordering, schwz_idx **l_rp,
+                   schwz_idx **l_col, double **l_val, schwz_idx **u_rp,
+                   schwz_idx **u_col, double **u_val, schwz_idx **perm);
+void schwz_free(void *p);
+
+/* ------------------------------------------------------------------------ */
+/* 3. Device-resident RAS iteration of one subdomain                         */
+/* ------------------------------------------------------------------------ */
+
+typedef struct {
+    int32_t local_solver;    /* schwz_local_solver */
+    int32_t precond;         /* schwz_precond */
+    double local_tol;        /* metadata.local_solver_tolerance */
+    int32_t local_max_iters; /* -1 => local_size_x (solve.cpp:458-463) */
+    int32_t natural_factor_ordering; /* settings.naturally_ordered_factor */
+    int32_t spmv_variant;    /* 0 default */
+    int32_t reserved;
+} schwz_solver_options;
+
+/* Upload matrices / index lists, allocate x~=[interior|overlap|halo] (zero,
+ * SURVEY F9), local rhs, CG work vectors; factor on the host for the direct
+ * path.  h_local_rhs has local_size_x entries: [rhs[interior]; rhs[overlap_row]]
+ * (Initialize::setup_vectors, source/initialization.cpp:332-359).
+ * Requires all put lists to be set.  Binds to the current HIP device. */
+int schwz_subdomain_to_device(schwz_subdomain *sd, const double *h_local_rhs,
+                              const schwz_solver_options *opt);
+
+/* step 0a: send[off_k + i] = x~[put_k[i]] for every out-neighbour
+ * (exchange_boundary_twosided pack half, restricted_schwarz.cpp:884-911;
+ * CommHelpers::pack_buffer, include/comm_helpers.hpp:93-118).
+ * d_send has num_send entries. */
+int schwz_ras_pack(schwz_subdomain *sd, double *d_send, schwz_stream stream);
+/* step 0b: x~[get_k[i]] = recv[off_k + i] for every in-neighbour
+ * (restricted_schwarz.cpp:950-962; CommHelpers::unpack_buffer,
+ * include/comm_helpers.hpp:154-177).  d_recv has num_recv entries. */
+int schwz_ras_unpack(schwz_subdomain *sd, const double *d_recv, schwz_stream stream);
+/* step 1: b~ = b_loc - A_Gamma x~ (SolverRAS::update_boundary,
+ * restricted_schwarz.cpp:992-1017) */
+int schwz_ras_update_boundary(schwz_subdomain *sd, schwz_stream stream);
+/* step 2 (local half): rho = || b~ - A_loc [x~_int; x~_ovl] ||_2
+ * (Solve::check_local_convergence, source/solve.cpp:796-856).  The norm is
+ * written to *h_resnorm after a stream sync (the reference copies the scalar
+ * to the host at solve.cpp:842-843). */
+int schwz_ras_local_residual(schwz_subdomain *sd, double *h_resnorm, schwz_stream stream);
+/* step 3: y = solve(A_loc, b~), warm-started (Solve::local_solve,
+ * source/solve.cpp:667-792).  h_inner_iters may be NULL (no sync). */
+int schwz_ras_local_solve(schwz_subdomain *sd, int *h_inner_iters, schwz_stream stream);
+/* step 4: x~[interior] = y[0:local_size] (Communicate::local_to_global_vector,
+ * source/communicate.cpp:65-94) */
+int schwz_ras_restrict(schwz_subdomain *sd, schwz_stream stream);
+
+/* device pointers of the state vectors (for tests and host layers):
+ * which: 0 = x~ (local_size_x+halo), 1 = b~ / local_solution (local_size_x),
+ *        2 = y / init_guess (local_size_x), 3 = local_rhs (local_size_x) */
+int schwz_ras_vector(schwz_subdomain *sd, int which, double **d_ptr, int64_t *len);
+/* copy x~[0:local_size] to the host (synchronous) -- the rank's piece of the
+ * solution assembled in Solve::compute_residual_norm (solve.cpp:1025-1085) */
+int schwz_ras_get_interior(schwz_subdomain *sd, double *h_out, schwz_stream stream);
+/* || b_int - (A x)_int ||^2 contribution of this subdomain's interior rows to
+ * the final true residual (solve.cpp:1079-1084) given up-to-date halo values
+ * in x~; returns the squared partial norm on the host (synchronous). */
+int schwz_ras_true_residual_sq(schwz_subdomain *sd, double *h_out, schwz_stream stream);
+
+/* HBM bytes one launch of the dominant kernels moves algorithmically
+ * (SURVEY 8d): which: 0 = local SpMV, 1 = one PCG iteration, used by bench.py */
+int64_t schwz_ras_algorithmic_bytes(const schwz_subdomain *sd, int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,810 @@
+// Host-side setup of the RAS hot path: problem sources, partitioning, the
+// per-subdomain index sets / matrices / comm lists, and a sparse LL^T.
+// No HIP calls in this file -- it also runs on a CPU-only host.
+//
+// Unlike the reference, nothing of global length is ever materialised per rank
+// (SURVEY F7): the global matrix is a row source (explicit CSR or an analytic
+// stencil), interior ids are an arithmetic range and only overlap / halo ids
+// go through a hash map.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <numeric>
+#include <queue>
+#include <sstream>
+
+#include "schwz_internal.hpp"
+
+namespace schwz {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string &msg) { g_last_error = msg; }
+
+}  // namespace schwz
+
+using namespace schwz;
+
+// ---------------------------------------------------------------------------
+// problem
+// ---------------------------------------------------------------------------
+
+int64_t schwz_problem::nnz() const
+{
+    if (kind == 0) return rp.empty() ? 0 : rp.back();
+    if (kind == 2) return 5 * N - 4 * nx;
+    return 7 * N - 2 * (nx * ny + ny * nz + nx * nz);
+}
+
+int schwz_problem::row(int64_t g, int64_t *cols, double *vals) const
+{
+    int c = 0;
+    if (kind == 0) {
+        for (int64_t j = rp[g]; j < rp[g + 1]; ++j) {
+            cols[c] = col[j];
+            vals[c] = val[j];
+            ++c;
+        }
+    } else if (kind == 2) {
+        // source/initialization.cpp:214-265: offsets in key order {-n,-1,0,1,n},
+        // pairs (kn,kn-1),(kn-1,kn) excluded
+        const int64_t n = nx;
+        if (g - n >= 0) { cols[c] = g - n; vals[c++] = -1.0; }
+        if (g % n != 0) { cols[c] = g - 1; vals[c++] = -1.0; }
+        cols[c] = g; vals[c++] = 4.0;
+        if ((g + 1) % n != 0) { cols[c] = g + 1; vals[c++] = -1.0; }
+        if (g + n < N) { cols[c] = g + n; vals[c++] = -1.0; }
+    } else {
+        const int64_t sxy = nx * ny;
+        const int64_t x = g % nx, y = (g / nx) % ny, z = g / sxy;
+        if (z > 0) { cols[c] = g - sxy; vals[c++] = -1.0; }
+        if (y > 0) { cols[c] = g - nx; vals[c++] = -1.0; }
+        if (x > 0) { cols[c] = g - 1; vals[c++] = -1.0; }
+        cols[c] = g; vals[c++] = 6.0;
+        if (x < nx - 1) { cols[c] = g + 1; vals[c++] = -1.0; }
+        if (y < ny - 1) { cols[c] = g + nx; vals[c++] = -1.0; }
+        if (z < nz - 1) { cols[c] = g + sxy; vals[c++] = -1.0; }
+    }
+    return c;
+}
+
+static void sort_row(int64_t *c, double *v, int len)
+{
+    for (int i = 1; i < len; ++i) {
+        int64_t cc = c[i];
+        double vv = v[i];
+        int j = i;
+        while (j > 0 && c[j - 1] > cc) {
+            c[j] = c[j - 1];
+            v[j] = v[j - 1];
+            --j;
+        }
+        c[j] = cc;
+        v[j] = vv;
+    }
+}
+
+template <typename T>
+static T *to_malloc(const std::vector<T> &v)
+{
+    T *p = (T *)std::malloc(sizeof(T) * (v.empty() ? 1 : v.size()));
+    if (p && !v.empty()) std::memcpy(p, v.data(), sizeof(T) * v.size());
+    return p;
+}
+
+extern "C" {
+
+const char *schwz_last_error(void) { return g_last_error.c_str(); }
+const char *schwz_version(void) { return "schwz-hip 0.1 (gfx950)"; }
+void schwz_free(void *p) { std::free(p); }
+
+int schwz_problem_laplacian(int dim, int64_t nx, int64_t ny, int64_t nz, schwz_problem **out)
+{
+    SCHWZ_REQUIRE(out, "schwz_problem_laplacian: null output");
+    SCHWZ_REQUIRE(dim == 2 || dim == 3, "schwz_problem_laplacian: dim must be 2 or 3");
+    SCHWZ_REQUIRE(nx > 0, "schwz_problem_laplacian: grid size must be positive");
+    auto *p = new schwz_problem();
+    p->kind = dim;
+    p->nx = nx;
+    if (dim == 2) {
+        p->ny = nx;
+        p->nz = 1;
+        p->N = nx * nx;
+        p->max_row_nnz = 5;
+    } else {
+        SCHWZ_REQUIRE(ny > 0 && nz > 0, "schwz_problem_laplacian: grid size must be positive");
+        p->ny = ny;
+        p->nz = nz;
+        p->N = nx * ny * nz;
+        p->max_row_nnz = 7;
+    }
+    *out = p;
+    return SCHWZ_OK;
+}
+
+int schwz_problem_from_csr(int64_t N, const int64_t *rp, const schwz_idx *col, const double *val,
+                           schwz_problem **out)
+{
+    SCHWZ_REQUIRE(out && rp && N >= 0, "schwz_problem_from_csr: bad arguments");
+    auto *p = new schwz_problem();
+    p->kind = 0;
+    p->N = N;
+    p->rp.assign(rp, rp + N + 1);
+    const int64_t nnz = rp[N];
+    p->col.assign(col, col + nnz);
+    p->val.assign(val, val + nnz);
+    for (int64_t i = 0; i < N; ++i) {
+        const int len = (int)(rp[i + 1] - rp[i]);
+        p->max_row_nnz = std::max(p->max_row_nnz, len);
+        // sort_by_column_index (initialization.cpp:212)
+        bool sorted = true;
+        for (int64_t j = rp[i] + 1; j < rp[i + 1]; ++j)
+            if (p->col[j - 1] > p->col[j]) sorted = false;
+        if (!sorted) {
+            std::vector<std::pair<schwz_idx, double>> tmp((size_t)len);
+            for (int k = 0; k < len; ++k) tmp[k] = {p->col[rp[i] + k], p->val[rp[i] + k]};
+            std::stable_sort(tmp.begin(), tmp.end(),
+                             [](const auto &a, const auto &b) { return a.first < b.first; });
+            for (int k = 0; k < len; ++k) {
+                p->col[rp[i] + k] = tmp[k].first;
+                p->val[rp[i] + k] = tmp[k].second;
+            }
+        }
+    }
+    for (int64_t j = 0; j < nnz; ++j) {
+        if (p->col[j] < 0 || p->col[j] >= N) {
+            delete p;
+            set_error("schwz_problem_from_csr: column index out of range");
+            return SCHWZ_ERR_INVALID;
+        }
+    }
+    *out = p;
+    return SCHWZ_OK;
+}
+
+// Matrix-Market coordinate real/integer/pattern, general/symmetric
+int schwz_problem_from_matrix_market(const char *path, schwz_problem **out)
+{
+    SCHWZ_REQUIRE(path && out, "schwz_problem_from_matrix_market: null argument");
+    std::ifstream in(path);
+    if (!in) {
+        set_error(std::string("Could not find the file \"") + path + "\"");
+        return SCHWZ_ERR_IO;
+    }
+    std::string line;
+    std::getline(in, line);
+    std::string low = line;
+    std::transform(low.begin(), low.end(), low.begin(), ::tolower);
+    if (low.find("%%matrixmarket") != 0 || low.find("coordinate") == std::string::npos) {
+        set_error("matrix market: only coordinate format is supported");
+        return SCHWZ_ERR_IO;
+    }
+    const bool symmetric = low.find("symmetric") != std::string::npos;
+    const bool pattern = low.find("pattern") != std::string::npos;
+    while (std::getline(in, line))
+        if (!line.empty() && line[0] != '%') break;
+    int64_t nr = 0, nc = 0, nz = 0;
+    {
+        std::istringstream ss(line);
+        ss >> nr >> nc >> nz;
+    }
+    if (nr <= 0 || nr != nc) {
+        set_error("matrix market: need a square matrix");
+        return SCHWZ_ERR_IO;
+    }
+    std::vector<int64_t> ri, ci;
+    std::vector<double> vv;
+    ri.reserve((size_t)nz * (symmetric ? 2 : 1));
+    ci.reserve(ri.capacity());
+    vv.reserve(ri.capacity());
+    for (int64_t k = 0; k < nz; ++k) {
+        int64_t r, c;
+        double v = 1.0;
+        if (!(in >> r >> c)) {
+            set_error("matrix market: truncated file");
+            return SCHWZ_ERR_IO;
+        }
+        if (!pattern) in >> v;
+        ri.push_back(r - 1);
+        ci.push_back(c - 1);
+        vv.push_back(v);
+        if (symmetric && r != c) {
+            ri.push_back(c - 1);
+            ci.push_back(r - 1);
+            vv.push_back(v);
+        }
+    }
+    std::vector<int64_t> rp((size_t)nr + 1, 0);
+    for (int64_t r : ri) rp[r + 1]++;
+    for (int64_t i = 0; i < nr; ++i) rp[i + 1] += rp[i];
+    std::vector<schwz_idx> col(ri.size());
+    std::vector<double> val(ri.size());
+    std::vector<int64_t> fill(rp.begin(), rp.end() - 1);
+    for (size_t k = 0; k < ri.size(); ++k) {
+        col[fill[ri[k]]] = (schwz_idx)ci[k];
+        val[fill[ri[k]]] = vv[k];
+        fill[ri[k]]++;
+    }
+    return schwz_problem_from_csr(nr, rp.data(), col.data(), val.data(), out);
+}
+
+void schwz_problem_destroy(schwz_problem *p) { delete p; }
+int64_t schwz_problem_size(const schwz_problem *p) { return p ? p->N : 0; }
+int64_t schwz_problem_nnz(const schwz_problem *p) { return p ? p->nnz() : 0; }
+
+int schwz_problem_row(const schwz_problem *p, int64_t row, int *n, int64_t *cols, double *vals, int capacity)
+{
+    SCHWZ_REQUIRE(p && n && row >= 0 && row < p->N, "schwz_problem_row: bad arguments");
+    SCHWZ_REQUIRE(capacity >= p->max_row_nnz, "schwz_problem_row: capacity too small");
+    *n = p->row(row, cols, vals);
+    return SCHWZ_OK;
+}
+
+// source/restricted_schwarz.cpp:105-152
+int schwz_problem_permute(const schwz_problem *p, int P, const uint32_t *part, int64_t *perm,
+                          int64_t *first_row, schwz_problem **out)
+{
+    SCHWZ_REQUIRE(p && part && perm && first_row && out && P > 0, "schwz_problem_permute: bad arguments");
+    const int64_t N = p->N;
+    std::vector<int64_t> cnt((size_t)P, 0);
+    for (int64_t i = 0; i < N; ++i) {
+        SCHWZ_REQUIRE(part[i] < (uint32_t)P, "schwz_problem_permute: part id out of range");
+        cnt[part[i]]++;
+    }
+    first_row[0] = 0;
+    for (int q = 0; q < P; ++q) first_row[q + 1] = first_row[q] + cnt[q];
+    std::vector<int64_t> next(first_row, first_row + P);
+    for (int64_t i = 0; i < N; ++i) perm[next[part[i]]++] = i;
+    std::vector<int64_t> iperm((size_t)N);
+    for (int64_t i = 0; i < N; ++i) iperm[perm[i]] = i;
+    std::vector<int64_t> rp((size_t)N + 1, 0);
+    std::vector<schwz_idx> col;
+    std::vector<double> val;
+    col.reserve((size_t)p->nnz());
+    val.reserve((size_t)p->nnz());
+    std::vector<int64_t> c((size_t)p->max_row_nnz + 1);
+    std::vector<double> v((size_t)p->max_row_nnz + 1);
+    for (int64_t row = 0; row < N; ++row) {
+        const int len = p->row(perm[row], c.data(), v.data());
+        for (int k = 0; k < len; ++k) {
+            col.push_back((schwz_idx)iperm[c[k]]);
+            val.push_back(v[k]);
+        }
+        rp[row + 1] = (int64_t)col.size();
+    }
+    // the reference does not re-sort after permuting; schwz_problem_from_csr
+    // sorts rows, which only changes the order within a row (sums are re-sorted
+    // by local column index later anyway, restricted_schwarz.cpp:297-298)
+    return schwz_problem_from_csr(N, rp.data(), col.data(), val.data(), out);
+}
+
+// source/restricted_schwarz.cpp:84,97-102
+int schwz_partition_regular(int64_t N, int P, int64_t *first_row)
+{
+    SCHWZ_REQUIRE(first_row && P > 0 && N >= 0, "schwz_partition_regular: bad arguments");
+    const int64_t nb = (N + P - 1) / P;
+    first_row[0] = 0;
+    for (int p = 0; p < P; ++p) first_row[p + 1] = first_row[p] + std::min(N - first_row[p], nb);
+    return SCHWZ_OK;
+}
+
+// include/partition_tools.hpp:70-106
+int schwz_partition_regular2d(int64_t n1d, int P, uint32_t *part)
+{
+    SCHWZ_REQUIRE(part && n1d > 0 && P > 0, "schwz_partition_regular2d: bad arguments");
+    const int sq_p = (int)std::sqrt((double)P);
+    SCHWZ_REQUIRE(sq_p * sq_p == P && n1d % sq_p == 0,
+                  "regular2d needs a square subdomain count that divides the grid (SURVEY F10)");
+    const int64_t b = n1d / sq_p;
+    for (int j1 = 0; j1 < sq_p; ++j1) {
+        const int64_t offset2 = (int64_t)j1 * sq_p * b * b;
+        for (int j2 = 0; j2 < sq_p; ++j2) {
+            const uint32_t id = (uint32_t)(sq_p * j1 + j2);
+            const int64_t offset1 = (int64_t)j2 * n1d / sq_p;
+            for (int64_t i1 = 0; i1 < b; ++i1)
+                for (int64_t i2 = 0; i2 < b; ++i2) part[offset2 + offset1 + i1 * n1d + i2] = id;
+        }
+    }
+    return SCHWZ_OK;
+}
+
+// Recursive bisection by BFS level structure from a pseudo-peripheral node:
+// stands in for METIS_PartGraphKway (include/partition_tools.hpp:183-195).
+static void bisect(const schwz_problem *p, std::vector<int64_t> &nodes, int parts, uint32_t base,
+                   uint32_t *part, std::vector<int32_t> &mark, int32_t &stamp)
+{
+    if (nodes.empty()) return;
+    if (parts == 1) {
+        for (int64_t g : nodes) part[g] = base;
+        return;
+    }
+    const int left_parts = parts / 2;
+    const int64_t target = (int64_t)((double)nodes.size() * left_parts / parts + 0.5);
+    std::vector<int64_t> c((size_t)p->max_row_nnz + 1);
+    std::vector<double> v((size_t)p->max_row_nnz + 1);
+    // mark membership
+    ++stamp;
+    const int32_t member = stamp;
+    for (int64_t g : nodes) mark[g] = member;
+    auto bfs = [&](int64_t start, std::vector<int64_t> &order) {
+        ++stamp;
+        const int32_t seen = stamp;
+        order.clear();
+        size_t head = 0;
+        order.push_back(start);
+        mark[start] = seen;
+        for (;;) {
+            while (head < order.size()) {
+                const int64_t u = order[head++];
+                const int len = p->row(u, c.data(), v.data());
+                for (int k = 0; k < len; ++k) {
+                    const int64_t w = c[k];
+                    if (mark[w] == member) {
+                        mark[w] = seen;
+                        order.push_back(w);
+                    }
+                }
+            }
+            if (order.size() == nodes.size()) break;
+            // disconnected piece: continue from the first unseen member
+            for (int64_t g : nodes)
+                if (mark[g] == member) {
+                    mark[g] = seen;
+                    order.push_back(g);
+                    break;
+                }
+        }
+        // restore membership marks for the next sweep
+        for (int64_t g : order) mark[g] = member;
+    };
+    std::vector<int64_t> order;
+    bfs(nodes.front(), order);
+    int64_t far = order.back();
+    bfs(far, order);
+    far = order.back();
+    bfs(far, order);
+    std::vector<int64_t> left(order.begin(), order.begin() + target);
+    std::vector<int64_t> right(order.begin() + target, order.end());
+    std::sort(left.begin(), left.end());
+    std::sort(right.begin(), right.end());
+    nodes.clear();
+    nodes.shrink_to_fit();
+    bisect(p, left, left_parts, base, part, mark, stamp);
+    bisect(p, right, parts - left_parts, base + (uint32_t)left_parts, part, mark, stamp);
+}
+
+int schwz_partition_graph(const schwz_problem *p, int P, uint32_t *part)
+{
+    SCHWZ_REQUIRE(p && part && P > 0, "schwz_partition_graph: bad arguments");
+    std::vector<int64_t> nodes((size_t)p->N);
+    std::iota(nodes.begin(), nodes.end(), 0);
+    std::vector<int32_t> mark((size_t)p->N, 0);
+    int32_t stamp = 0;
+    if (p->N > 0) bisect(p, nodes, P, 0, part, mark, stamp);
+    return SCHWZ_OK;
+}
+
+// ---------------------------------------------------------------------------
+// subdomain index sets (restricted_schwarz.cpp:56-304) and get lists (:336-371)
+// ---------------------------------------------------------------------------
+
+int schwz_subdomain_setup(const schwz_problem *p, int P, int me, int overlap, const int64_t *first_row,
+                          schwz_subdomain **out)
+{
+    SCHWZ_REQUIRE(p && out && first_row, "schwz_subdomain_setup: null argument");
+    SCHWZ_REQUIRE(P > 0 && me >= 0 && me < P, "schwz_subdomain_setup: bad rank / subdomain count");
+    SCHWZ_REQUIRE(overlap >= 1, "schwz_subdomain_setup: overlap must be >= 1");
+    SCHWZ_REQUIRE(first_row[0] == 0 && first_row[P] == p->N, "schwz_subdomain_setup: first_row must cover all rows");
+    auto *sd = new schwz_subdomain();
+    sd->P = P;
+    sd->me = me;
+    sd->overlap = overlap;
+    sd->N = p->N;
+    sd->first_row.assign(first_row, first_row + P + 1);
+    const int64_t lo = first_row[me], hi = first_row[me + 1];
+    sd->local_size = hi - lo;
+    if (sd->local_size >= INT32_MAX / 2) {
+        delete sd;
+        set_error("schwz_subdomain_setup: subdomain too large for int32 local indices");
+        return SCHWZ_ERR_INVALID;
+    }
+    const int mr = p->max_row_nnz + 1;
+    std::vector<int64_t> c((size_t)mr);
+    std::vector<double> v((size_t)mr);
+    auto &l2g = sd->l2g;
+    // interior ids are implicit; l2g stores them anyway for the callers
+    l2g.resize((size_t)sd->local_size);
+    std::iota(l2g.begin(), l2g.end(), lo);
+    auto mapped = [&](int64_t g) { return (g >= lo && g < hi) || sd->g2l_x.count(g) != 0; };
+    // overlap-1 BFS layers in discovery order (:166-180)
+    int64_t old = 0;
+    for (int k = 1; k < overlap; ++k) {
+        const int64_t now = (int64_t)l2g.size();
+        for (int64_t i = old; i < now; ++i) {
+            const int len = p->row(l2g[(size_t)i], c.data(), v.data());
+            for (int j = 0; j < len; ++j) {
+                if (!mapped(c[j])) {
+                    sd->g2l_x.emplace(c[j], (schwz_idx)l2g.size());
+                    l2g.push_back(c[j]);
+                }
+            }
+        }
+        old = now;
+    }
+    sd->local_size_x = (int64_t)l2g.size();
+    sd->overlap_size = sd->local_size_x - sd->local_size;
+    const int64_t n = sd->local_size_x;
+
+    // local / interface split (:194-284).  Entries of interior rows whose column
+    // is unmapped ("invalid edge", only possible for overlap == 1) are dropped
+    // like the reference does.
+    sd->l_rp.assign((size_t)n + 1, 0);
+    sd->i_rp.assign((size_t)n + 1, 0);
+    std::vector<schwz_idx> lc((size_t)mr);
+    std::vector<double> lv((size_t)mr);
+    int64_t nnz_l = 0;
+    for (int64_t r = 0; r < n; ++r) {
+        const int len = p->row(l2g[(size_t)r], c.data(), v.data());
+        for (int j = 0; j < len; ++j) {
+            const schwz_idx loc = sd->to_local(c[j]);
+            if (loc >= 0)
+                ++nnz_l;
+        }
+        if (nnz_l >= INT32_MAX) {
+            delete sd;
+            set_error("schwz_subdomain_setup: local matrix exceeds 2^31-1 nonzeros");
+            return SCHWZ_ERR_INVALID;
+        }
+        sd->l_rp[(size_t)r + 1] = (schwz_idx)nnz_l;
+    }
+    sd->l_col.resize((size_t)nnz_l);
+    sd->l_val.resize((size_t)nnz_l);
+#pragma omp parallel for schedule(static) firstprivate(c, v)
+    for (int64_t r = 0; r < n; ++r) {
+        const int len = p->row(l2g[(size_t)r], c.data(), v.data());
+        int64_t pos = sd->l_rp[(size_t)r];
+        const int64_t start = pos;
+        for (int j = 0; j < len; ++j) {
+            const schwz_idx loc = sd->to_local(c[j]);
+            if (loc >= 0) {
+                sd->l_col[(size_t)pos] = loc;
+                sd->l_val[(size_t)pos] = v[j];
+                ++pos;
+            }
+        }
+        // sort_by_column_index (:297)
+        for (int64_t a = start + 1; a < pos; ++a) {
+            const schwz_idx cc = sd->l_col[(size_t)a];
+            const double vv = sd->l_val[(size_t)a];
+            int64_t b = a;
+            while (b > start && sd->l_col[(size_t)b - 1] > cc) {
+                sd->l_col[(size_t)b] = sd->l_col[(size_t)b - 1];
+                sd->l_val[(size_t)b] = sd->l_val[(size_t)b - 1];
+                --b;
+            }
+            sd->l_col[(size_t)b] = cc;
+            sd->l_val[(size_t)b] = vv;
+        }
+    }
+    // interface entries: overlap rows only, GLOBAL columns, ascending (:262-284,298)
+    for (int64_t r = sd->local_size; r < n; ++r) {
+        const int len = p->row(l2g[(size_t)r], c.data(), v.data());
+        int cnt = 0;
+        for (int j = 0; j < len; ++j) {
+            if (sd->to_local(c[j]) < 0) {
+                sd->i_col_global.push_back(c[j]);
+                sd->i_val.push_back(v[j]);
+                ++cnt;
+            }
+        }
+        sort_row(sd->i_col_global.data() + sd->i_col_global.size() - cnt,
+                 sd->i_val.data() + sd->i_val.size() - cnt, cnt);
+        sd->i_rp[(size_t)r + 1] = (schwz_idx)sd->i_col_global.size();
+    }
+    for (int64_t r = 0; r < sd->local_size; ++r) sd->i_rp[(size_t)r + 1] = 0;
+    // halo marking: one more BFS step from the last layer (:285-295)
+    {
+        const int64_t now = (int64_t)l2g.size();
+        for (int64_t i = old; i < now; ++i) {
+            const int len = p->row(l2g[(size_t)i], c.data(), v.data());
+            for (int j = 0; j < len; ++j) {
+                if (!mapped(c[j])) {
+                    sd->g2l_x.emplace(c[j], (schwz_idx)l2g.size());
+                    l2g.push_back(c[j]);
+                }
+            }
+        }
+    }
+    sd->halo_size = (int64_t)l2g.size() - sd->local_size_x;
+
+    // get lists (:336-371): every mapped id owned by p, ascending.  Only the
+    // non-interior ids can belong to another rank, so sort those once.
+    std::vector<int64_t> ext(l2g.begin() + sd->local_size, l2g.end());
+    std::sort(ext.begin(), ext.end());
+    size_t pos = 0;
+    for (int q = 0; q < P; ++q) {
+        if (q == me) {
+            while (pos < ext.size() && ext[pos] < first_row[q + 1]) ++pos;
+            continue;
+        }
+        std::vector<int64_t> lst;
+        while (pos < ext.size() && ext[pos] < first_row[q + 1]) lst.push_back(ext[pos++]);
+        if (!lst.empty()) {
+            sd->num_recv += (int64_t)lst.size();
+            sd->nbr_in.push_back(q);
+            sd->get.push_back(std::move(lst));
+        }
+    }
+    *out = sd;
+    return SCHWZ_OK;
+}
+
+int schwz_subdomain_sizes(const schwz_subdomain *sd, int64_t *s)
+{
+    SCHWZ_REQUIRE(sd && s, "schwz_subdomain_sizes: null argument");
+    s[0] = sd->local_size;
+    s[1] = sd->local_size_x;
+    s[2] = sd->overlap_size;
+    s[3] = sd->halo_size;
+    s[4] = (int64_t)sd->l_col.size();
+    s[5] = (int64_t)sd->i_col_global.size();
+    s[6] = (int64_t)sd->nbr_in.size();
+    s[7] = (int64_t)sd->nbr_out.size();
+    s[8] = sd->num_recv;
+    s[9] = sd->num_send;
+    return SCHWZ_OK;
+}
+
+int schwz_subdomain_local_to_global(const schwz_subdomain *sd, int64_t *out)
+{
+    SCHWZ_REQUIRE(sd && out, "schwz_subdomain_local_to_global: null argument");
+    std::copy(sd->l2g.begin(), sd->l2g.end(), out);
+    return SCHWZ_OK;
+}
+
+int schwz_subdomain_local_matrix(const schwz_subdomain *sd, schwz_idx *rp, schwz_idx *col, double *val)
+{
+    SCHWZ_REQUIRE(sd && rp && (col || sd->l_col.empty()), "schwz_subdomain_local_matrix: null argument");
+    std::copy(sd->l_rp.begin(), sd->l_rp.end(), rp);
+    std::copy(sd->l_col.begin(), sd->l_col.end(), col);
+    std::copy(sd->l_val.begin(), sd->l_val.end(), val);
+    return SCHWZ_OK;
+}
+
+int schwz_subdomain_interface_matrix(const schwz_subdomain *sd, schwz_idx *rp, int64_t *col, double *val)
+{
+    SCHWZ_REQUIRE(sd && rp, "schwz_subdomain_interface_matrix: null argument");
+    std::copy(sd->i_rp.begin(), sd->i_rp.end(), rp);
+    std::copy(sd->i_col_global.begin(), sd->i_col_global.end(), col);
+    std::copy(sd->i_val.begin(), sd->i_val.end(), val);
+    return SCHWZ_OK;
+}
+
+static int list_out(const std::vector<int> &ranks, const std::vector<std::vector<int64_t>> &lists, int k,
+                    int *rank, int64_t *count, int64_t *ids)
+{
+    SCHWZ_REQUIRE(k >= 0 && k < (int)ranks.size(), "neighbour index out of range");
+    if (rank) *rank = ranks[(size_t)k];
+    if (count) *count = (int64_t)lists[(size_t)k].size();
+    if (ids) std::copy(lists[(size_t)k].begin(), lists[(size_t)k].end(), ids);
+    return SCHWZ_OK;
+}
+
+int schwz_subdomain_get_list(const schwz_subdomain *sd, int k, int *rank, int64_t *count, int64_t *ids)
+{
+    SCHWZ_REQUIRE(sd, "schwz_subdomain_get_list: null argument");
+    return list_out(sd->nbr_in, sd->get, k, rank, count, ids);
+}
+
+int schwz_subdomain_put_list(const schwz_subdomain *sd, int k, int *rank, int64_t *count, int64_t *ids)
+{
+    SCHWZ_REQUIRE(sd, "schwz_subdomain_put_list: null argument");
+    return list_out(sd->nbr_out, sd->put, k, rank, count, ids);
+}
+
+int schwz_subdomain_add_put_list(schwz_subdomain *sd, int p, int64_t count, const int64_t *ids)
+{
+    SCHWZ_REQUIRE(sd && (ids || count == 0), "schwz_subdomain_add_put_list: null argument");
+    SCHWZ_REQUIRE(!sd->on_device, "schwz_subdomain_add_put_list: lists are frozen after to_device");
+    SCHWZ_REQUIRE(p >= 0 && p < sd->P && p != sd->me, "schwz_subdomain_add_put_list: bad neighbour rank");
+    SCHWZ_REQUIRE(sd->nbr_out.empty() || sd->nbr_out.back() < p,
+                  "schwz_subdomain_add_put_list: neighbours must be added in ascending rank order");
+    if (count <= 0) return SCHWZ_OK;
+    const int64_t lo = sd->first_row[sd->me], hi = sd->first_row[sd->me + 1];
+    for (int64_t i = 0; i < count; ++i)
+        SCHWZ_REQUIRE(ids[i] >= lo && ids[i] < hi, "schwz_subdomain_add_put_list: id not owned by this subdomain");
+    sd->nbr_out.push_back(p);
+    sd->put.emplace_back(ids, ids + count);
+    sd->num_send += count;
+    return SCHWZ_OK;
+}
+
+static int offset_of(const std::vector<std::vector<int64_t>> &lists, int k, int64_t *off)
+{
+    SCHWZ_REQUIRE(off && k >= 0 && k <= (int)lists.size(), "neighbour index out of range");
+    int64_t o = 0;
+    for (int i = 0; i < k; ++i) o += (int64_t)lists[(size_t)i].size();
+    *off = o;
+    return SCHWZ_OK;
+}
+
+int schwz_subdomain_send_offset(const schwz_subdomain *sd, int k, int64_t *off)
+{
+    SCHWZ_REQUIRE(sd, "schwz_subdomain_send_offset: null argument");
+    return offset_of(sd->put, k, off);
+}
+
+int schwz_subdomain_recv_offset(const schwz_subdomain *sd, int k, int64_t *off)
+{
+    SCHWZ_REQUIRE(sd, "schwz_subdomain_recv_offset: null argument");
+    return offset_of(sd->get, k, off);
+}
+
+// ---------------------------------------------------------------------------
+// sparse LL^T (left-looking, column by column, with linked row lists)
+// ---------------------------------------------------------------------------
+
+// Cuthill-McKee reversed; any fill-reducing ordering is admissible here (CHOLMOD
+// would choose AMD, solve.cpp:102-105 only lets the user force the natural one).
+static void rcm(int64_t n, const schwz_idx *rp, const schwz_idx *col, std::vector<schwz_idx> &perm)
+{
+    perm.clear();
+    perm.reserve((size_t)n);
+    std::vector<char> seen((size_t)n, 0);
+    std::vector<schwz_idx> nb;
+    auto deg = [&](schwz_idx i) { return rp[i + 1] - rp[i]; };
+    size_t head = 0;
+    while ((int64_t)perm.size() < n) {
+        schwz_idx s = -1;
+        for (int64_t i = 0; i < n; ++i)
+            if (!seen[(size_t)i] && (s < 0 || deg((schwz_idx)i) < deg(s))) s = (schwz_idx)i;
+        seen[(size_t)s] = 1;
+        perm.push_back(s);
+        while (head < perm.size()) {
+            const schwz_idx u = perm[head++];
+            nb.clear();
+            for (schwz_idx j = rp[u]; j < rp[u + 1]; ++j) {
+                const schwz_idx w = col[j];
+                if (w != u && !seen[(size_t)w]) {
+                    seen[(size_t)w] = 1;
+                    nb.push_back(w);
+                }
+            }
+            std::sort(nb.begin(), nb.end(), [&](schwz_idx a, schwz_idx b) {
+                return deg(a) != deg(b) ? deg(a) < deg(b) : a < b;
+            });
+            perm.insert(perm.end(), nb.begin(), nb.end());
+        }
+    }
+    std::reverse(perm.begin(), perm.end());
+}
+
+int schwz_cholesky(int64_t n, const schwz_idx *rp, const schwz_idx *col, const double *val, int natural,
+                   schwz_idx **l_rp_o, schwz_idx **l_col_o, double **l_val_o, schwz_idx **u_rp_o,
+                   schwz_idx **u_col_o, double **u_val_o, schwz_idx **perm_o)
+{
+    SCHWZ_REQUIRE(rp && l_rp_o && l_col_o && l_val_o && u_rp_o && u_col_o && u_val_o && perm_o && n >= 0,
+                  "schwz_cholesky: bad arguments");
+    std::vector<schwz_idx> perm;
+    if (natural) {
+        perm.resize((size_t)n);
+        std::iota(perm.begin(), perm.end(), 0);
+    } else {
+        rcm(n, rp, col, perm);
+    }
+    std::vector<schwz_idx> iperm((size_t)n);
+    for (int64_t i = 0; i < n; ++i) iperm[(size_t)perm[(size_t)i]] = (schwz_idx)i;
+
+    // Column j of L is built from column j of B = A(perm,perm) (rows >= j) minus
+    // the contributions of every earlier column k with L(j,k) != 0.  `next_in_row`
+    // chains the columns that currently have their next unprocessed entry in row j.
+    std::vector<std::vector<schwz_idx>> lcol_rows((size_t)n);  // row ids per column (ascending)
+    std::vector<std::vector<double>> lcol_vals((size_t)n);
+    std::vector<schwz_idx> cursor((size_t)n, 0);       // position of next entry below the diagonal
+    std::vector<schwz_idx> head((size_t)n, -1), nxt((size_t)n, -1);
+    std::vector<double> w((size_t)n, 0.0);
+    std::vector<char> inpat((size_t)n, 0);
+    std::vector<schwz_idx> pat;
+    for (int64_t j = 0; j < n; ++j) {
+        pat.clear();
+        // scatter column j of B (lower part): entries (i, j) with i >= j come
+        // from row perm[j] of A by symmetry
+        const schwz_idx aj = perm[(size_t)j];
+        for (schwz_idx t = rp[aj]; t < rp[aj + 1]; ++t) {
+            const schwz_idx i = iperm[(size_t)col[t]];
+            if (i >= j) {
+                if (!inpat[(size_t)i]) {
+                    inpat[(size_t)i] = 1;
+                    pat.push_back(i);
+                }
+                w[(size_t)i] += val[t];
+            }
+        }
+        if (!inpat[(size_t)j]) {
+            inpat[(size_t)j] = 1;
+            pat.push_back((schwz_idx)j);
+        }
+        // subtract L(j:n,k) * L(j,k) for every k in row j's list
+        schwz_idx k = head[(size_t)j];
+        while (k != -1) {
+            const schwz_idx knext = nxt[(size_t)k];
+            const auto &rows = lcol_rows[(size_t)k];
+            const auto &vals = lcol_vals[(size_t)k];
+            const schwz_idx c0 = cursor[(size_t)k];  // rows[c0] == j
+            const double ljk = vals[(size_t)c0];
+            for (size_t t = (size_t)c0; t < rows.size(); ++t) {
+                const schwz_idx i = rows[t];
+                if (!inpat[(size_t)i]) {
+                    inpat[(size_t)i] = 1;
+                    pat.push_back(i);
+                }
+                w[(size_t)i] -= vals[t] * ljk;
+            }
+            // advance column k to its next row
+            cursor[(size_t)k] = c0 + 1;
+            if ((size_t)(c0 + 1) < rows.size()) {
+                const schwz_idx r = rows[(size_t)c0 + 1];
+                nxt[(size_t)k] = head[(size_t)r];
+                head[(size_t)r] = k;
+            }
+            k = knext;
+        }
+        std::sort(pat.begin(), pat.end());
+        const double d = w[(size_t)j];
+        if (!(d > 0.0)) {
+            set_error("schwz_cholesky: matrix is not positive definite");
+            return SCHWZ_ERR_NOT_SPD;
+        }
+        const double ljj = std::sqrt(d);
+        auto &rows = lcol_rows[(size_t)j];
+        auto &vals = lcol_vals[(size_t)j];
+        rows.reserve(pat.size());
+        vals.reserve(pat.size());
+        for (schwz_idx i : pat) {
+            rows.push_back(i);
+            vals.push_back(i == j ? ljj : w[(size_t)i] / ljj);
+            w[(size_t)i] = 0.0;
+            inpat[(size_t)i] = 0;
+        }
+        cursor[(size_t)j] = 1;  // rows[0] is the diagonal
+        if (rows.size() > 1) {
+            const schwz_idx r = rows[1];
+            nxt[(size_t)j] = head[(size_t)r];
+            head[(size_t)r] = (schwz_idx)j;
+        }
+    }
+    // U = L^T in CSR = columns of L (diagonal first); L in CSR = its transpose
+    // (solve.cpp:288-304)
+    std::vector<schwz_idx> u_rp((size_t)n + 1, 0), l_rp((size_t)n + 1, 0);
+    for (int64_t j = 0; j < n; ++j) {
+        u_rp[(size_t)j + 1] = u_rp[(size_t)j] + (schwz_idx)lcol_rows[(size_t)j].size();
+        for (schwz_idx i : lcol_rows[(size_t)j]) l_rp[(size_t)i + 1]++;
+    }
+    for (int64_t i = 0; i < n; ++i) l_rp[(size_t)i + 1] += l_rp[(size_t)i];
+    const size_t lnz = (size_t)u_rp[(size_t)n];
+    std::vector<schwz_idx> u_col(lnz), l_col(lnz);
+    std::vector<double> u_val(lnz), l_val(lnz);
+    std::vector<schwz_idx> fill(l_rp.begin(), l_rp.end() - 1);
+    for (int64_t j = 0; j < n; ++j) {
+        size_t o = (size_t)u_rp[(size_t)j];
+        for (size_t t = 0; t < lcol_rows[(size_t)j].size(); ++t, ++o) {
+            const schwz_idx i = lcol_rows[(size_t)j][t];
+            u_col[o] = i;
+            u_val[o] = lcol_vals[(size_t)j][t];
+            l_col[(size_t)fill[(size_t)i]] = (schwz_idx)j;
+            l_val[(size_t)fill[(size_t)i]] = lcol_vals[(size_t)j][t];
+            fill[(size_t)i]++;
+        }
+    }
+    *l_rp_o = to_malloc(l_rp);
+    *l_col_o = to_malloc(l_col);
+    *l_val_o = to_malloc(l_val);
+    *u_rp_o = to_malloc(u_rp);
+    *u_col_o = to_malloc(u_col);
+    *u_val_o = to_malloc(u_val);
+    *perm_o = to_malloc(perm);
+    return SCHWZ_OK;
+}
+
+}  // extern "C"

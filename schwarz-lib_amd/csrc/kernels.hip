@@ -1,0 +1,871 @@
+// HIP kernels for gfx950 (MI355X): CSR SpMV with LDS-staged products, fused CG
+// vector kernels, gather/scatter, level-scheduled triangular solves.
+//
+// Everything here is HBM-bandwidth bound fp64 / int32 streaming work; there is no
+// dense contraction, so MFMA is deliberately unused (BASELINE.json north_star).
+// Wavefronts are 64 lanes; workgroups are 256 threads (4 waves).
+#include <hip/hip_runtime.h>
+
+#include <climits>
+
+#include "schwz_internal.hpp"
+
+namespace schwz {
+
+// ---------------------------------------------------------------------------
+// reductions
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Sum over the 256-thread workgroup; result valid in every thread.
+// `red` must hold 4 doubles.  Fixed order => bitwise reproducible.
+__device__ __forceinline__ double block_sum(double v, double *red)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();  // protect `red` from a previous use
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// Every workgroup folds the per-workgroup partial sums of the previous launch
+// itself (fixed order): no extra launch and no atomics on the critical path.
+__device__ __forceinline__ double fold_partials(const double *part, int count, double *red)
+{
+    double s = 0.0;
+    for (int i = threadIdx.x; i < count; i += kBlock) s += part[i];
+    return block_sum(s, red);
+}
+
+// ---------------------------------------------------------------------------
+// CSR SpMV, tiled: each workgroup owns a run of consecutive rows whose nonzeros
+// (<= kTileNnz) are read with unit stride, multiplied with the gathered x and
+// staged in LDS; one lane per row then sums its LDS segment.  Tiles are dealt to
+// workgroups so that each XCD (blockIdx % 8) sweeps one contiguous eighth of the
+// matrix: the x entries a tile shares with its neighbours (i+-1, i+-nx, i+-nx*ny
+// for the Poisson stencils) stay in that XCD's 4 MiB L2.
+// ---------------------------------------------------------------------------
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void spmv_tiled_kernel(CsrView A, SpmvArgs a)
+{
+    __shared__ double prod[kTileNnz];
+    __shared__ double red[4];
+    if (MODE == kSpmvDot || MODE == kSpmvResidInit) {
+        if (a.stop_iter && a.it >= *a.stop_iter) return;
+    }
+    const int tid = threadIdx.x;
+    const int xcd = blockIdx.x % kXcds;
+    const int slot = blockIdx.x / kXcds;
+    const int per_xcd = gridDim.x / kXcds;
+    const int chunk = (A.ntiles + kXcds - 1) / kXcds;
+    double acc0 = 0.0, acc1 = 0.0;
+
+    for (int t = slot; t < chunk; t += per_xcd) {
+        const int tile = xcd * chunk + t;
+        if (tile >= A.ntiles) break;
+        const int r0 = A.tile_row[tile], r1 = A.tile_row[tile + 1];
+        const int s = A.rp[r0], e = A.rp[r1];
+        const int cnt = e - s;
+        double sum = 0.0;
+        int row = r0 + tid;
+        bool have_row = false;
+        if (cnt <= kTileNnz) {
+            for (int i = tid; i < cnt; i += kBlock)
+                prod[i] = A.val[s + i] * a.x[A.col[s + i]];
+            __syncthreads();
+            if (row < r1) {
+                have_row = true;
+                const int b0 = A.rp[row] - s, b1 = A.rp[row + 1] - s;
+                for (int j = b0; j < b1; ++j) sum += prod[j];
+            }
+            __syncthreads();
+        } else {
+            // a single row longer than a tile: the whole workgroup reduces it
+            double part = 0.0;
+            for (int i = tid; i < cnt; i += kBlock) part += A.val[s + i] * a.x[A.col[s + i]];
+            part = block_sum(part, red);
+            row = r0;
+            if (tid == 0) {
+                have_row = true;
+                sum = part;
+            }
+        }
+        if (have_row) {
+            if (MODE == kSpmvPlain) {
+                a.y[row] = (a.beta == 0.0) ? a.alpha * sum : a.alpha * sum + a.beta * a.y[row];
+            } else if (MODE == kSpmvDot) {
+                a.y[row] = sum;
+                acc0 += a.x[row] * sum;
+            } else if (MODE == kSpmvResidInit) {
+                const double r = a.b[row] - sum;
+                const double z = a.dinv ? a.dinv[row] * r : r;
+                a.y[row] = r;
+                a.p[row] = z;
+                acc0 += r * z;
+                acc1 += r * r;
+            } else {  // kSpmvResidNorm
+                if (row < a.row_limit) {
+                    const double r = a.b[row] - sum;
+                    acc1 += r * r;
+                }
+            }
+        }
+    }
+    if (MODE != kSpmvPlain) {
+        const double s0 = block_sum(acc0, red);
+        const double s1 = block_sum(acc1, red);
+        if (tid == 0) {
+            a.partials[blockIdx.x] = s0;
+            a.partials[gridDim.x + blockIdx.x] = s1;
+        }
+    }
+}
+
+// Baseline for A/B runs: one row per lane, no staging (what a direct port of a
+// row-parallel CPU loop would do).  Only the plain mode.
+__global__ __launch_bounds__(kBlock) void spmv_rowlane_kernel(CsrView A, SpmvArgs a)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < A.nrows; row += stride) {
+        double sum = 0.0;
+        for (int j = A.rp[row]; j < A.rp[row + 1]; ++j) sum += A.val[j] * a.x[A.col[j]];
+        a.y[row] = (a.beta == 0.0) ? a.alpha * sum : a.alpha * sum + a.beta * a.y[row];
+    }
+}
+
+int spmv_grid(const CsrView &A)
+{
+    int g = A.ntiles < kMaxGrid ? A.ntiles : kMaxGrid;
+    g = ((g + kXcds - 1) / kXcds) * kXcds;
+    return g < kXcds ? kXcds : g;
+}
+
+int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipStream_t s)
+{
+    if (A.nrows == 0) return SCHWZ_OK;
+    const int grid = spmv_grid(A);
+    if (variant == 1 && mode == kSpmvPlain) {
+        hipLaunchKernelGGL(spmv_rowlane_kernel, dim3(kMaxGrid), dim3(kBlock), 0, s, A, a);
+    } else {
+        switch (mode) {
+        case kSpmvPlain:
+            hipLaunchKernelGGL(spmv_tiled_kernel<kSpmvPlain>, dim3(grid), dim3(kBlock), 0, s, A, a);
+            break;
+        case kSpmvDot:
+            hipLaunchKernelGGL(spmv_tiled_kernel<kSpmvDot>, dim3(grid), dim3(kBlock), 0, s, A, a);
+            break;
+        case kSpmvResidInit:
+            hipLaunchKernelGGL(spmv_tiled_kernel<kSpmvResidInit>, dim3(grid), dim3(kBlock), 0, s, A, a);
+            break;
+        default:
+            hipLaunchKernelGGL(spmv_tiled_kernel<kSpmvResidNorm>, dim3(grid), dim3(kBlock), 0, s, A, a);
+            break;
+        }
+    }
+    SCHWZ_HIP_TRY(hipGetLastError());
+    return SCHWZ_OK;
+}
+
+// ---------------------------------------------------------------------------
+// CG vector kernels.  One CG iteration = spmv_tiled_kernel<kSpmvDot> + these two.
+// Scalars live in CgState in HBM; nothing returns to the host inside the loop.
+// ---------------------------------------------------------------------------
+
+__global__ void cg_init_finalize_kernel(CgState *st, const double *partials, int nparts, double rtol)
+{
+    __shared__ double red[4];
+    const double rho = fold_partials(partials, nparts, red);
+    const double rr = fold_partials(partials + nparts, nparts, red);
+    if (threadIdx.x == 0) {
+        st->rho[0] = rho;
+        st->rho[1] = 0.0;
+        st->rr = rr;
+        st->r0 = sqrt(rr);
+        st->iters = 0;
+        // loop-top test of iteration 0: ||r|| <= rtol*||r_initial||
+        st->stop_iter = (sqrt(rr) <= rtol * sqrt(rr)) ? 0 : INT_MAX;
+    }
+}
+
+// x += alpha p ; r -= alpha q ; z = dinv r ; partials: r.z and r.r
+__global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, double *__restrict__ x,
+                                                           double *__restrict__ r,
+                                                           const double *__restrict__ p,
+                                                           const double *__restrict__ q,
+                                                           const double *__restrict__ dinv,
+                                                           const double *pq_partials, int nparts_in,
+                                                           const CgState *st, int it,
+                                                           double *partials_out)
+{
+    __shared__ double red[4];
+    if (it >= st->stop_iter) return;
+    const double pq = fold_partials(pq_partials, nparts_in, red);
+    const double alpha = st->rho[it & 1] / pq;
+    double a0 = 0.0, a1 = 0.0;
+    const int64_t n2 = n >> 1;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    double2 *x2 = reinterpret_cast<double2 *>(x);
+    double2 *r2 = reinterpret_cast<double2 *>(r);
+    const double2 *p2 = reinterpret_cast<const double2 *>(p);
+    const double2 *q2 = reinterpret_cast<const double2 *>(q);
+    const double2 *d2 = reinterpret_cast<const double2 *>(dinv);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
+        double2 xv = x2[i], rv = r2[i];
+        const double2 pv = p2[i], qv = q2[i];
+        xv.x += alpha * pv.x;
+        xv.y += alpha * pv.y;
+        rv.x -= alpha * qv.x;
+        rv.y -= alpha * qv.y;
+        x2[i] = xv;
+        r2[i] = rv;
+        double zx = rv.x, zy = rv.y;
+        if (dinv) {
+            const double2 dv = d2[i];
+            zx *= dv.x;
+            zy *= dv.y;
+        }
+        a0 += rv.x * zx;
+        a0 += rv.y * zy;
+        a1 += rv.x * rv.x;
+        a1 += rv.y * rv.y;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
+        x[i] += alpha * p[i];
+        const double rv = r[i] - alpha * q[i];
+        r[i] = rv;
+        const double z = dinv ? dinv[i] * rv : rv;
+        a0 += rv * z;
+        a1 += rv * rv;
+    }
+    const double s0 = block_sum(a0, red);
+    const double s1 = block_sum(a1, red);
+    if (threadIdx.x == 0) {
+        partials_out[blockIdx.x] = s0;
+        partials_out[gridDim.x + blockIdx.x] = s1;
+    }
+}
+
+// beta = rho'/rho ; p = dinv r + beta p ; state update by workgroup 0
+__global__ __launch_bounds__(kBlock) void cg_direction_kernel(int64_t n, double *__restrict__ p,
+                                                              const double *__restrict__ r,
+                                                              const double *__restrict__ dinv,
+                                                              const double *partials_in, int nparts,
+                                                              CgState *st, int it, double rtol)
+{
+    __shared__ double red[4];
+    if (it >= st->stop_iter) return;
+    const double rho_new = fold_partials(partials_in, nparts, red);
+    const double rr = fold_partials(partials_in + nparts, nparts, red);
+    const double beta = rho_new / st->rho[it & 1];
+    const int64_t n2 = n >> 1;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    double2 *p2 = reinterpret_cast<double2 *>(p);
+    const double2 *r2 = reinterpret_cast<const double2 *>(r);
+    const double2 *d2 = reinterpret_cast<const double2 *>(dinv);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
+        double2 pv = p2[i];
+        double2 zv = r2[i];
+        if (dinv) {
+            const double2 dv = d2[i];
+            zv.x *= dv.x;
+            zv.y *= dv.y;
+        }
+        pv.x = zv.x + beta * pv.x;
+        pv.y = zv.y + beta * pv.y;
+        p2[i] = pv;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
+        const double z = dinv ? dinv[i] * r[i] : r[i];
+        p[i] = z + beta * p[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // other workgroups read rho[it&1] and stop_iter concurrently: the slot
+        // written here is the other one, and stop_iter only ever drops to it+1,
+        // which every reader of this launch compares as "not yet".
+        st->rho[(it + 1) & 1] = rho_new;
+        st->rr = rr;
+        st->iters = it + 1;
+        if (sqrt(rr) <= rtol * st->r0) st->stop_iter = it + 1;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// gather / scatter with the four reference ops
+// ---------------------------------------------------------------------------
+
+template <int OP>
+__device__ __forceinline__ double combine(double into, double from)
+{
+    if (OP == SCHWZ_OP_COPY) return from;
+    if (OP == SCHWZ_OP_ADD) return from + into;
+    if (OP == SCHWZ_OP_DIFF) return from - into;
+    return (from + into) / 2;
+}
+
+template <int OP>
+__global__ void gather_kernel(int64_t n, const schwz_idx *__restrict__ idx,
+                              const double *__restrict__ from, double *__restrict__ into)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        into[i] = combine<OP>(OP == SCHWZ_OP_COPY ? 0.0 : into[i], from[idx[i]]);
+}
+
+template <int OP>
+__global__ void scatter_kernel(int64_t n, const schwz_idx *__restrict__ idx,
+                               const double *__restrict__ from, double *__restrict__ into)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const schwz_idx k = idx[i];
+        into[k] = combine<OP>(OP == SCHWZ_OP_COPY ? 0.0 : into[k], from[i]);
+    }
+}
+
+static int grid_for(int64_t n)
+{
+    int64_t g = (n + kBlock - 1) / kBlock;
+    if (g > kMaxGrid) g = kMaxGrid;
+    return g < 1 ? 1 : (int)g;
+}
+
+// b~[row] = b[row] - sum_j A_Gamma[row][j] x~[col_j] for the overlap rows only
+// (rows < local_size have no interface entries; their b~ is set once at upload).
+__global__ void interface_update_kernel(int64_t nrows, int64_t row0, const schwz_idx *__restrict__ rp,
+                                        const schwz_idx *__restrict__ col,
+                                        const double *__restrict__ val,
+                                        const double *__restrict__ x, const double *__restrict__ b,
+                                        double *__restrict__ bt)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrows; i += stride) {
+        double s = 0.0;
+        for (int j = rp[i]; j < rp[i + 1]; ++j) s += val[j] * x[col[j]];
+        bt[row0 + i] = b[row0 + i] - s;
+    }
+}
+
+// dinv[i] = 1 / A[i][i] (1 when the row stores no diagonal): scalar Jacobi, i.e.
+// block-Jacobi with max_block_size 1
+__global__ void extract_dinv_kernel(CsrView A, double *__restrict__ dinv)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.nrows; i += stride) {
+        double d = 1.0;
+        for (int j = A.rp[i]; j < A.rp[i + 1]; ++j)
+            if (A.col[j] == i) d = A.val[j];
+        dinv[i] = 1.0 / d;
+    }
+}
+
+__global__ void final_norm_kernel(const double *partials, int nparts, double *out)
+{
+    __shared__ double red[4];
+    const double s = fold_partials(partials, nparts, red);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+// ---------------------------------------------------------------------------
+// level-scheduled sparse triangular solves in ONE workgroup: rows of a level are
+// independent; levels are separated by a workgroup barrier.  Used for the
+// direct local solve, whose factors are small (BASELINE config 4: ~500 rows).
+// ---------------------------------------------------------------------------
+
+constexpr int kTrsBlock = 1024;
+
+// out[i] = in[perm[i]]   (gko Permutation row_permute)
+// L t = out ; U out = t ; y[perm[i]] = out[i]
+__global__ __launch_bounds__(kTrsBlock) void trs_solve_kernel(
+    int64_t n, const schwz_idx *__restrict__ perm, const schwz_idx *__restrict__ l_rp,
+    const schwz_idx *__restrict__ l_col, const double *__restrict__ l_val,
+    const schwz_idx *__restrict__ l_order, const schwz_idx *__restrict__ l_lvl, int l_nlvl,
+    const schwz_idx *__restrict__ u_rp, const schwz_idx *__restrict__ u_col,
+    const double *__restrict__ u_val, const schwz_idx *__restrict__ u_order,
+    const schwz_idx *__restrict__ u_lvl, int u_nlvl, const double *__restrict__ b,
+    double *__restrict__ y, double *w0, double *w1)
+{
+    const int tid = threadIdx.x;
+    for (int64_t i = tid; i < n; i += kTrsBlock) w0[i] = b[perm[i]];
+    __threadfence_block();
+    __syncthreads();
+    for (int lv = 0; lv < l_nlvl; ++lv) {
+        for (int k = l_lvl[lv] + tid; k < l_lvl[lv + 1]; k += kTrsBlock) {
+            const int row = l_order[k];
+            const int e = l_rp[row + 1] - 1;
+            double s = w0[row];
+            for (int j = l_rp[row]; j < e; ++j) s -= l_val[j] * w1[l_col[j]];
+            w1[row] = s / l_val[e];
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    for (int lv = 0; lv < u_nlvl; ++lv) {
+        for (int k = u_lvl[lv] + tid; k < u_lvl[lv + 1]; k += kTrsBlock) {
+            const int row = u_order[k];
+            const int s0 = u_rp[row];
+            double s = w1[row];
+            for (int j = s0 + 1; j < u_rp[row + 1]; ++j) s -= u_val[j] * w0[u_col[j]];
+            w0[row] = s / u_val[s0];
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    for (int64_t i = tid; i < n; i += kTrsBlock) y[perm[i]] = w0[i];
+}
+
+}  // namespace schwz
+
+// ===========================================================================
+// C ABI: stand-alone device objects
+// ===========================================================================
+
+using namespace schwz;
+
+extern "C" {
+
+int schwz_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int schwz_set_device(int device)
+{
+    SCHWZ_HIP_TRY(hipSetDevice(device));
+    return SCHWZ_OK;
+}
+
+#define LAUNCH_GS(kern, OPV)                                                                       \
+    hipLaunchKernelGGL((kern<OPV>), dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, n, \
+                       d_idx, d_from, d_into)
+
+int schwz_gather(int64_t n, const schwz_idx *d_idx, const double *d_from, double *d_into, int op,
+                 schwz_stream stream)
+{
+    SCHWZ_REQUIRE(n >= 0, "schwz_gather: negative length");
+    if (n == 0) return SCHWZ_OK;
+    switch (op) {
+    case SCHWZ_OP_COPY: LAUNCH_GS(gather_kernel, SCHWZ_OP_COPY); break;
+    case SCHWZ_OP_ADD: LAUNCH_GS(gather_kernel, SCHWZ_OP_ADD); break;
+    case SCHWZ_OP_DIFF: LAUNCH_GS(gather_kernel, SCHWZ_OP_DIFF); break;
+    case SCHWZ_OP_AVG: LAUNCH_GS(gather_kernel, SCHWZ_OP_AVG); break;
+    default: set_error("Undefined gather operation"); return SCHWZ_ERR_INVALID;
+    }
+    SCHWZ_HIP_TRY(hipGetLastError());
+    return SCHWZ_OK;
+}
+
+int schwz_scatter(int64_t n, const schwz_idx *d_idx, const double *d_from, double *d_into, int op,
+                  schwz_stream stream)
+{
+    SCHWZ_REQUIRE(n >= 0, "schwz_scatter: negative length");
+    if (n == 0) return SCHWZ_OK;
+    switch (op) {
+    case SCHWZ_OP_COPY: LAUNCH_GS(scatter_kernel, SCHWZ_OP_COPY); break;
+    case SCHWZ_OP_ADD: LAUNCH_GS(scatter_kernel, SCHWZ_OP_ADD); break;
+    case SCHWZ_OP_DIFF: LAUNCH_GS(scatter_kernel, SCHWZ_OP_DIFF); break;
+    case SCHWZ_OP_AVG: LAUNCH_GS(scatter_kernel, SCHWZ_OP_AVG); break;
+    default: set_error("Undefined scatter operation"); return SCHWZ_ERR_INVALID;
+    }
+    SCHWZ_HIP_TRY(hipGetLastError());
+    return SCHWZ_OK;
+}
+#undef LAUNCH_GS
+
+// ---- CSR --------------------------------------------------------------------
+
+}  // extern "C"
+
+template <typename T>
+static int upload(const T *h, size_t count, void **d)
+{
+    *d = nullptr;
+    SCHWZ_HIP_TRY(hipMalloc(d, (count ? count : 1) * sizeof(T)));
+    if (count) SCHWZ_HIP_TRY(hipMemcpy(*d, h, count * sizeof(T), hipMemcpyHostToDevice));
+    return SCHWZ_OK;
+}
+
+extern "C" {
+
+int schwz_csr_create(int64_t nrows, int64_t ncols, const schwz_idx *h_rp, const schwz_idx *h_col,
+                     const double *h_val, schwz_csr **out)
+{
+    SCHWZ_REQUIRE(out && nrows >= 0 && ncols >= 0 && h_rp, "schwz_csr_create: bad arguments");
+    SCHWZ_REQUIRE(nrows < INT32_MAX, "schwz_csr_create: more than 2^31-1 local rows");
+    const int64_t nnz = h_rp[nrows];
+    SCHWZ_REQUIRE(h_rp[0] == 0 && nnz >= 0, "schwz_csr_create: malformed row_ptr");
+    // row tiles: consecutive rows, <= kTileRows rows and <= kTileNnz nonzeros; a
+    // row longer than kTileNnz forms a tile of its own.
+    std::vector<schwz_idx> tiles;
+    tiles.reserve((size_t)(nrows / 128 + 2));
+    tiles.push_back(0);
+    int64_t r = 0;
+    while (r < nrows) {
+        int64_t e = r;
+        const int64_t s = h_rp[r];
+        while (e < nrows && e - r < kTileRows && h_rp[e + 1] - s <= kTileNnz) ++e;
+        if (e == r) e = r + 1;  // long row
+        tiles.push_back((schwz_idx)e);
+        r = e;
+    }
+    for (int64_t i = 0; i < nnz; ++i) {
+        if (h_col[i] < 0 || h_col[i] >= ncols) {
+            set_error("schwz_csr_create: column index out of range");
+            return SCHWZ_ERR_INVALID;
+        }
+    }
+    schwz_csr *A = new schwz_csr();
+    int rc;
+    if ((rc = upload(h_rp, (size_t)nrows + 1, &A->d_rp)) || (rc = upload(h_col, (size_t)nnz, &A->d_col)) ||
+        (rc = upload(h_val, (size_t)nnz, &A->d_val)) || (rc = upload(tiles.data(), tiles.size(), &A->d_tile))) {
+        schwz_csr_destroy(A);
+        return rc;
+    }
+    A->v.nrows = nrows;
+    A->v.ncols = ncols;
+    A->v.nnz = nnz;
+    A->v.rp = (const schwz_idx *)A->d_rp;
+    A->v.col = (const schwz_idx *)A->d_col;
+    A->v.val = (const double *)A->d_val;
+    A->v.ntiles = (int)tiles.size() - 1;
+    A->v.tile_row = (const schwz_idx *)A->d_tile;
+    *out = A;
+    return SCHWZ_OK;
+}
+
+void schwz_csr_destroy(schwz_csr *A)
+{
+    if (!A) return;
+    (void)hipFree(A->d_rp);
+    (void)hipFree(A->d_col);
+    (void)hipFree(A->d_val);
+    (void)hipFree(A->d_tile);
+    delete A;
+}
+
+int64_t schwz_csr_nnz(const schwz_csr *A) { return A ? A->v.nnz : 0; }
+
+int schwz_csr_spmv(const schwz_csr *A, double alpha, const double *d_x, double beta, double *d_y,
+                   int variant, schwz_stream stream)
+{
+    SCHWZ_REQUIRE(A && d_x && d_y, "schwz_csr_spmv: null argument");
+    SpmvArgs a;
+    a.alpha = alpha;
+    a.beta = beta;
+    a.x = d_x;
+    a.y = d_y;
+    return launch_spmv(A->v, kSpmvPlain, a, variant, (hipStream_t)stream);
+}
+
+// ---- profiling hooks (bench.py roofline leg) ------------------------------------
+// HIP-event pairs around every launch of the dominant kernel (the CSR SpMV of the
+// PCG iteration) on the stream it is launched on.
+}  // extern "C"
+
+namespace {
+struct ProfState {
+    bool on = false;
+    std::vector<hipEvent_t> ev;
+    size_t used = 0;
+} g_prof;
+}  // namespace
+
+extern "C" {
+
+int schwz_profile_begin(int capacity)
+{
+    SCHWZ_REQUIRE(capacity > 0, "schwz_profile_begin: capacity must be positive");
+    while (g_prof.ev.size() < (size_t)2 * capacity) {
+        hipEvent_t e;
+        SCHWZ_HIP_TRY(hipEventCreate(&e));
+        g_prof.ev.push_back(e);
+    }
+    g_prof.used = 0;
+    g_prof.on = true;
+    return SCHWZ_OK;
+}
+
+int schwz_profile_end(double *h_total_ms, int64_t *h_launches)
+{
+    SCHWZ_REQUIRE(h_total_ms && h_launches, "schwz_profile_end: null output");
+    g_prof.on = false;
+    SCHWZ_HIP_TRY(hipDeviceSynchronize());
+    double total = 0.0;
+    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+        float ms = 0.f;
+        SCHWZ_HIP_TRY(hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]));
+        total += ms;
+    }
+    *h_total_ms = total;
+    *h_launches = (int64_t)(g_prof.used / 2);
+    g_prof.used = 0;
+    return SCHWZ_OK;
+}
+
+// ---- PCG --------------------------------------------------------------------
+
+int schwz_pcg_create(const schwz_csr *A, int precond, schwz_pcg **out)
+{
+    SCHWZ_REQUIRE(A && out, "schwz_pcg_create: null argument");
+    SCHWZ_REQUIRE(A->v.nrows == A->v.ncols, "schwz_pcg_create: matrix not square");
+    SCHWZ_REQUIRE(precond == SCHWZ_PRECOND_NONE || precond == SCHWZ_PRECOND_JACOBI,
+                  "schwz_pcg_create: unknown preconditioner");
+    schwz_pcg *s = new schwz_pcg();
+    s->A = A;
+    s->precond = precond;
+    s->n = A->v.nrows;
+    const size_t nb = (size_t)(s->n ? s->n : 1) * sizeof(double);
+    SCHWZ_HIP_TRY(hipMalloc((void **)&s->r, nb));
+    SCHWZ_HIP_TRY(hipMalloc((void **)&s->p, nb));
+    SCHWZ_HIP_TRY(hipMalloc((void **)&s->q, nb));
+    SCHWZ_HIP_TRY(hipMalloc((void **)&s->partials, sizeof(double) * 4 * kMaxGrid));
+    SCHWZ_HIP_TRY(hipMalloc((void **)&s->state, sizeof(CgState)));
+    SCHWZ_HIP_TRY(hipHostMalloc((void **)&s->h_state, 2 * sizeof(CgState), hipHostMallocDefault));
+    SCHWZ_HIP_TRY(hipEventCreateWithFlags(&s->ev[0], hipEventDisableTiming));
+    SCHWZ_HIP_TRY(hipEventCreateWithFlags(&s->ev[1], hipEventDisableTiming));
+    if (precond == SCHWZ_PRECOND_JACOBI) {
+        SCHWZ_HIP_TRY(hipMalloc((void **)&s->dinv, nb));
+        if (s->n) {
+            hipLaunchKernelGGL(extract_dinv_kernel, dim3(grid_for(s->n)), dim3(kBlock), 0, 0, A->v, s->dinv);
+            SCHWZ_HIP_TRY(hipGetLastError());
+            SCHWZ_HIP_TRY(hipDeviceSynchronize());
+        }
+    }
+    *out = s;
+    return SCHWZ_OK;
+}
+
+void schwz_pcg_destroy(schwz_pcg *s)
+{
+    if (!s) return;
+    (void)hipFree(s->r);
+    (void)hipFree(s->p);
+    (void)hipFree(s->q);
+    (void)hipFree(s->dinv);
+    (void)hipFree(s->partials);
+    (void)hipFree(s->state);
+    (void)hipHostFree(s->h_state);
+    if (s->ev[0]) (void)hipEventDestroy(s->ev[0]);
+    if (s->ev[1]) (void)hipEventDestroy(s->ev[1]);
+    delete s;
+}
+
+int schwz_pcg_solve(schwz_pcg *s, const double *d_b, double *d_x, double rtol, int max_iters,
+                    int *h_iters, double *h_resnorm, schwz_stream stream)
+{
+    SCHWZ_REQUIRE(s && d_b && d_x, "schwz_pcg_solve: null argument");
+    SCHWZ_REQUIRE(max_iters >= 0, "schwz_pcg_solve: negative max_iters");
+    SCHWZ_REQUIRE((reinterpret_cast<uintptr_t>(d_x) & 15) == 0, "schwz_pcg_solve: x must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const CsrView &A = s->A->v;
+    const int64_t n = s->n;
+    if (n == 0) {
+        if (h_iters) *h_iters = 0;
+        if (h_resnorm) *h_resnorm = 0.0;
+        return SCHWZ_OK;
+    }
+    const int gs = spmv_grid(A);
+    const int gv = grid_for((n + 1) / 2);
+    double *part_spmv = s->partials;             // [2][gs]
+    double *part_vec = s->partials + 2 * kMaxGrid;  // [2][gv]
+    // r = b - A x ; p = M^-1 r ; rho, rr
+    {
+        SpmvArgs a;
+        a.x = d_x;
+        a.b = d_b;
+        a.y = s->r;
+        a.p = s->p;
+        a.dinv = s->dinv;
+        a.partials = part_spmv;
+        int rc = launch_spmv(A, kSpmvResidInit, a, s->variant, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(cg_init_finalize_kernel, dim3(1), dim3(kBlock), 0, st, s->state, part_spmv, gs, rtol);
+    }
+    // With a positive tolerance the host looks at the state every `chunk`
+    // iterations, one chunk behind the launches, so the queue never drains.
+    const bool poll = rtol > 0.0;
+    int chunk = 16;
+    int it = 0, pending = -1, bank = 0;
+    bool stopped = false;
+    while (it < max_iters && !stopped) {
+        const int end = (poll && it + chunk < max_iters) ? it + chunk : max_iters;
+        for (; it < end; ++it) {
+            SpmvArgs a;
+            a.x = s->p;
+            a.y = s->q;
+            a.partials = part_spmv;
+            a.stop_iter = &s->state->stop_iter;
+            a.it = it;
+            const bool prof = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
+            if (prof) SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used], st));
+            int rc = launch_spmv(A, kSpmvDot, a, s->variant, st);
+            if (rc) return rc;
+            if (prof) {
+                SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used + 1], st));
+                g_prof.used += 2;
+            }
+            hipLaunchKernelGGL(cg_update_kernel, dim3(gv), dim3(kBlock), 0, st, n, d_x, s->r, s->p, s->q,
+                               s->dinv, part_spmv, gs, s->state, it, part_vec);
+            hipLaunchKernelGGL(cg_direction_kernel, dim3(gv), dim3(kBlock), 0, st, n, s->p, s->r, s->dinv,
+                               part_vec, gv, s->state, it, rtol);
+        }
+        SCHWZ_HIP_TRY(hipGetLastError());
+        if (poll && it < max_iters) {
+            if (pending >= 0) {
+                SCHWZ_HIP_TRY(hipEventSynchronize(s->ev[pending]));
+                if (s->h_state[pending].stop_iter != INT_MAX) stopped = true;
+            }
+            SCHWZ_HIP_TRY(hipMemcpyAsync(&s->h_state[bank], s->state, sizeof(CgState), hipMemcpyDeviceToHost, st));
+            SCHWZ_HIP_TRY(hipEventRecord(s->ev[bank], st));
+            pending = bank;
+            bank ^= 1;
+            if (chunk < 64) chunk *= 2;
+        }
+    }
+    if (h_iters || h_resnorm) {
+        SCHWZ_HIP_TRY(hipMemcpyAsync(&s->h_state[0], s->state, sizeof(CgState), hipMemcpyDeviceToHost, st));
+        SCHWZ_HIP_TRY(hipStreamSynchronize(st));
+        if (h_iters) *h_iters = s->h_state[0].iters;
+        if (h_resnorm) *h_resnorm = sqrt(s->h_state[0].rr);
+    }
+    return SCHWZ_OK;
+}
+
+// ---- triangular solves --------------------------------------------------------
+
+// levels of a triangular CSR: lower => forward dependencies on columns < row
+static void level_schedule(int64_t n, const schwz_idx *rp, const schwz_idx *col, bool lower,
+                           std::vector<schwz_idx> &order, std::vector<schwz_idx> &lvl_ptr)
+{
+    std::vector<schwz_idx> level((size_t)n, 0);
+    schwz_idx nl = 0;
+    if (lower) {
+        for (int64_t i = 0; i < n; ++i) {
+            schwz_idx l = 0;
+            for (schwz_idx j = rp[i]; j < rp[i + 1]; ++j)
+                if (col[j] < i && level[col[j]] + 1 > l) l = level[col[j]] + 1;
+            level[i] = l;
+            if (l + 1 > nl) nl = l + 1;
+        }
+    } else {
+        for (int64_t i = n - 1; i >= 0; --i) {
+            schwz_idx l = 0;
+            for (schwz_idx j = rp[i]; j < rp[i + 1]; ++j)
+                if (col[j] > i && level[col[j]] + 1 > l) l = level[col[j]] + 1;
+            level[i] = l;
+            if (l + 1 > nl) nl = l + 1;
+        }
+    }
+    lvl_ptr.assign((size_t)nl + 1, 0);
+    for (int64_t i = 0; i < n; ++i) lvl_ptr[level[i] + 1]++;
+    for (schwz_idx l = 0; l < nl; ++l) lvl_ptr[l + 1] += lvl_ptr[l];
+    order.resize((size_t)n);
+    std::vector<schwz_idx> fill(lvl_ptr.begin(), lvl_ptr.end() - 1);
+    for (int64_t i = 0; i < n; ++i) order[fill[level[i]]++] = (schwz_idx)i;
+}
+
+int schwz_trs_create(int64_t n, const schwz_idx *l_rp, const schwz_idx *l_col, const double *l_val,
+                     const schwz_idx *u_rp, const schwz_idx *u_col, const double *u_val,
+                     const schwz_idx *perm, schwz_trs **out)
+{
+    SCHWZ_REQUIRE(out && n >= 0 && l_rp && u_rp && perm, "schwz_trs_create: bad arguments");
+    for (int64_t i = 0; i < n; ++i) {
+        SCHWZ_REQUIRE(l_rp[i + 1] > l_rp[i] && l_col[l_rp[i + 1] - 1] == i,
+                      "schwz_trs_create: L must hold its diagonal last in each row");
+        SCHWZ_REQUIRE(u_rp[i + 1] > u_rp[i] && u_col[u_rp[i]] == i,
+                      "schwz_trs_create: U must hold its diagonal first in each row");
+        SCHWZ_REQUIRE(perm[i] >= 0 && perm[i] < n, "schwz_trs_create: permutation out of range");
+    }
+    schwz_trs *t = new schwz_trs();
+    t->n = n;
+    std::vector<schwz_idx> lo, ll, uo, ul;
+    level_schedule(n, l_rp, l_col, true, lo, ll);
+    level_schedule(n, u_rp, u_col, false, uo, ul);
+    t->l_nlvl = (int)ll.size() - 1;
+    t->u_nlvl = (int)ul.size() - 1;
+    int rc = 0;
+    void *d;
+#define UP(dst, src, cnt, T)                        \
+    if (!rc) {                                      \
+        rc = upload<T>((src), (size_t)(cnt), &d);   \
+        dst = (decltype(dst))d;                     \
+    }
+    UP(t->l_rp, l_rp, n + 1, schwz_idx)
+    UP(t->l_col, l_col, l_rp[n], schwz_idx)
+    UP(t->l_val, l_val, l_rp[n], double)
+    UP(t->u_rp, u_rp, n + 1, schwz_idx)
+    UP(t->u_col, u_col, u_rp[n], schwz_idx)
+    UP(t->u_val, u_val, u_rp[n], double)
+    UP(t->perm, perm, n, schwz_idx)
+    UP(t->l_order, lo.data(), lo.size(), schwz_idx)
+    UP(t->l_lvl, ll.data(), ll.size(), schwz_idx)
+    UP(t->u_order, uo.data(), uo.size(), schwz_idx)
+    UP(t->u_lvl, ul.data(), ul.size(), schwz_idx)
+#undef UP
+    if (rc) {
+        schwz_trs_destroy(t);
+        return rc;
+    }
+    SCHWZ_HIP_TRY(hipMalloc((void **)&t->w0, sizeof(double) * (size_t)(n ? n : 1)));
+    SCHWZ_HIP_TRY(hipMalloc((void **)&t->w1, sizeof(double) * (size_t)(n ? n : 1)));
+    *out = t;
+    return SCHWZ_OK;
+}
+
+void schwz_trs_destroy(schwz_trs *t)
+{
+    if (!t) return;
+    void *ptrs[] = {t->l_rp, t->l_col, t->l_val, t->u_rp, t->u_col, t->u_val, t->perm,
+                    t->l_order, t->l_lvl, t->u_order, t->u_lvl, t->w0, t->w1};
+    for (void *p : ptrs) (void)hipFree(p);
+    delete t;
+}
+
+int schwz_trs_solve(schwz_trs *t, const double *d_b, double *d_y, schwz_stream stream)
+{
+    SCHWZ_REQUIRE(t && d_b && d_y, "schwz_trs_solve: null argument");
+    if (t->n == 0) return SCHWZ_OK;
+    hipLaunchKernelGGL(trs_solve_kernel, dim3(1), dim3(kTrsBlock), 0, (hipStream_t)stream, t->n, t->perm,
+                       t->l_rp, t->l_col, t->l_val, t->l_order, t->l_lvl, t->l_nlvl, t->u_rp, t->u_col,
+                       t->u_val, t->u_order, t->u_lvl, t->u_nlvl, d_b, d_y, t->w0, t->w1);
+    SCHWZ_HIP_TRY(hipGetLastError());
+    return SCHWZ_OK;
+}
+
+}  // extern "C"
+
+// ===========================================================================
+// kernels used by subdomain.hip
+// ===========================================================================
+
+namespace schwz {
+
+int launch_interface_update(int64_t nrows, int64_t row0, const schwz_idx *rp, const schwz_idx *col,
+                            const double *val, const double *x, const double *b, double *bt, hipStream_t s)
+{
+    if (nrows == 0) return SCHWZ_OK;
+    hipLaunchKernelGGL(interface_update_kernel, dim3(grid_for(nrows)), dim3(kBlock), 0, s, nrows, row0, rp,
+                       col, val, x, b, bt);
+    SCHWZ_HIP_TRY(hipGetLastError());
+    return SCHWZ_OK;
+}
+
+int launch_final_norm(const double *partials, int nparts, double *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(final_norm_kernel, dim3(1), dim3(kBlock), 0, s, partials, nparts, out);
+    SCHWZ_HIP_TRY(hipGetLastError());
+    return SCHWZ_OK;
+}
+
+}  // namespace schwz

@@ -1,0 +1,171 @@
+// Internal declarations shared by the translation units of libschwz_hip.so.
+// Not part of the ABI (include/schwz_hip.h is).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "schwz_hip.h"
+
+namespace schwz {
+
+void set_error(const std::string &msg);
+
+#define SCHWZ_HIP_TRY(expr)                                                        \
+    do {                                                                           \
+        hipError_t e_ = (expr);                                                    \
+        if (e_ != hipSuccess) {                                                    \
+            ::schwz::set_error(std::string(__FILE__) + ":" + std::to_string(__LINE__) + \
+                               ": " #expr " -> " + hipGetErrorString(e_));         \
+            return SCHWZ_ERR_HIP;                                                  \
+        }                                                                          \
+    } while (0)
+
+#define SCHWZ_REQUIRE(cond, msg)                      \
+    do {                                              \
+        if (!(cond)) {                                \
+            ::schwz::set_error(std::string(msg));     \
+            return SCHWZ_ERR_INVALID;                 \
+        }                                             \
+    } while (0)
+
+// ---- SpMV tiling constants (see DESIGN.md "CSR SpMV") ------------------------
+constexpr int kBlock = 256;      // threads per workgroup = 4 waves of 64
+constexpr int kTileNnz = 2048;   // products staged in LDS per tile (16 KiB fp64)
+constexpr int kTileRows = 256;   // one lane per row in the reduction phase
+constexpr int kMaxGrid = 2048;   // 256 CUs x 8 workgroups, grid-stride beyond
+constexpr int kXcds = 8;
+
+struct CsrView {
+    int64_t nrows = 0, ncols = 0, nnz = 0;
+    const schwz_idx *rp = nullptr;
+    const schwz_idx *col = nullptr;
+    const double *val = nullptr;
+    int ntiles = 0;
+    const schwz_idx *tile_row = nullptr;  // ntiles+1 row boundaries
+};
+
+// epilogues of the tiled SpMV kernel
+enum SpmvMode {
+    kSpmvPlain = 0,      // y = alpha*A*x + beta*y
+    kSpmvDot = 1,        // y = A*x ; partial[b] = sum x_i*y_i
+    kSpmvResidInit = 2,  // r = b - A*x ; p = dinv*r ; partials sum r*z, sum r*r
+    kSpmvResidNorm = 3   // partial sum (b - A*x)^2, nothing stored
+};
+
+struct SpmvArgs {
+    double alpha = 1.0, beta = 0.0;
+    const double *x = nullptr;
+    double *y = nullptr;        // out vector (y / q / r)
+    const double *b = nullptr;  // rhs for the residual modes
+    double *p = nullptr;        // kSpmvResidInit: search direction out
+    const double *dinv = nullptr;
+    double *partials = nullptr;  // [2][grid]
+    const int *stop_iter = nullptr;  // device flag checked by CG launches
+    int it = 0;
+    int64_t row_limit = 0;  // rows >= row_limit are skipped in kSpmvResidNorm
+};
+
+int spmv_grid(const CsrView &A);
+int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipStream_t s);
+
+// device-side CG scalar state
+struct CgState {
+    double rho[2];
+    double rr;
+    double r0;
+    int iters;
+    int stop_iter;
+};
+
+}  // namespace schwz
+
+// ---- opaque ABI types -------------------------------------------------------
+
+struct schwz_csr {
+    schwz::CsrView v;
+    void *d_rp = nullptr, *d_col = nullptr, *d_val = nullptr, *d_tile = nullptr;
+};
+
+struct schwz_pcg {
+    const schwz_csr *A = nullptr;
+    int precond = 0;
+    int64_t n = 0;
+    double *r = nullptr, *p = nullptr, *q = nullptr, *dinv = nullptr;
+    double *partials = nullptr;  // 2 * kMaxGrid * 2 (two banks)
+    schwz::CgState *state = nullptr;
+    schwz::CgState *h_state = nullptr;  // pinned
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int variant = 0;
+};
+
+struct schwz_trs {
+    int64_t n = 0;
+    schwz_idx *l_rp = nullptr, *l_col = nullptr, *u_rp = nullptr, *u_col = nullptr;
+    double *l_val = nullptr, *u_val = nullptr;
+    schwz_idx *perm = nullptr;
+    // level schedules: rows sorted by level, level pointers
+    schwz_idx *l_order = nullptr, *l_lvl = nullptr, *u_order = nullptr, *u_lvl = nullptr;
+    int l_nlvl = 0, u_nlvl = 0;
+    double *w0 = nullptr, *w1 = nullptr;
+};
+
+// host-side global problem (explicit CSR or analytic stencil)
+struct schwz_problem {
+    int kind = 0;  // 0 csr, 2 lap2d, 3 lap3d
+    int64_t N = 0;
+    int64_t nx = 0, ny = 0, nz = 0;
+    std::vector<int64_t> rp;
+    std::vector<schwz_idx> col;
+    std::vector<double> val;
+    int64_t nnz() const;
+    // writes up to 16 (stencil) or row-length entries; returns count
+    int row(int64_t g, int64_t *cols, double *vals) const;
+    int max_row_nnz = 0;
+};
+
+struct schwz_subdomain {
+    // ---- host index sets -------------------------------------------------
+    int P = 0, me = 0, overlap = 0;
+    int64_t N = 0;
+    std::vector<int64_t> first_row;
+    int64_t local_size = 0, local_size_x = 0, overlap_size = 0, halo_size = 0;
+    std::vector<int64_t> l2g;                      // local_size_x + halo
+    std::unordered_map<int64_t, schwz_idx> g2l_x;  // non-interior global -> local
+    std::vector<schwz_idx> l_rp, l_col;
+    std::vector<double> l_val;
+    std::vector<schwz_idx> i_rp;       // interface rows (local_size_x+1)
+    std::vector<int64_t> i_col_global;
+    std::vector<double> i_val;
+    std::vector<int> nbr_in, nbr_out;
+    std::vector<std::vector<int64_t>> get, put;  // global ids
+    int64_t num_recv = 0, num_send = 0;
+    schwz_idx to_local(int64_t g) const
+    {
+        if (g >= first_row[me] && g < first_row[me + 1]) return (schwz_idx)(g - first_row[me]);
+        auto it = g2l_x.find(g);
+        return it == g2l_x.end() ? -1 : it->second;
+    }
+    // ---- device state -----------------------------------------------------
+    bool on_device = false;
+    schwz_solver_options opt{};
+    schwz_csr *A = nullptr;  // local_matrix
+    schwz_pcg *cg = nullptr;
+    schwz_trs *trs = nullptr;
+    // interface rows: only overlap rows are non-empty; stored compactly
+    schwz_idx *d_i_rp = nullptr, *d_i_col = nullptr;  // cols index x~ directly
+    double *d_i_val = nullptr;
+    int64_t nnz_interface = 0;
+    schwz_idx *d_put_idx = nullptr, *d_get_idx = nullptr;  // local ids, packed
+    double *d_x = nullptr;       // x~ [interior|overlap|halo]
+    double *d_rhs = nullptr;     // b_loc
+    double *d_btilde = nullptr;  // b~ = local_solution on entry of the solve
+    double *d_y = nullptr;       // init_guess / solve result
+    double *d_partials = nullptr;
+    double *h_scalar = nullptr;  // pinned
+};

@@ -1,0 +1,261 @@
+// Device-resident RAS iteration of one subdomain: the five steps of
+// SchwarzBase::run (source/schwarz_base.cpp:387-452) as stream-ordered launches.
+//
+// HBM layout per subdomain (one GPU):
+//   x~      [interior | overlap | halo]  doubles   -- replaces the N-long
+//           global_solution of the reference (schwarz_base.cpp:340-341)
+//   A_loc   CSR over [interior|overlap] rows and columns, int32 indices
+//   A_Gamma CSR over the overlap rows only, columns index x~ directly
+//   b_loc, b~, y (CG warm start), r, p, q, 1/diag : local_size_x doubles each
+//   put / get lists: int32 local ids, packed in neighbour order
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "schwz_internal.hpp"
+
+namespace schwz {
+int launch_interface_update(int64_t nrows, int64_t row0, const schwz_idx *rp, const schwz_idx *col,
+                            const double *val, const double *x, const double *b, double *bt, hipStream_t s);
+int launch_final_norm(const double *partials, int nparts, double *out, hipStream_t s);
+}  // namespace schwz
+
+using namespace schwz;
+
+template <typename T>
+static int dev_upload(const std::vector<T> &h, T **d)
+{
+    *d = nullptr;
+    SCHWZ_HIP_TRY(hipMalloc((void **)d, (h.empty() ? 1 : h.size()) * sizeof(T)));
+    if (!h.empty()) SCHWZ_HIP_TRY(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return SCHWZ_OK;
+}
+
+static int dev_zeros(int64_t n, double **d)
+{
+    *d = nullptr;
+    SCHWZ_HIP_TRY(hipMalloc((void **)d, (size_t)(n ? n : 1) * sizeof(double)));
+    SCHWZ_HIP_TRY(hipMemset(*d, 0, (size_t)(n ? n : 1) * sizeof(double)));
+    return SCHWZ_OK;
+}
+
+extern "C" {
+
+void schwz_subdomain_destroy(schwz_subdomain *sd)
+{
+    if (!sd) return;
+    if (sd->on_device) {
+        schwz_pcg_destroy(sd->cg);
+        schwz_trs_destroy(sd->trs);
+        schwz_csr_destroy(sd->A);
+        void *ptrs[] = {sd->d_i_rp, sd->d_i_col, sd->d_i_val, sd->d_put_idx, sd->d_get_idx, sd->d_x,
+                        sd->d_rhs, sd->d_btilde, sd->d_y, sd->d_partials};
+        for (void *p : ptrs) (void)hipFree(p);
+        if (sd->h_scalar) (void)hipHostFree(sd->h_scalar);
+    }
+    delete sd;
+}
+
+int schwz_subdomain_to_device(schwz_subdomain *sd, const double *h_local_rhs, const schwz_solver_options *opt)
+{
+    SCHWZ_REQUIRE(sd && h_local_rhs && opt, "schwz_subdomain_to_device: null argument");
+    SCHWZ_REQUIRE(!sd->on_device, "schwz_subdomain_to_device: already on the device");
+    SCHWZ_REQUIRE(opt->local_solver == SCHWZ_SOLVER_ITERATIVE || opt->local_solver == SCHWZ_SOLVER_DIRECT,
+                  "schwz_subdomain_to_device: unknown local solver");
+    if (schwz_device_count() < 1) {
+        set_error("schwz_subdomain_to_device: no HIP device visible (there is no CPU fallback)");
+        return SCHWZ_ERR_HIP;
+    }
+    sd->opt = *opt;
+    const int64_t n = sd->local_size_x;
+    const int64_t nx = n + sd->halo_size;
+    int rc;
+    // every received id must have a slot in x~ and every interface column too
+    std::vector<schwz_idx> put_idx, get_idx;
+    put_idx.reserve((size_t)sd->num_send);
+    get_idx.reserve((size_t)sd->num_recv);
+    for (const auto &lst : sd->put)
+        for (int64_t g : lst) put_idx.push_back((schwz_idx)(g - sd->first_row[sd->me]));
+    for (const auto &lst : sd->get)
+        for (int64_t g : lst) {
+            const schwz_idx l = sd->to_local(g);
+            SCHWZ_REQUIRE(l >= sd->local_size && l < nx, "get list id is not an overlap/halo id");
+            get_idx.push_back(l);
+        }
+    // interface rows, compact over the overlap rows, columns -> x~ slots
+    std::vector<schwz_idx> i_rp((size_t)sd->overlap_size + 1, 0), i_col(sd->i_col_global.size());
+    for (int64_t r = 0; r < sd->overlap_size; ++r)
+        i_rp[(size_t)r + 1] = sd->i_rp[(size_t)(sd->local_size + r) + 1];
+    for (size_t k = 0; k < i_col.size(); ++k) {
+        const schwz_idx l = sd->to_local(sd->i_col_global[k]);
+        SCHWZ_REQUIRE(l >= n && l < nx, "interface column is not a halo id");
+        i_col[k] = l;
+    }
+    sd->nnz_interface = (int64_t)i_col.size();
+    if ((rc = schwz_csr_create(n, n, sd->l_rp.data(), sd->l_col.data(), sd->l_val.data(), &sd->A))) return rc;
+    sd->on_device = true;  // from here on destroy() releases device memory
+    if ((rc = dev_upload(i_rp, &sd->d_i_rp)) || (rc = dev_upload(i_col, &sd->d_i_col)) ||
+        (rc = dev_upload(sd->i_val, &sd->d_i_val)) || (rc = dev_upload(put_idx, &sd->d_put_idx)) ||
+        (rc = dev_upload(get_idx, &sd->d_get_idx)))
+        return rc;
+    if ((rc = dev_zeros(nx, &sd->d_x)) || (rc = dev_zeros(n, &sd->d_y))) return rc;
+    std::vector<double> rhs(h_local_rhs, h_local_rhs + n);
+    if ((rc = dev_upload(rhs, &sd->d_rhs)) || (rc = dev_upload(rhs, &sd->d_btilde))) return rc;
+    SCHWZ_HIP_TRY(hipMalloc((void **)&sd->d_partials, sizeof(double) * (2 * kMaxGrid + 2)));
+    SCHWZ_HIP_TRY(hipHostMalloc((void **)&sd->h_scalar, 4 * sizeof(double), hipHostMallocDefault));
+    if (opt->local_solver == SCHWZ_SOLVER_ITERATIVE) {
+        if ((rc = schwz_pcg_create(sd->A, opt->precond, &sd->cg))) return rc;
+        sd->cg->variant = opt->spmv_variant;
+    } else {
+        // Solve::compute_local_factors + the Ginkgo TRS setup (solve.cpp:75-143,281-399)
+        schwz_idx *l_rp, *l_col, *u_rp, *u_col, *perm;
+        double *l_val, *u_val;
+        if ((rc = schwz_cholesky(n, sd->l_rp.data(), sd->l_col.data(), sd->l_val.data(),
+                                 opt->natural_factor_ordering, &l_rp, &l_col, &l_val, &u_rp, &u_col, &u_val,
+                                 &perm)))
+            return rc;
+        rc = schwz_trs_create(n, l_rp, l_col, l_val, u_rp, u_col, u_val, perm, &sd->trs);
+        schwz_free(l_rp);
+        schwz_free(l_col);
+        schwz_free(l_val);
+        schwz_free(u_rp);
+        schwz_free(u_col);
+        schwz_free(u_val);
+        schwz_free(perm);
+        if (rc) return rc;
+    }
+    SCHWZ_HIP_TRY(hipDeviceSynchronize());
+    return SCHWZ_OK;
+}
+
+#define REQUIRE_DEVICE(sd, name) \
+    SCHWZ_REQUIRE((sd) && (sd)->on_device, name ": subdomain is not on the device")
+
+int schwz_ras_pack(schwz_subdomain *sd, double *d_send, schwz_stream stream)
+{
+    REQUIRE_DEVICE(sd, "schwz_ras_pack");
+    if (sd->num_send == 0) return SCHWZ_OK;
+    SCHWZ_REQUIRE(d_send, "schwz_ras_pack: null send buffer");
+    return schwz_gather(sd->num_send, sd->d_put_idx, sd->d_x, d_send, SCHWZ_OP_COPY, stream);
+}
+
+int schwz_ras_unpack(schwz_subdomain *sd, const double *d_recv, schwz_stream stream)
+{
+    REQUIRE_DEVICE(sd, "schwz_ras_unpack");
+    if (sd->num_recv == 0) return SCHWZ_OK;
+    SCHWZ_REQUIRE(d_recv, "schwz_ras_unpack: null recv buffer");
+    return schwz_scatter(sd->num_recv, sd->d_get_idx, d_recv, sd->d_x, SCHWZ_OP_COPY, stream);
+}
+
+int schwz_ras_update_boundary(schwz_subdomain *sd, schwz_stream stream)
+{
+    REQUIRE_DEVICE(sd, "schwz_ras_update_boundary");
+    // rows < local_size have no interface entries: b~ = b there, set at upload.
+    // restricted_schwarz.cpp:1007: only applied when num_subdomains > 1 && overlap > 0
+    if (sd->P <= 1 || sd->nnz_interface == 0) return SCHWZ_OK;
+    return launch_interface_update(sd->overlap_size, sd->local_size, sd->d_i_rp, sd->d_i_col, sd->d_i_val,
+                                   sd->d_x, sd->d_rhs, sd->d_btilde, (hipStream_t)stream);
+}
+
+static int residual_norm_sq(schwz_subdomain *sd, const double *b, int64_t row_limit, double *h_out,
+                            hipStream_t st)
+{
+    SpmvArgs a;
+    a.x = sd->d_x;
+    a.b = b;
+    a.partials = sd->d_partials;
+    a.row_limit = row_limit;
+    int rc = launch_spmv(sd->A->v, kSpmvResidNorm, a, 0, st);
+    if (rc) return rc;
+    const int g = spmv_grid(sd->A->v);
+    double *d_out = sd->d_partials + 2 * kMaxGrid;
+    if ((rc = launch_final_norm(sd->d_partials + g, g, d_out, st))) return rc;
+    SCHWZ_HIP_TRY(hipMemcpyAsync(sd->h_scalar, d_out, sizeof(double), hipMemcpyDeviceToHost, st));
+    SCHWZ_HIP_TRY(hipStreamSynchronize(st));
+    *h_out = sd->h_scalar[0];
+    return SCHWZ_OK;
+}
+
+int schwz_ras_local_residual(schwz_subdomain *sd, double *h_resnorm, schwz_stream stream)
+{
+    REQUIRE_DEVICE(sd, "schwz_ras_local_residual");
+    SCHWZ_REQUIRE(h_resnorm, "schwz_ras_local_residual: null output");
+    if (sd->local_size_x == 0) {
+        *h_resnorm = 0.0;
+        return SCHWZ_OK;
+    }
+    double sq = 0.0;
+    int rc = residual_norm_sq(sd, sd->d_btilde, sd->local_size_x, &sq, (hipStream_t)stream);
+    if (rc) return rc;
+    *h_resnorm = std::sqrt(sq);
+    return SCHWZ_OK;
+}
+
+int schwz_ras_true_residual_sq(schwz_subdomain *sd, double *h_out, schwz_stream stream)
+{
+    REQUIRE_DEVICE(sd, "schwz_ras_true_residual_sq");
+    SCHWZ_REQUIRE(h_out, "schwz_ras_true_residual_sq: null output");
+    if (sd->local_size == 0) {
+        *h_out = 0.0;
+        return SCHWZ_OK;
+    }
+    return residual_norm_sq(sd, sd->d_rhs, sd->local_size, h_out, (hipStream_t)stream);
+}
+
+int schwz_ras_local_solve(schwz_subdomain *sd, int *h_inner_iters, schwz_stream stream)
+{
+    REQUIRE_DEVICE(sd, "schwz_ras_local_solve");
+    if (sd->opt.local_solver == SCHWZ_SOLVER_DIRECT) {
+        if (h_inner_iters) *h_inner_iters = 0;
+        return schwz_trs_solve(sd->trs, sd->d_btilde, sd->d_y, stream);
+    }
+    const int64_t n = sd->local_size_x;
+    const int maxit = sd->opt.local_max_iters == -1 ? (int)n : sd->opt.local_max_iters;
+    return schwz_pcg_solve(sd->cg, sd->d_btilde, sd->d_y, sd->opt.local_tol, maxit, h_inner_iters, nullptr,
+                           stream);
+}
+
+int schwz_ras_restrict(schwz_subdomain *sd, schwz_stream stream)
+{
+    REQUIRE_DEVICE(sd, "schwz_ras_restrict");
+    if (sd->local_size == 0) return SCHWZ_OK;
+    SCHWZ_HIP_TRY(hipMemcpyAsync(sd->d_x, sd->d_y, (size_t)sd->local_size * sizeof(double),
+                                 hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return SCHWZ_OK;
+}
+
+int schwz_ras_vector(schwz_subdomain *sd, int which, double **d_ptr, int64_t *len)
+{
+    REQUIRE_DEVICE(sd, "schwz_ras_vector");
+    SCHWZ_REQUIRE(d_ptr && len, "schwz_ras_vector: null output");
+    switch (which) {
+    case 0: *d_ptr = sd->d_x; *len = sd->local_size_x + sd->halo_size; break;
+    case 1: *d_ptr = sd->d_btilde; *len = sd->local_size_x; break;
+    case 2: *d_ptr = sd->d_y; *len = sd->local_size_x; break;
+    case 3: *d_ptr = sd->d_rhs; *len = sd->local_size_x; break;
+    default: set_error("schwz_ras_vector: unknown vector id"); return SCHWZ_ERR_INVALID;
+    }
+    return SCHWZ_OK;
+}
+
+int schwz_ras_get_interior(schwz_subdomain *sd, double *h_out, schwz_stream stream)
+{
+    REQUIRE_DEVICE(sd, "schwz_ras_get_interior");
+    SCHWZ_REQUIRE(h_out || sd->local_size == 0, "schwz_ras_get_interior: null output");
+    if (sd->local_size == 0) return SCHWZ_OK;
+    SCHWZ_HIP_TRY(hipMemcpyAsync(h_out, sd->d_x, (size_t)sd->local_size * sizeof(double), hipMemcpyDeviceToHost,
+                                 (hipStream_t)stream));
+    SCHWZ_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return SCHWZ_OK;
+}
+
+// B_spmv = 12 nnz + 4 (n+1) + 16 n ; one PCG iteration = B_spmv + 136 n
+int64_t schwz_ras_algorithmic_bytes(const schwz_subdomain *sd, int which)
+{
+    if (!sd) return 0;
+    const int64_t n = sd->local_size_x, nnz = (int64_t)sd->l_col.size();
+    const int64_t spmv = 12 * nnz + 4 * (n + 1) + 16 * n;
+    return which == 0 ? spmv : spmv + 136 * n;
+}
+
+}  // extern "C"

@@ -1,0 +1,161 @@
+"""ctypes binding of libschwz_hip.so (the C ABI declared in include/schwz_hip.h).
+
+The library is built in-tree by `make -C schwarz-lib_amd` (see
+__graft_entry__.build).  There is no fallback: if the shared object is missing
+the import of this module raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_PKG), "lib", "libschwz_hip.so")
+
+OK = 0
+ERR_INVALID, ERR_HIP, ERR_NOT_IMPLEMENTED, ERR_NOT_SPD, ERR_IO, ERR_DIVERGED = 1, 2, 3, 4, 5, 6
+OP_ADD, OP_COPY, OP_DIFF, OP_AVG = 0, 1, 2, 3
+SOLVER_ITERATIVE, SOLVER_DIRECT = 0, 1
+PRECOND_NONE, PRECOND_JACOBI = 0, 1
+
+# every symbol include/schwz_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "schwz_last_error", "schwz_version", "schwz_device_count", "schwz_set_device",
+    "schwz_gather", "schwz_scatter",
+    "schwz_csr_create", "schwz_csr_destroy", "schwz_csr_nnz", "schwz_csr_spmv",
+    "schwz_pcg_create", "schwz_pcg_destroy", "schwz_pcg_solve",
+    "schwz_profile_begin", "schwz_profile_end",
+    "schwz_trs_create", "schwz_trs_destroy", "schwz_trs_solve",
+    "schwz_problem_laplacian", "schwz_problem_from_csr", "schwz_problem_from_matrix_market",
+    "schwz_problem_destroy", "schwz_problem_size", "schwz_problem_nnz", "schwz_problem_row",
+    "schwz_problem_permute",
+    "schwz_partition_regular", "schwz_partition_regular2d", "schwz_partition_graph",
+    "schwz_subdomain_setup", "schwz_subdomain_destroy", "schwz_subdomain_sizes",
+    "schwz_subdomain_local_to_global", "schwz_subdomain_local_matrix",
+    "schwz_subdomain_interface_matrix", "schwz_subdomain_get_list",
+    "schwz_subdomain_add_put_list", "schwz_subdomain_put_list",
+    "schwz_subdomain_send_offset", "schwz_subdomain_recv_offset",
+    "schwz_cholesky", "schwz_free",
+    "schwz_subdomain_to_device", "schwz_ras_pack", "schwz_ras_unpack",
+    "schwz_ras_update_boundary", "schwz_ras_local_residual", "schwz_ras_local_solve",
+    "schwz_ras_restrict", "schwz_ras_vector", "schwz_ras_get_interior",
+    "schwz_ras_true_residual_sq", "schwz_ras_algorithmic_bytes",
+]
+
+
+class SchwzError(RuntimeError):
+    """Mirrors the reference's Error hierarchy (include/exception.hpp:42-210)."""
+
+    def __init__(self, code, msg):
+        super().__init__("schwz error %d: %s" % (code, msg))
+        self.code = code
+
+
+class NotImplementedSchwz(SchwzError):
+    pass
+
+
+class SolverOptions(C.Structure):
+    _fields_ = [
+        ("local_solver", C.c_int32),
+        ("precond", C.c_int32),
+        ("local_tol", C.c_double),
+        ("local_max_iters", C.c_int32),
+        ("natural_factor_ordering", C.c_int32),
+        ("spmv_variant", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "libschwz_hip.so not found at %s: build it with `make -C schwarz-lib_amd` "
+        "(there is no CPU fallback)" % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+
+vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int, C.c_double
+pvp = C.POINTER(C.c_void_p)
+
+
+def _sig(name, restype, argtypes):
+    f = getattr(lib, name)
+    f.restype = restype
+    f.argtypes = argtypes
+
+
+_sig("schwz_last_error", C.c_char_p, [])
+_sig("schwz_version", C.c_char_p, [])
+_sig("schwz_device_count", i32, [])
+_sig("schwz_set_device", i32, [i32])
+_sig("schwz_gather", i32, [i64, vp, vp, vp, i32, vp])
+_sig("schwz_scatter", i32, [i64, vp, vp, vp, i32, vp])
+_sig("schwz_csr_create", i32, [i64, i64, vp, vp, vp, pvp])
+_sig("schwz_csr_destroy", None, [vp])
+_sig("schwz_csr_nnz", i64, [vp])
+_sig("schwz_csr_spmv", i32, [vp, dbl, vp, dbl, vp, i32, vp])
+_sig("schwz_pcg_create", i32, [vp, i32, pvp])
+_sig("schwz_pcg_destroy", None, [vp])
+_sig("schwz_pcg_solve", i32, [vp, vp, vp, dbl, i32, C.POINTER(C.c_int), C.POINTER(dbl), vp])
+_sig("schwz_profile_begin", i32, [i32])
+_sig("schwz_profile_end", i32, [C.POINTER(dbl), C.POINTER(i64)])
+_sig("schwz_trs_create", i32, [i64] + [vp] * 7 + [pvp])
+_sig("schwz_trs_destroy", None, [vp])
+_sig("schwz_trs_solve", i32, [vp, vp, vp, vp])
+_sig("schwz_problem_laplacian", i32, [i32, i64, i64, i64, pvp])
+_sig("schwz_problem_from_csr", i32, [i64, vp, vp, vp, pvp])
+_sig("schwz_problem_from_matrix_market", i32, [C.c_char_p, pvp])
+_sig("schwz_problem_destroy", None, [vp])
+_sig("schwz_problem_size", i64, [vp])
+_sig("schwz_problem_nnz", i64, [vp])
+_sig("schwz_problem_row", i32, [vp, i64, C.POINTER(C.c_int), vp, vp, i32])
+_sig("schwz_problem_permute", i32, [vp, i32, vp, vp, vp, pvp])
+_sig("schwz_partition_regular", i32, [i64, i32, vp])
+_sig("schwz_partition_regular2d", i32, [i64, i32, vp])
+_sig("schwz_partition_graph", i32, [vp, i32, vp])
+_sig("schwz_subdomain_setup", i32, [vp, i32, i32, i32, vp, pvp])
+_sig("schwz_subdomain_destroy", None, [vp])
+_sig("schwz_subdomain_sizes", i32, [vp, vp])
+_sig("schwz_subdomain_local_to_global", i32, [vp, vp])
+_sig("schwz_subdomain_local_matrix", i32, [vp, vp, vp, vp])
+_sig("schwz_subdomain_interface_matrix", i32, [vp, vp, vp, vp])
+_sig("schwz_subdomain_get_list", i32, [vp, i32, C.POINTER(C.c_int), C.POINTER(i64), vp])
+_sig("schwz_subdomain_put_list", i32, [vp, i32, C.POINTER(C.c_int), C.POINTER(i64), vp])
+_sig("schwz_subdomain_add_put_list", i32, [vp, i32, i64, vp])
+_sig("schwz_subdomain_send_offset", i32, [vp, i32, C.POINTER(i64)])
+_sig("schwz_subdomain_recv_offset", i32, [vp, i32, C.POINTER(i64)])
+_sig("schwz_cholesky", i32, [i64, vp, vp, vp, i32] + [pvp] * 7)
+_sig("schwz_free", None, [vp])
+_sig("schwz_subdomain_to_device", i32, [vp, vp, C.POINTER(SolverOptions)])
+_sig("schwz_ras_pack", i32, [vp, vp, vp])
+_sig("schwz_ras_unpack", i32, [vp, vp, vp])
+_sig("schwz_ras_update_boundary", i32, [vp, vp])
+_sig("schwz_ras_local_residual", i32, [vp, C.POINTER(dbl), vp])
+_sig("schwz_ras_local_solve", i32, [vp, C.POINTER(C.c_int), vp])
+_sig("schwz_ras_restrict", i32, [vp, vp])
+_sig("schwz_ras_vector", i32, [vp, i32, pvp, C.POINTER(i64)])
+_sig("schwz_ras_get_interior", i32, [vp, vp, vp])
+_sig("schwz_ras_true_residual_sq", i32, [vp, C.POINTER(dbl), vp])
+_sig("schwz_ras_algorithmic_bytes", i64, [vp, i32])
+
+
+def check(rc):
+    if rc != OK:
+        msg = lib.schwz_last_error().decode("utf-8", "replace")
+        if rc == ERR_NOT_IMPLEMENTED:
+            raise NotImplementedSchwz(rc, msg)
+        raise SchwzError(rc, msg)
+
+
+def ptr(a):
+    """void* of a numpy array (host) or a raw integer address (device)."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return a.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(int(a))
+
+
+def device_count():
+    return int(lib.schwz_device_count())

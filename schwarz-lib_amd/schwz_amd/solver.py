@@ -1,0 +1,486 @@
+"""Host-side mirror of the reference solver API for the RAS hot path.
+
+`Settings`, `Metadata` and `SolverRAS(settings, metadata).initialize() / .run()`
+keep the names, argument meaning and error behaviour of
+include/settings.hpp:77-496, include/restricted_schwarz.hpp:61-107 and
+SchwarzBase::initialize / run (source/schwarz_base.cpp:128-271, 323-506), as
+driven by benchmarking/bench_ras.cpp:48-197.  All arithmetic runs in
+libschwz_hip.so on the GPU; this file only orders the launches and talks to
+the communication layer.
+"""
+import time
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _capi as capi
+from . import core
+from .comm import InProcessComm
+
+# Settings::partition_settings / local_solver_settings (include/settings.hpp:96-156)
+PARTITION_REGULAR = "regular"
+PARTITION_REGULAR2D = "regular2d"
+PARTITION_METIS = "metis"
+PARTITION_CUSTOM = "custom"
+SOLVER_DIRECT_CHOLMOD = "direct-cholmod"
+SOLVER_DIRECT_UMFPACK = "direct-umfpack"
+SOLVER_DIRECT_GINKGO = "direct-ginkgo"
+SOLVER_ITERATIVE_GINKGO = "iterative-ginkgo"
+
+# MEASURE_ELAPSED_FUNC_TIME ids and names (schwarz_base.cpp:393-450)
+TIMING_NAMES = ["boundary_exchange", "boundary_update", "convergence_check", "local_solve",
+                "expand_local_vec"]
+
+
+@dataclass
+class CommSettings:
+    enable_onesided: bool = False
+    enable_overlap: bool = False
+    enable_put: bool = False
+    enable_get: bool = True
+    stage_through_host: bool = False
+    enable_one_by_one: bool = False
+    enable_flush_local: bool = False
+    enable_flush_all: bool = True
+    enable_lock_local: bool = False
+    enable_lock_all: bool = True
+
+
+@dataclass
+class ConvergenceSettings:
+    put_all_local_residual_norms: bool = True
+    enable_global_simple_tree: bool = False
+    enable_decentralized_leader_election: bool = False
+    enable_global_check: bool = True
+    enable_accumulate: bool = False
+    enable_global_check_iter_offset: bool = False
+    convergence_crit: str = "solution_based"
+
+
+@dataclass
+class Settings:
+    executor_string: str = "hip"
+    matrix_filename: str = "null"
+    explicit_laplacian: bool = True
+    use_mixed_precision: bool = False
+    enable_random_rhs: bool = False
+    print_matrices: bool = False
+    debug_print: bool = False
+    partition: str = PARTITION_REGULAR
+    local_solver: str = SOLVER_ITERATIVE_GINKGO
+    non_symmetric_matrix: bool = False
+    restart_iter: int = 1
+    reset_local_crit_iter: int = -1
+    overlap: int = 2
+    naturally_ordered_factor: bool = False
+    metis_objtype: str = ""
+    write_debug_out: bool = False
+    write_iters_and_residuals: bool = False
+    enable_logging: bool = False
+    write_perm_data: bool = False
+    shifted_iter: int = 1
+    factorization: str = "cholmod"
+    reorder: str = ""
+    comm_settings: CommSettings = field(default_factory=CommSettings)
+    convergence_settings: ConvergenceSettings = field(default_factory=ConvergenceSettings)
+    # extension (the reference has a 2-D generator only): 2 or 3, and
+    # an optional (nx, ny, nz) for non-cubic 3-D grids
+    laplacian_dim: int = 2
+    laplacian_shape: tuple = None
+    # optional user partition vector for PARTITION_CUSTOM
+    partition_vector: object = None
+    spmv_variant: int = 0
+
+
+@dataclass
+class Metadata:
+    global_size: int = 0
+    oned_laplacian_size: int = 0
+    local_size: int = 0
+    local_size_x: int = 0
+    local_size_o: int = 0
+    overlap_size: int = 0
+    num_subdomains: int = 1
+    my_rank: int = 0
+    my_local_rank: int = 0
+    local_num_procs: int = 1
+    comm_size: int = 1
+    num_threads: int = 1
+    iter_count: int = 0
+    tolerance: float = 1e-6
+    local_solver_tolerance: float = 1e-12
+    max_iters: int = 100
+    local_max_iters: int = -1
+    updated_max_iters: int = -1
+    local_precond: str = "null"
+    precond_max_block_size: int = 16
+    current_residual_norm: float = -1.0
+    min_residual_norm: float = -1.0
+    time_struct: list = field(default_factory=list)
+    comm_data_struct: list = field(default_factory=list)
+    post_process_data: dict = field(default_factory=lambda: dict(
+        global_residual_vector_out=[], local_residual_vector_out=[],
+        local_converged_iter_count=[], local_converged_resnorm=[], local_timestamp=[]))
+    first_row: object = None
+    permutation: object = None
+
+
+class HipBackend:
+    """Device memory, streams and subdomain objects for `--executor=hip`."""
+
+    name = "hip"
+
+    def __init__(self, device_index=0):
+        import torch
+        if capi.device_count() < 1 or not torch.cuda.is_available():
+            raise capi.SchwzError(capi.ERR_HIP,
+                                  "executor 'hip' needs a GPU: no HIP device is visible and "
+                                  "there is no CPU fallback")
+        self._torch = torch
+        self.device = torch.device("cuda", device_index)
+        torch.cuda.set_device(self.device)
+        capi.check(capi.lib.schwz_set_device(device_index))
+
+    def stream(self):
+        return self._torch.cuda.current_stream().cuda_stream
+
+    def empty(self, n):
+        return self._torch.empty(max(int(n), 1), dtype=self._torch.float64, device=self.device)
+
+    def synchronize(self):
+        self._torch.cuda.synchronize()
+
+    # problem sources / partitions (host code of libschwz_hip.so)
+    problem_laplacian = staticmethod(core.Problem.laplacian)
+    problem_from_matrix_market = staticmethod(core.Problem.from_matrix_market)
+    problem_from_csr = staticmethod(core.Problem.from_csr)
+    partition_regular = staticmethod(core.partition_regular)
+    partition_regular2d = staticmethod(core.partition_regular2d)
+
+    def subdomain(self, problem, P, me, overlap, first_row):
+        return core.Subdomain(problem, P, me, overlap, first_row)
+
+
+def _local_solver_code(settings):
+    ls = settings.local_solver
+    if ls == SOLVER_ITERATIVE_GINKGO:
+        return capi.SOLVER_ITERATIVE
+    if ls in (SOLVER_DIRECT_GINKGO, SOLVER_DIRECT_CHOLMOD):
+        # direct-cholmod runs CHOLMOD's host solve in the reference
+        # (solve.cpp:688-694); the same P^T L^-T L^-1 P is applied on the GPU here
+        return capi.SOLVER_DIRECT
+    raise capi.NotImplementedSchwz(capi.ERR_NOT_IMPLEMENTED,
+                                   "local solver '%s' is not implemented" % ls)
+
+
+def _precond_code(metadata):
+    lp = metadata.local_precond
+    if lp in ("null", "", None):
+        return capi.PRECOND_NONE
+    if lp == "block-jacobi" and int(metadata.precond_max_block_size) == 1:
+        return capi.PRECOND_JACOBI
+    raise capi.NotImplementedSchwz(
+        capi.ERR_NOT_IMPLEMENTED,
+        "local_precond '%s' (max block size %s) is not implemented; available: null, "
+        "block-jacobi with precond_max_block_size=1" % (lp, metadata.precond_max_block_size))
+
+
+class SolverRAS:
+    """Restricted Additive Schwarz solver (include/restricted_schwarz.hpp:61-107).
+
+    One process drives the subdomains listed in `comm.local_ranks`: all of them
+    (InProcessComm, one GPU) or exactly one (TorchDistComm, one GPU per rank).
+    """
+
+    def __init__(self, settings, metadata, comm=None, backend=None, quiet=False):
+        self.settings = settings
+        self.metadata = metadata
+        self.quiet = quiet
+        if settings.executor_string not in ("hip", "cuda"):
+            # the reference's "reference"/"omp" executors are CPU paths; this
+            # build has none (the CPU restatement lives in oracle/ for tests only)
+            raise capi.NotImplementedSchwz(
+                capi.ERR_NOT_IMPLEMENTED,
+                "executor '%s' is not available: only 'hip' (MI355X) exists and there is "
+                "no CPU fallback" % settings.executor_string)
+        self.comm = comm if comm is not None else InProcessComm(max(metadata.num_subdomains, 1))
+        self.backend = backend if backend is not None else HipBackend(
+            getattr(self.comm, "device_index", 0))
+        metadata.num_subdomains = self.comm.size
+        metadata.comm_size = self.comm.size
+        metadata.my_rank = self.comm.rank
+        self.subdomains = {}
+        self.problem = None
+        self.result = None
+
+    def _print(self, *a):
+        if self.comm.is_root and not self.quiet:
+            print(*a, flush=True)
+
+    # ------------------------------------------------------------------ setup
+    def _setup_global_matrix(self):
+        """Initialize::setup_global_matrix (initialization.cpp:197-272)."""
+        s, m, be = self.settings, self.metadata, self.backend
+        if s.matrix_filename != "null":
+            prob = be.problem_from_matrix_market(s.matrix_filename)
+            self._print("Matrix from file " + s.matrix_filename)
+        elif s.explicit_laplacian:
+            n = int(m.oned_laplacian_size)
+            if s.laplacian_dim == 3:
+                nx, ny, nz = s.laplacian_shape if s.laplacian_shape else (n, n, n)
+                prob = be.problem_laplacian(3, nx, ny, nz)
+                self._print("Laplacian 3D Matrix %dx%dx%d (generated in house) " % (nx, ny, nz))
+            else:
+                prob = be.problem_laplacian(2, n)
+                self._print("Laplacian 2D Matrix (generated in house) ")
+        else:
+            raise capi.SchwzError(capi.ERR_IO, " Need to provide a matrix or enable the default "
+                                               "laplacian matrix.")
+        m.global_size = prob.N
+        return prob
+
+    def _partition(self, prob):
+        """Initialize::partition (initialization.cpp:278-329) + the first_row /
+        permutation part of setup_local_matrices (restricted_schwarz.cpp:84-152)."""
+        s, m, be = self.settings, self.metadata, self.backend
+        P = m.num_subdomains
+        first_row = be.partition_regular(prob.N, P)
+        perm = None
+        if s.partition == PARTITION_REGULAR:
+            self._print(" Regular 1D partition")
+        elif s.partition in (PARTITION_REGULAR2D, PARTITION_METIS, PARTITION_CUSTOM):
+            if s.partition == PARTITION_REGULAR2D:
+                self._print(" Regular 2D partition")
+                part = be.partition_regular2d(int(round(prob.N ** 0.5)), P) if P > 1 else None
+            elif s.partition == PARTITION_METIS:
+                self._print(" METIS partition")
+                part = prob.partition_graph(P) if P > 1 else None
+            else:
+                part = s.partition_vector
+            if P > 1:
+                prob, perm, first_row = prob.permute(part, P)
+        else:
+            raise capi.NotImplementedSchwz(capi.ERR_NOT_IMPLEMENTED,
+                                           "partition '%s' is not implemented" % s.partition)
+        m.first_row = first_row
+        m.permutation = perm
+        return prob
+
+    def _rhs(self, ids):
+        """rhs = 1.0 (schwarz_base.cpp:169).  The random rhs of
+        initialization.cpp:88-96 is not reproduced."""
+        if self.settings.enable_random_rhs:
+            raise capi.NotImplementedSchwz(capi.ERR_NOT_IMPLEMENTED,
+                                           "enable_random_rhs is not implemented")
+        return np.ones(len(ids), dtype=np.float64)
+
+    def initialize(self):
+        """SchwarzBase::initialize (schwarz_base.cpp:128-271)."""
+        s, m, be, comm = self.settings, self.metadata, self.backend, self.comm
+        solver_code = _local_solver_code(s)
+        precond_code = _precond_code(m)
+        if s.non_symmetric_matrix:
+            raise capi.NotImplementedSchwz(capi.ERR_NOT_IMPLEMENTED,
+                                           "GMRES (non_symmetric_matrix) is not implemented")
+        prob = self._setup_global_matrix()
+        prob = self._partition(prob)
+        self.problem = prob
+        P = m.num_subdomains
+        for me in comm.local_ranks:
+            self.subdomains[me] = be.subdomain(prob, P, me, s.overlap, m.first_row)
+        puts = comm.handshake({me: sd.get_lists() for me, sd in self.subdomains.items()})
+        for me, sd in self.subdomains.items():
+            for q, ids in puts[me]:
+                sd.add_put_list(q, ids)
+        self.send_buf, self.recv_buf = {}, {}
+        for me, sd in self.subdomains.items():
+            sd.to_device(sd.local_rhs(self._rhs), local_solver=solver_code, precond=precond_code,
+                         local_tol=m.local_solver_tolerance, local_max_iters=m.local_max_iters,
+                         natural_factor_ordering=s.naturally_ordered_factor,
+                         spmv_variant=s.spmv_variant)
+            self.send_buf[me] = be.empty(sd.num_send)
+            self.recv_buf[me] = be.empty(sd.num_recv)
+        first = self.subdomains[comm.local_ranks[0]]
+        m.local_size, m.local_size_x = first.local_size, first.local_size_x
+        m.overlap_size, m.local_size_o = first.overlap_size, m.global_size
+        # per-pair views into the packed buffers, neighbour order
+        self._sends, self._recvs = {}, {}
+        for me, sd in self.subdomains.items():
+            off = sd.send_offsets()
+            for k, (q, _) in enumerate(sd.put_lists()):
+                self._sends[(me, q)] = self.send_buf[me][off[k]:off[k + 1]]
+            off = sd.recv_offsets()
+            for k, (p, _) in enumerate(sd.get_lists()):
+                self._recvs[(p, me)] = self.recv_buf[me][off[k]:off[k + 1]]
+        m.comm_data_struct = [
+            (me, [(q, len(ids)) for q, ids in sd.put_lists()],
+             [(p, len(ids)) for p, ids in sd.get_lists()], sd.num_send, sd.num_recv)
+            for me, sd in self.subdomains.items()]
+        self._print(" Problem size: %d, subdomains: %d, local size (rank %d): %d (+%d overlap)" %
+                    (m.global_size, P, comm.rank, m.local_size, m.overlap_size))
+        if solver_code == capi.SOLVER_ITERATIVE:
+            lmi = m.local_size_x if m.local_max_iters == -1 else m.local_max_iters
+            self._print(" Local max iters %d with restart iter %d" % (lmi, s.restart_iter))
+        else:
+            self._print(" Local direct solve with HIP TRS")
+
+    # -------------------------------------------------------------------- run
+    def _exchange(self):
+        stream = self.backend.stream()
+        for me, sd in self.subdomains.items():
+            sd.pack(self.send_buf[me].data_ptr(), stream)
+        self.comm.exchange(self._sends, self._recvs)
+        for me, sd in self.subdomains.items():
+            sd.unpack(self.recv_buf[me].data_ptr(), stream)
+
+    def begin_run(self):
+        """State of SchwarzBase::run before its loop (schwarz_base.cpp:340-386)."""
+        m, P = self.metadata, self.metadata.num_subdomains
+        cs, cv = self.settings.comm_settings, self.settings.convergence_settings
+        if cs.enable_onesided and not (cv.enable_global_simple_tree or
+                                       cv.enable_decentralized_leader_election):
+            raise capi.SchwzError(capi.ERR_INVALID, "Global Convergence check type unspecified")
+        self._lres0 = {me: -1.0 for me in self.subdomains}
+        self._flags = {me: False for me in self.subdomains}
+        self._gres, self._gres0 = 0.0, -1.0
+        self._num_converged = 0
+        self._timings = [[] for _ in range(5)]
+        ppd = m.post_process_data
+        for k in ppd:
+            ppd[k] = []
+        ppd["global_residual_vector_out"] = [[] for _ in range(P)]
+        m.iter_count = 0
+
+    def step(self):
+        """One pass of the loop body of SchwarzBase::run (schwarz_base.cpp:387-452).
+        Returns True when the convergence test fired (no local solve is done then)."""
+        s, m, be, comm = self.settings, self.metadata, self.backend, self.comm
+        cs, cv = s.comm_settings, s.convergence_settings
+        P = m.num_subdomains
+        locals_ = list(self.subdomains.items())
+        ppd = m.post_process_data
+        tol = m.tolerance
+        it = m.iter_count
+        stream = be.stream()
+        t0 = time.perf_counter()
+        # 0 boundary exchange (one-sided mode skips iteration 0, restricted_schwarz.cpp:725)
+        if not (cs.enable_onesided and it == 0):
+            self._exchange()
+        t1 = time.perf_counter()
+        # 1 boundary update
+        for _, sd in locals_:
+            sd.update_boundary(stream)
+        t2 = time.perf_counter()
+        # 2 convergence check (solve.cpp:959-1005)
+        lres = {}
+        for me, sd in locals_:
+            lres[me] = sd.local_residual(stream) if tol >= 0.0 else -1.0
+            if self._lres0[me] < 0.0:
+                self._lres0[me] = lres[me]
+            if np.isnan(lres[me]):
+                raise capi.SchwzError(capi.ERR_DIVERGED, "local residual is NaN")
+            ppd["local_residual_vector_out"].append(lres[me])
+            ppd["local_converged_resnorm"].append(
+                lres[me] / self._lres0[me] if self._lres0[me] != 0 else float("nan"))
+            m.current_residual_norm = lres[me]
+            m.min_residual_norm = lres[me] if it == 0 else min(lres[me], m.min_residual_norm)
+        iter_cond = ((it > m.max_iters * 0.05) or m.max_iters < 1000) \
+            if cv.enable_global_check_iter_offset else True
+        if tol > 0.0 and iter_cond:
+            if cv.enable_global_check and not cs.enable_onesided:
+                allres = comm.allgather_scalars(lres)  # solve.cpp:890-891
+                gres = 0.0
+                for j in range(P):
+                    ppd["global_residual_vector_out"][j].append(allres[j])
+                    gres += allres[j]  # SUM of the norms (solve.cpp:895-905)
+                self._gres = gres
+                if self._gres0 < 0.0:
+                    self._gres0 = gres
+                self._num_converged = P if gres / self._gres0 <= tol else 0
+            elif cs.enable_onesided:
+                # local test (solve.cpp:913-915) + monotone flags (conv_tools.hpp:249-251)
+                for me, _ in locals_:
+                    if lres[me] / self._lres0[me] <= tol:
+                        self._flags[me] = True
+                allflags = comm.allgather_scalars(
+                    {me: float(self._flags[me]) for me, _ in locals_})
+                self._num_converged = int(sum(allflags))
+            else:
+                self._num_converged = 0  # never converges on this branch
+        t3 = time.perf_counter()
+        if np.isnan(self._gres) or self._gres > 1e12:
+            raise capi.SchwzError(capi.ERR_DIVERGED,
+                                  " Rank %d diverged in %d iters " % (comm.rank, it))
+        tm = self._timings
+        tm[0].append(t1 - t0)
+        tm[1].append(t2 - t1)
+        tm[2].append(t3 - t2)
+        if self._num_converged == P:
+            return True
+        # 3 local solve
+        for _, sd in locals_:
+            sd.local_solve(stream)
+        t4 = time.perf_counter()
+        # 4 restricted write-back
+        for _, sd in locals_:
+            sd.restrict(stream)
+        t5 = time.perf_counter()
+        tm[3].append(t4 - t3)
+        tm[4].append(t5 - t4)
+        m.iter_count += 1
+        return False
+
+    def finish_run(self, elapsed, gather_solution=True):
+        """The tail of SchwarzBase::run (schwarz_base.cpp:453-503)."""
+        m, comm = self.metadata, self.comm
+        P = m.num_subdomains
+        stream = self.backend.stream()
+        locals_ = list(self.subdomains.items())
+        m.time_struct = [(i, comm.rank, len(self._timings[i]), TIMING_NAMES[i], self._timings[i])
+                         for i in range(5)]
+        converged = self._num_converged == P
+        out = dict(iter_count=m.iter_count, converged=converged, elapsed=elapsed,
+                   residual_norm=None, rhs_norm=None, sol_norm=None, solution=None)
+        if not converged:
+            self._print("Rank %d did not converge in %d iterations." % (comm.rank, m.iter_count))
+        else:
+            self._print(" Rank %d converged in %d iterations " % (comm.rank, m.iter_count))
+        # Solve::compute_residual_norm (solve.cpp:1025-1085): the interiors form the
+        # solution; (A x) on the interior rows needs fresh overlap values, hence
+        # one more exchange.
+        self._exchange()
+        parts = {me: sd.true_residual_sq(stream) for me, sd in locals_}
+        res_sq = sum(comm.allgather_scalars(parts))
+        rhs_sq = sum(comm.allgather_scalars(
+            {me: float(np.sum(self._rhs(sd.local_to_global[:sd.local_size]) ** 2))
+             for me, sd in locals_}))
+        out["residual_norm"] = float(np.sqrt(res_sq))
+        out["rhs_norm"] = float(np.sqrt(rhs_sq))
+        if gather_solution:
+            pieces = {me: sd.get_interior(stream) for me, sd in locals_}
+            sol_sq = sum(comm.allgather_scalars({me: float(np.dot(pieces[me], pieces[me]))
+                                                 for me in pieces}))
+            out["sol_norm"] = float(np.sqrt(sol_sq))
+            out["solution"] = comm.gather_vectors(pieces)
+        if converged:
+            self._print(" residual norm %g\n relative residual norm of solution %g\n"
+                        " Time taken for solve %g" %
+                        (out["residual_norm"], out["residual_norm"] / out["rhs_norm"], elapsed))
+        self.result = out
+        return out
+
+    def run(self, gather_solution=True):
+        """SchwarzBase::run (schwarz_base.cpp:323-506).  Returns a dict with the
+        solution (on the root rank) and the run statistics."""
+        m, be, comm = self.metadata, self.backend, self.comm
+        self.begin_run()
+        be.synchronize()
+        comm.barrier()
+        start = time.perf_counter()
+        while m.iter_count < m.max_iters:
+            if self.step():
+                break
+        be.synchronize()
+        comm.barrier()  # schwarz_base.cpp:453
+        elapsed = time.perf_counter() - start
+        return self.finish_run(elapsed, gather_solution)

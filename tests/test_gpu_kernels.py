@@ -1,0 +1,186 @@
+"""GPU parity of the stand-alone HIP kernels against the CPU oracle.
+
+All calls go through the C ABI (include/schwz_hip.h).  Integer/index results
+are bit-exact; fp64 results are compared with the tolerances written below
+(parallel reduction order differs from the oracle's sequential sums).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL_SPMV = 1e-13   # a 7-term dot product re-associated
+RTOL_CG = 1e-9      # CG iterates after tens of iterations, fp64
+
+
+def _dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("op", [0, 1, 2, 3])
+@pytest.mark.parametrize("n", [0, 1, 63, 1000, 100003])
+def test_gather_scatter_ops(schwz, oracle, torch_cuda, op, n):
+    torch = torch_cuda
+    rng = np.random.default_rng(n + op)
+    m = max(2 * n, 8)
+    idx = rng.permutation(m)[:n].astype(np.int32)  # unique -> scatter is race free
+    src = rng.standard_normal(m)
+    into = rng.standard_normal(max(n, 1))
+    # gather
+    exp = oracle.gather(idx, src, into[:n].copy(), op)
+    d_idx, d_src, d_into = _dev(torch, idx if n else np.zeros(1, np.int32)), _dev(torch, src), _dev(torch, into)
+    schwz.gather(n, d_idx.data_ptr(), d_src.data_ptr(), d_into.data_ptr(), op)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_into.cpu().numpy()[:n], exp)
+    # scatter
+    from_ = rng.standard_normal(max(n, 1))
+    tgt = rng.standard_normal(m)
+    exp = oracle.scatter(idx, from_[:n], tgt.copy(), op)
+    d_from, d_tgt = _dev(torch, from_), _dev(torch, tgt)
+    schwz.scatter(n, d_idx.data_ptr(), d_from.data_ptr(), d_tgt.data_ptr(), op)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_tgt.cpu().numpy(), exp)
+
+
+def _ragged_matrix(rng, n, max_len, long_row=None):
+    """CSR with ragged rows, some empty, optionally one very long row."""
+    lens = rng.integers(0, max_len + 1, size=n)
+    lens[rng.integers(0, n, size=max(n // 10, 1))] = 0
+    if long_row is not None:
+        lens[n // 2] = min(long_row, n)
+    rp = np.zeros(n + 1, dtype=np.int32)
+    rp[1:] = np.cumsum(lens)
+    col = np.zeros(rp[-1], dtype=np.int32)
+    for i in range(n):
+        col[rp[i]:rp[i + 1]] = np.sort(rng.choice(n, size=lens[i], replace=False))
+    val = rng.standard_normal(rp[-1])
+    return rp, col, val
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("case", ["lap2d", "lap3d", "ragged", "longrow", "tiny"])
+def test_spmv_matches_oracle(schwz, oracle, torch_cuda, case, variant):
+    torch = torch_cuda
+    rng = np.random.default_rng(7)
+    if case == "lap2d":
+        rp, col, val = oracle.laplacian2d(97)
+    elif case == "lap3d":
+        rp, col, val = oracle.laplacian3d(23, 17, 11)
+    elif case == "ragged":
+        rp, col, val = _ragged_matrix(rng, 5000, 40)
+    elif case == "longrow":
+        rp, col, val = _ragged_matrix(rng, 6000, 12, long_row=5000)  # > one LDS tile
+    else:
+        rp, col, val = _ragged_matrix(rng, 3, 2)
+    n = len(rp) - 1
+    A = schwz.Csr(rp, col, val)
+    x = rng.standard_normal(n)
+    y0 = rng.standard_normal(n)
+    for alpha, beta in ((1.0, 0.0), (-1.0, 1.0), (0.5, -2.0)):
+        exp = oracle.spmv(rp, col, val, x, alpha, beta, y0.copy())
+        d_x, d_y = _dev(torch, x), _dev(torch, y0)
+        A.spmv(d_x.data_ptr(), d_y.data_ptr(), alpha, beta, variant=variant)
+        torch.cuda.synchronize()
+        got = d_y.cpu().numpy()
+        scale = np.abs(exp).max() + 1e-300
+        assert np.abs(got - exp).max() <= RTOL_SPMV * max(scale, 1.0) * 50
+
+
+def test_spmv_is_reproducible(schwz, oracle, torch_cuda):
+    torch = torch_cuda
+    rp, col, val = oracle.laplacian3d(40)
+    A = schwz.Csr(rp, col, val)
+    x = _dev(torch, np.random.default_rng(1).standard_normal(len(rp) - 1))
+    y1, y2 = torch.zeros_like(x), torch.zeros_like(x)
+    A.spmv(x.data_ptr(), y1.data_ptr())
+    A.spmv(x.data_ptr(), y2.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2)
+
+
+@pytest.mark.parametrize("precond", [0, 1])
+@pytest.mark.parametrize("case", ["lap2d", "lap3d", "ani3"])
+def test_pcg_fixed_iterations_match_oracle(schwz, oracle, torch_cuda, case, precond):
+    """rtol=0: exactly max_iters updates on both sides; iterates must agree."""
+    torch = torch_cuda
+    if case == "lap2d":
+        rp, col, val = oracle.laplacian2d(64)
+    elif case == "lap3d":
+        rp, col, val = oracle.laplacian3d(20, 20, 20)
+    else:
+        g = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "ani3_crop.npz"))
+        rp, col, val = g["rp"], g["col"], g["val"]
+    n = len(rp) - 1
+    rng = np.random.default_rng(3)
+    b = rng.standard_normal(n)
+    x0 = rng.standard_normal(n) * 0.1
+    A = schwz.Csr(rp, col, val)
+    cg = schwz.Pcg(A, precond)
+    for iters in (1, 7, 30):
+        exp, it_o, rn_o = oracle.pcg(rp, col, val, b, x0, precond, 0.0, iters)
+        d_b, d_x = _dev(torch, b), _dev(torch, x0)
+        it_g, rn_g = cg.solve(d_b.data_ptr(), d_x.data_ptr(), 0.0, iters)
+        got = d_x.cpu().numpy()
+        assert it_g == it_o == iters
+        assert np.abs(got - exp).max() <= RTOL_CG * np.abs(exp).max()
+        assert abs(rn_g - rn_o) <= 1e-8 * max(rn_o, 1e-300) + 1e-14
+
+
+@pytest.mark.parametrize("precond", [0, 1])
+def test_pcg_tolerance_stop_matches_oracle(schwz, oracle, torch_cuda, precond):
+    """Residual-reduction stop: same iteration count and solution."""
+    torch = torch_cuda
+    rp, col, val = oracle.laplacian2d(48)
+    n = len(rp) - 1
+    b = np.ones(n)
+    A = schwz.Csr(rp, col, val)
+    cg = schwz.Pcg(A, precond)
+    for rtol in (1e-2, 1e-6, 1e-12):
+        exp, it_o, rn_o = oracle.pcg(rp, col, val, b, None, precond, rtol, n)
+        d_b, d_x = _dev(torch, b), torch.zeros(n, dtype=torch.float64, device="cuda")
+        it_g, rn_g = cg.solve(d_b.data_ptr(), d_x.data_ptr(), rtol, n)
+        got = d_x.cpu().numpy()
+        assert abs(it_g - it_o) <= 1, (it_g, it_o)
+        assert np.abs(got - exp).max() <= 1e-7 * np.abs(exp).max()
+
+
+def test_pcg_zero_rhs_stops_immediately(schwz, oracle, torch_cuda):
+    torch = torch_cuda
+    rp, col, val = oracle.laplacian2d(8)
+    n = len(rp) - 1
+    A = schwz.Csr(rp, col, val)
+    cg = schwz.Pcg(A, 1)
+    d_b = torch.zeros(n, dtype=torch.float64, device="cuda")
+    d_x = torch.zeros(n, dtype=torch.float64, device="cuda")
+    it, rn = cg.solve(d_b.data_ptr(), d_x.data_ptr(), 0.0, 5)
+    assert it == 0 and rn == 0.0
+    assert not torch.isnan(d_x).any()
+
+
+@pytest.mark.parametrize("natural", [True, False])
+@pytest.mark.parametrize("case", ["lap2d", "ani3"])
+def test_direct_solve_matches_oracle(schwz, oracle, torch_cuda, case, natural):
+    """Own LL^T + level-scheduled HIP tri-solves vs the oracle's factor+solve."""
+    torch = torch_cuda
+    import os
+    if case == "lap2d":
+        rp, col, val = oracle.laplacian2d(24)
+    else:
+        g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ani3_crop.npz"))
+        rp, col, val = g["rp"], g["col"], g["val"]
+    n = len(rp) - 1
+    f = schwz.cholesky(rp, col, val, natural)
+    fo = oracle.cholesky(rp, col, val, natural)
+    # identical ordering rule and arithmetic order per column up to rounding
+    assert np.array_equal(f["perm"], fo["perm"])
+    assert np.array_equal(f["l_rp"], fo["l_rp"]) and np.array_equal(f["l_col"], fo["l_col"])
+    assert np.abs(f["l_val"] - fo["l_val"]).max() <= 1e-12 * np.abs(fo["l_val"]).max()
+    b = np.random.default_rng(5).standard_normal(n)
+    exp = oracle.direct_solve(fo, b)
+    trs = schwz.Trs(f["l_rp"], f["l_col"], f["l_val"], f["u_rp"], f["u_col"], f["u_val"], f["perm"])
+    d_b = _dev(torch, b)
+    d_y = torch.zeros(n, dtype=torch.float64, device="cuda")
+    trs.solve(d_b.data_ptr(), d_y.data_ptr())
+    torch.cuda.synchronize()
+    got = d_y.cpu().numpy()
+    assert np.abs(got - exp).max() <= 1e-10 * np.abs(exp).max()

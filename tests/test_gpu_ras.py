@@ -1,0 +1,286 @@
+"""GPU parity of the whole RAS iteration (through the C ABI and the host
+mirror SolverRAS) against the CPU oracle on the same inputs, plus
+size-independent properties at larger sizes."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+# fp64 tolerances: the GPU sums in a different (tree) order than the oracle
+TOL_HIST = 1e-9   # relative, per-iteration residual history
+TOL_SOL = 1e-8    # relative, converged solution
+
+
+def _run_gpu(schwz, P, settings_kw, metadata_kw):
+    s = schwz.Settings(**settings_kw)
+    m = schwz.Metadata(num_subdomains=P, **metadata_kw)
+    solver = schwz.SolverRAS(s, m, comm=schwz.InProcessComm(P), quiet=True)
+    solver.initialize()
+    out = solver.run()
+    return solver, m, out
+
+
+def _oracle_settings(oracle, m, s, **kw):
+    return oracle.make_settings(
+        max_iters=m.max_iters, tol=m.tolerance, overlap=s.overlap,
+        local_solver=oracle.SOLVER_DIRECT if s.local_solver.startswith("direct") else oracle.SOLVER_ITERATIVE,
+        precond=1 if m.local_precond == "block-jacobi" else 0,
+        local_tol=m.local_solver_tolerance, local_max_iters=m.local_max_iters,
+        enable_global_check=int(s.convergence_settings.enable_global_check),
+        enable_onesided=int(s.comm_settings.enable_onesided),
+        natural_factor_ordering=int(s.naturally_ordered_factor), **kw)
+
+
+def _check_against_oracle(oracle, csr, P, solver, m, out, x_ref=None, exact_iters=True):
+    rp, col, val = csr
+    N = len(rp) - 1
+    fr = np.asarray(m.first_row, dtype=np.int32)
+    r = oracle.ras_run(rp, col, val, np.ones(N), P, fr, _oracle_settings(oracle, m, solver.settings))
+    if exact_iters:
+        assert out["iter_count"] == r["iter_count"]
+    else:
+        assert abs(out["iter_count"] - r["iter_count"]) <= 1
+    assert out["converged"] == r["converged"]
+    hist = np.array(m.post_process_data["global_residual_vector_out"]).sum(axis=0)
+    k = min(len(hist), len(r["hist_global"]))
+    assert np.abs(hist[:k] - r["hist_global"][:k]).max() <= TOL_HIST * r["hist_global"][0]
+    scale = np.abs(r["solution"]).max()
+    assert np.abs(out["solution"] - r["solution"]).max() <= TOL_SOL * scale
+    assert abs(out["residual_norm"] - r["residual_norm"]) <= 1e-6 * r["rhs_norm"]
+    assert abs(out["rhs_norm"] - r["rhs_norm"]) <= 1e-12 * r["rhs_norm"]
+    if x_ref is not None and out["converged"]:
+        assert np.abs(out["solution"] - x_ref).max() <= 1e-5 * np.abs(x_ref).max()
+
+
+@pytest.mark.parametrize("P", [1, 2, 4])
+@pytest.mark.parametrize("precond", ["null", "block-jacobi"])
+def test_ras_2d_iterative_matches_oracle(schwz, oracle, torch_cuda, P, precond):
+    n = 32
+    solver, m, out = _run_gpu(
+        schwz, P, dict(),
+        dict(oned_laplacian_size=n, tolerance=1e-8, max_iters=300, local_precond=precond,
+             precond_max_block_size=1))
+    _check_against_oracle(oracle, oracle.laplacian2d(n), P, solver, m, out)
+
+
+@pytest.mark.parametrize("P", [2, 8])
+def test_ras_3d_fixed_inner_work_matches_oracle(schwz, oracle, torch_cuda, P):
+    """The bench operating point: CG + scalar Jacobi, K inner iterations, local_tol=0."""
+    shape = (16, 12, 24)
+    solver, m, out = _run_gpu(
+        schwz, P, dict(laplacian_dim=3, laplacian_shape=shape),
+        dict(tolerance=1e-6, max_iters=400, local_precond="block-jacobi", precond_max_block_size=1,
+             local_solver_tolerance=0.0, local_max_iters=10))
+    _check_against_oracle(oracle, oracle.laplacian3d(*shape), P, solver, m, out)
+    assert out["converged"]
+
+
+def test_ras_config1_shape_two_subdomains(schwz, oracle, torch_cuda):
+    """BASELINE config 1 geometry at reduced size: 2-D, regular-1D partition, 2 subdomains,
+    reference-default local solve (local_tol 1e-12, unlimited inner iterations)."""
+    n = 64
+    x_ref = np.load(os.path.join(G, "lap2d_64.npz"))["x_ones"]
+    solver, m, out = _run_gpu(schwz, 2, dict(), dict(oned_laplacian_size=n, tolerance=1e-6, max_iters=400))
+    _check_against_oracle(oracle, oracle.laplacian2d(n), 2, solver, m, out, x_ref=None, exact_iters=False)
+    assert out["converged"] and out["residual_norm"] / out["rhs_norm"] < 1e-4
+    assert np.abs(out["solution"] - x_ref).max() <= 2e-3 * np.abs(x_ref).max()
+
+
+@pytest.mark.parametrize("natural", [False, True])
+def test_ras_ani4_direct_eight_subdomains(schwz, oracle, torch_cuda, tmp_path, natural):
+    """BASELINE config 4: ani4_crop.mtx, 8 subdomains, direct local solve (factor once,
+    HIP tri-solves per iteration).  Partition: contiguous rows here and the graph partition
+    in the next test."""
+    g = np.load(os.path.join(G, "ani4_crop.npz"))
+    path = _write_mtx(tmp_path, g)
+    solver, m, out = _run_gpu(
+        schwz, 8, dict(matrix_filename=path, explicit_laplacian=False, local_solver="direct-ginkgo",
+                       naturally_ordered_factor=natural),
+        dict(tolerance=1e-8, max_iters=3000))
+    _check_against_oracle(oracle, (g["rp"], g["col"], g["val"]), 8, solver, m, out, x_ref=g["x_ones"])
+    assert out["converged"]
+
+
+def _write_mtx(tmp_path, g):
+    n = len(g["rp"]) - 1
+    path = str(tmp_path / "a.mtx")
+    rows = np.repeat(np.arange(n), np.diff(g["rp"]))
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n%d %d %d\n" % (n, n, g["rp"][-1]))
+        for r, c, v in zip(rows, g["col"], g["val"]):
+            f.write("%d %d %.17g\n" % (r + 1, c + 1, v))
+    return path
+
+
+def test_ras_ani4_graph_partition(schwz, oracle, torch_cuda, tmp_path):
+    """Config 4 with the METIS stand-in: parity is against the oracle run on the SAME
+    permuted matrix / partition (SURVEY section 7 'hard parts')."""
+    g = np.load(os.path.join(G, "ani4_crop.npz"))
+    path = _write_mtx(tmp_path, g)
+    P = 8
+    solver, m, out = _run_gpu(
+        schwz, P, dict(matrix_filename=path, explicit_laplacian=False, local_solver="direct-ginkgo",
+                       partition="metis"),
+        dict(tolerance=1e-8, max_iters=3000))
+    rp, col, val = solver.problem.to_csr()  # permuted matrix actually solved
+    _check_against_oracle(oracle, (rp.astype(np.int32), col, val), P, solver, m, out)
+    assert out["converged"]
+    x_nat = np.empty(len(rp) - 1)
+    x_nat[np.asarray(m.permutation)] = out["solution"]
+    assert np.abs(x_nat - g["x_ones"]).max() <= 1e-5 * np.abs(g["x_ones"]).max()
+
+
+def test_ras_regular2d_partition(schwz, oracle, torch_cuda):
+    n, P = 16, 4
+    solver, m, out = _run_gpu(schwz, P, dict(partition="regular2d"),
+                              dict(oned_laplacian_size=n, tolerance=1e-8, max_iters=300))
+    rp, col, val = solver.problem.to_csr()
+    _check_against_oracle(oracle, (rp.astype(np.int32), col, val), P, solver, m, out)
+    x_ref = np.load(os.path.join(G, "lap2d_16.npz"))["x_ones"]
+    x_nat = np.empty(n * n)
+    x_nat[np.asarray(m.permutation)] = out["solution"]
+    assert np.abs(x_nat - x_ref).max() <= 1e-5 * np.abs(x_ref).max()
+
+
+def test_ras_onesided_local_criterion(schwz, oracle, torch_cuda):
+    n, P = 24, 4
+    s_kw = dict()
+    solver_s = schwz.Settings()
+    solver_s.comm_settings.enable_onesided = True
+    solver_s.convergence_settings.enable_global_simple_tree = True
+    m = schwz.Metadata(num_subdomains=P, oned_laplacian_size=n, tolerance=1e-6, max_iters=400)
+    solver = schwz.SolverRAS(solver_s, m, comm=schwz.InProcessComm(P), quiet=True)
+    solver.initialize()
+    out = solver.run()
+    rp, col, val = oracle.laplacian2d(n)
+    r = oracle.ras_run(rp, col, val, np.ones(n * n), P, np.asarray(m.first_row, dtype=np.int32),
+                       _oracle_settings(oracle, m, solver_s))
+    assert out["converged"] and r["converged"]
+    assert abs(out["iter_count"] - r["iter_count"]) <= 1
+    assert np.abs(out["solution"] - r["solution"]).max() <= 1e-6 * np.abs(r["solution"]).max()
+
+
+def test_overlap_three_layers(schwz, oracle, torch_cuda):
+    n, P = 24, 3
+    solver, m, out = _run_gpu(schwz, P, dict(overlap=4),
+                              dict(oned_laplacian_size=n, tolerance=1e-8, max_iters=300))
+    _check_against_oracle(oracle, oracle.laplacian2d(n), P, solver, m, out)
+
+
+def test_step_by_step_state_matches_oracle(schwz, oracle, torch_cuda):
+    """Drives the five C-ABI steps by hand for 3 outer iterations and compares every
+    intermediate vector with the oracle's (x~, b~, y, local residual)."""
+    torch = torch_cuda
+    shape, P = (8, 6, 12), 3
+    N = shape[0] * shape[1] * shape[2]
+    prob = schwz.Problem.laplacian(3, *shape)
+    fr = schwz.partition_regular(N, P)
+    rp, col, val = oracle.laplacian3d(*shape)
+    sds = [schwz.Subdomain(prob, P, me, 2, fr) for me in range(P)]
+    osds = [oracle.Subdomain(rp, col, val, P, me, 2, fr.astype(np.int32)) for me in range(P)]
+    oracle.connect(osds)
+    for me, lst in schwz.InProcessComm(P).handshake({me: sd.get_lists() for me, sd in enumerate(sds)}).items():
+        for q, ids in lst:
+            sds[me].add_put_list(q, ids)
+    os_ = oracle.make_settings(precond=1, local_tol=0.0, local_max_iters=6)
+    sts = [oracle.State(osd, np.ones(N), os_) for osd in osds]
+    send, recv = [], []
+    for sd in sds:
+        sd.to_device(np.ones(sd.local_size_x), precond=1, local_tol=0.0, local_max_iters=6)
+        send.append(torch.zeros(max(sd.num_send, 1), dtype=torch.float64, device="cuda"))
+        recv.append(torch.zeros(max(sd.num_recv, 1), dtype=torch.float64, device="cuda"))
+
+    def dev_vec(sd, which):
+        p, n = sd.vector(which)
+        out = torch.empty(n, dtype=torch.float64, device="cuda")
+        schwz.capi.check(0)
+        import ctypes
+        torch.cuda.synchronize()
+        # raw device->device copy through torch's from-blob is not available; use hip memcpy
+        # via a gather with identity indices
+        idx = torch.arange(n, dtype=torch.int32, device="cuda")
+        schwz.gather(n, idx.data_ptr(), p, out.data_ptr())
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+
+    for it in range(3):
+        # exchange
+        bufs = {}
+        for me, sd in enumerate(sds):
+            sd.pack(send[me].data_ptr())
+            off = sd.send_offsets()
+            for k, (q, _) in enumerate(sd.put_lists()):
+                bufs[(me, q)] = send[me][off[k]:off[k + 1]]
+                exp = sts[me].pack(k)
+                torch.cuda.synchronize()
+                assert np.array_equal(bufs[(me, q)].cpu().numpy(), exp) or \
+                    np.abs(bufs[(me, q)].cpu().numpy() - exp).max() <= 1e-10 * (np.abs(exp).max() + 1e-300)
+        omsgs = {(me, q): sts[me].pack(k) for me in range(P) for k, (q, _) in enumerate(osds[me].put_lists())}
+        for me, sd in enumerate(sds):
+            off = sd.recv_offsets()
+            for k, (p, _) in enumerate(sd.get_lists()):
+                recv[me][off[k]:off[k + 1]].copy_(bufs[(p, me)])
+                sts[me].unpack(k, omsgs[(p, me)])
+            sd.unpack(recv[me].data_ptr())
+        for me, sd in enumerate(sds):
+            sd.update_boundary()
+            sts[me].update_boundary()
+            bt = dev_vec(sd, 1)
+            assert np.abs(bt - sts[me].local_solution()).max() <= 1e-10 * (np.abs(bt).max() + 1e-300)
+            rho = sd.local_residual()
+            rho_o = sts[me].local_residual()
+            assert abs(rho - rho_o) <= 1e-10 * max(rho_o, 1e-300)
+            it_g = sd.local_solve(want_iters=True)
+            it_o = sts[me].local_solve()
+            assert it_g == it_o == 6
+            y = dev_vec(sd, 2)
+            assert np.abs(y - sts[me].local_solution()).max() <= 1e-9 * np.abs(y).max()
+            sd.restrict()
+            sts[me].restrict()
+            x = dev_vec(sd, 0)
+            xo = sts[me].global_solution()[osds[me].local_to_global]
+            assert np.abs(x - xo).max() <= 1e-9 * (np.abs(xo).max() + 1e-300)
+
+
+@pytest.mark.parametrize("P", [1, 4])
+def test_large_problem_properties(schwz, torch_cuda, P):
+    """Size-independent properties at a size the oracle is not run at (3-D 96^3 = 885k rows):
+    the residual history is monotone for this SPD problem, the reported true residual agrees with
+    an independent recomputation through plain SpMV launches, and P=1 with an exact local solve
+    converges in one outer iteration."""
+    torch = torch_cuda
+    n = 96
+    solver, m, out = _run_gpu(
+        schwz, P, dict(laplacian_dim=3),
+        dict(oned_laplacian_size=n, tolerance=1e-6, max_iters=200, local_precond="block-jacobi",
+             precond_max_block_size=1, local_solver_tolerance=1e-10 if P == 1 else 0.1,
+             local_max_iters=-1 if P == 1 else 70))
+    assert out["converged"]
+    if P == 1:
+        assert out["iter_count"] == 1
+    hist = np.array(m.post_process_data["global_residual_vector_out"]).sum(axis=0)
+    assert np.all(np.diff(hist) < 0)
+    # independent true residual: assemble x and apply the global operator with the plain SpMV
+    prob = schwz.Problem.laplacian(3, n, n, n)
+    N = prob.N
+    whole = schwz.Subdomain(prob, 1, 0, 2, schwz.partition_regular(N, 1))
+    rp, col, val = whole.local_matrix()
+    A = schwz.Csr(rp, col, val)
+    x = torch.from_numpy(out["solution"]).cuda()
+    r = torch.ones(N, dtype=torch.float64, device="cuda")
+    A.spmv(x.data_ptr(), r.data_ptr(), -1.0, 1.0)
+    torch.cuda.synchronize()
+    res = float(torch.linalg.norm(r))
+    assert abs(res - out["residual_norm"]) <= 1e-8 * out["rhs_norm"]
+    assert res / out["rhs_norm"] < 1e-4
+    # linearity of the operator path: A(2x) = 2 A x bit for bit (power-of-two scaling)
+    y1 = torch.zeros_like(x)
+    y2 = torch.zeros_like(x)
+    A.spmv(x.data_ptr(), y1.data_ptr())
+    x2 = 2.0 * x
+    A.spmv(x2.data_ptr(), y2.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(2.0 * y1, y2)

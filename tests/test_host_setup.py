@@ -1,0 +1,197 @@
+"""CPU tests of the product's host code (libschwz_hip.so, no GPU calls):
+the ABI surface, and bit-exact parity of problem generation / partitioning /
+subdomain index sets / comm lists / LL^T structure with the oracle."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_abi_exports_every_declared_symbol(schwz):
+    header = open(os.path.join(ROOT, "include", "schwz_hip.h")).read()
+    declared = set(re.findall(r"\b(schwz_[a-z0-9_]+)\s*\(", header))
+    lib = ctypes.CDLL(schwz.capi.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert declared == set(schwz.capi.SYMBOLS)
+
+
+def test_version_and_device_count(schwz):
+    assert b"gfx950" in schwz.capi.lib.schwz_version()
+    assert schwz.capi.device_count() >= 0
+
+
+def test_product_fails_loudly_without_gpu(schwz):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    s = schwz.Settings()
+    m = schwz.Metadata(oned_laplacian_size=8, num_subdomains=2)
+    with pytest.raises(schwz.SchwzError):
+        schwz.SolverRAS(s, m).initialize()
+    p = schwz.Problem.laplacian(2, 8)
+    sd = schwz.Subdomain(p, 1, 0, 2, schwz.partition_regular(64, 1))
+    with pytest.raises(schwz.SchwzError):
+        sd.to_device(np.ones(sd.local_size_x))
+
+
+def test_cpu_executors_are_refused(schwz):
+    for ex in ("reference", "omp"):
+        with pytest.raises(schwz.NotImplementedSchwz):
+            schwz.SolverRAS(schwz.Settings(executor_string=ex), schwz.Metadata())
+
+
+@pytest.mark.parametrize("dim,shape", [(2, (13,)), (3, (5, 4, 3)), (3, (7, 7, 7))])
+def test_problem_rows_match_oracle(schwz, oracle, dim, shape):
+    if dim == 2:
+        p = schwz.Problem.laplacian(2, shape[0])
+        o = oracle.laplacian2d(shape[0])
+    else:
+        p = schwz.Problem.laplacian(3, *shape)
+        o = oracle.laplacian3d(*shape)
+    rp, col, val = p.to_csr()
+    assert np.array_equal(rp, o[0]) and np.array_equal(col, o[1]) and np.array_equal(val, o[2])
+    assert p.nnz == o[0][-1]
+
+
+def test_matrix_market_reader(schwz, tmp_path):
+    g = np.load(os.path.join(G, "ani3_crop.npz"))
+    n = len(g["rp"]) - 1
+    path = tmp_path / "m.mtx"
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n% comment\n")
+        f.write("%d %d %d\n" % (n, n, g["rp"][-1]))
+        rows = np.repeat(np.arange(n), np.diff(g["rp"]))
+        # shuffled order: the reader must sort by column (initialization.cpp:212)
+        order = np.random.default_rng(0).permutation(len(rows))
+        for k in order:
+            f.write("%d %d %.17g\n" % (rows[k] + 1, g["col"][k] + 1, g["val"][k]))
+    p = schwz.Problem.from_matrix_market(str(path))
+    rp, col, val = p.to_csr()
+    assert np.array_equal(rp, g["rp"]) and np.array_equal(col, g["col"]) and np.array_equal(val, g["val"])
+    with pytest.raises(schwz.SchwzError):
+        schwz.Problem.from_matrix_market(str(tmp_path / "missing.mtx"))
+
+
+def _compare_subdomains(schwz, oracle, prob, csr, P, overlap, fr):
+    orp, ocol, oval = csr
+    sds, osds = [], []
+    for me in range(P):
+        sd = schwz.Subdomain(prob, P, me, overlap, fr)
+        osd = oracle.Subdomain(orp, ocol, oval, P, me, overlap, fr.astype(np.int32))
+        for a, b in zip(sd.local_matrix(), osd.local_matrix()):
+            assert np.array_equal(a, b)
+        for a, b in zip(sd.interface_matrix(), osd.interface_matrix()):
+            assert np.array_equal(a, b)
+        assert np.array_equal(sd.local_to_global, osd.local_to_global)
+        g1, g2 = sd.get_lists(), osd.get_lists()
+        assert [r for r, _ in g1] == [r for r, _ in g2]
+        for (_, a), (_, b) in zip(g1, g2):
+            assert np.array_equal(a, b)
+        assert (sd.local_size, sd.local_size_x, sd.overlap_size, sd.halo_size, sd.nnz_local,
+                sd.nnz_interface, sd.num_recv) == \
+               (osd.local_size, osd.local_size_x, osd.overlap_size, osd.halo_size, osd.nnz_local,
+                osd.nnz_interface, osd.num_recv)
+        sds.append(sd)
+        osds.append(osd)
+    oracle.connect(osds)
+    puts = schwz.InProcessComm(P).handshake({me: sd.get_lists() for me, sd in enumerate(sds)})
+    for me, sd in enumerate(sds):
+        for q, ids in puts[me]:
+            sd.add_put_list(q, ids)
+        p1, p2 = sd.put_lists(), osds[me].put_lists()
+        assert [r for r, _ in p1] == [r for r, _ in p2]
+        for (_, a), (_, b) in zip(p1, p2):
+            assert np.array_equal(a, b)
+        assert sd.num_send == osds[me].num_send
+        assert sd.send_offsets()[-1] == sd.num_send and sd.recv_offsets()[-1] == sd.num_recv
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 8])
+@pytest.mark.parametrize("overlap", [1, 2, 3, 5])
+def test_subdomain_index_sets_2d(schwz, oracle, P, overlap):
+    n = 12
+    prob = schwz.Problem.laplacian(2, n)
+    _compare_subdomains(schwz, oracle, prob, oracle.laplacian2d(n), P, overlap,
+                        schwz.partition_regular(n * n, P))
+
+
+@pytest.mark.parametrize("P", [2, 4, 7])
+def test_subdomain_index_sets_3d_ragged_slabs(schwz, oracle, P):
+    shape = (5, 4, 9)  # N=180: slabs cut through planes for P=7
+    prob = schwz.Problem.laplacian(3, *shape)
+    _compare_subdomains(schwz, oracle, prob, oracle.laplacian3d(*shape), P, 2,
+                        schwz.partition_regular(180, P))
+
+
+def test_subdomain_index_sets_general_matrix(schwz, oracle):
+    g = np.load(os.path.join(G, "ani3_crop.npz"))
+    prob = schwz.Problem.from_csr(g["rp"], g["col"], g["val"])
+    N = prob.N
+    _compare_subdomains(schwz, oracle, prob, (g["rp"], g["col"], g["val"]), 8, 2,
+                        schwz.partition_regular(N, 8))
+    _compare_subdomains(schwz, oracle, prob, (g["rp"], g["col"], g["val"]), 4, 4,
+                        schwz.partition_regular(N, 4))
+
+
+def test_partition_vector_permutation_matches_oracle(schwz, oracle):
+    n, P = 8, 4
+    part = schwz.partition_regular2d(n, P)
+    assert np.array_equal(part, oracle.partition_regular2d(n, P))
+    prob = schwz.Problem.laplacian(2, n)
+    pprob, perm, fr = prob.permute(part, P)
+    operm, oiperm, ofr, orp, ocol, oval = oracle.apply_partition(*oracle.laplacian2d(n), part, P)
+    assert np.array_equal(perm, operm) and np.array_equal(fr, ofr)
+    rp, col, val = pprob.to_csr()
+    # the product keeps permuted rows column-sorted; same entries per row
+    for i in range(n * n):
+        a = sorted(zip(col[rp[i]:rp[i + 1]], val[rp[i]:rp[i + 1]]))
+        b = sorted(zip(ocol[orp[i]:orp[i + 1]], oval[orp[i]:orp[i + 1]]))
+        assert a == b
+    with pytest.raises(schwz.SchwzError):
+        schwz.partition_regular2d(8, 3)
+
+
+def test_graph_partition_is_balanced_and_connected_enough(schwz):
+    g = np.load(os.path.join(G, "ani4_crop.npz"))
+    prob = schwz.Problem.from_csr(g["rp"], g["col"], g["val"])
+    part = prob.partition_graph(8)
+    counts = np.bincount(part, minlength=8)
+    assert counts.sum() == prob.N and counts.min() >= prob.N // 8 - 2 and counts.max() <= prob.N // 8 + 2
+    # edge cut far below a random assignment
+    rows = np.repeat(np.arange(prob.N), np.diff(g["rp"]))
+    cut = np.count_nonzero(part[rows] != part[g["col"]])
+    assert cut < 0.15 * len(rows)
+
+
+@pytest.mark.parametrize("natural", [True, False])
+def test_cholesky_matches_oracle_structure_and_values(schwz, oracle, natural):
+    g = np.load(os.path.join(G, "ani3_crop.npz"))
+    f = schwz.cholesky(g["rp"], g["col"], g["val"], natural)
+    fo = oracle.cholesky(g["rp"], g["col"], g["val"], natural)
+    for k in ("perm", "l_rp", "l_col", "u_rp", "u_col"):
+        assert np.array_equal(f[k], fo[k]), k
+    assert np.abs(f["l_val"] - fo["l_val"]).max() <= 1e-12 * np.abs(fo["l_val"]).max()
+    # identity A(perm,perm) = L L^T
+    import scipy.sparse as sp
+    n = len(g["rp"]) - 1
+    A = sp.csr_matrix((g["val"], g["col"], g["rp"]), shape=(n, n))
+    L = sp.csr_matrix((f["l_val"], f["l_col"], f["l_rp"]), shape=(n, n))
+    pm = f["perm"]
+    assert abs(L @ L.T - A[pm][:, pm]).max() < 1e-12
+    U = sp.csr_matrix((f["u_val"], f["u_col"], f["u_rp"]), shape=(n, n))
+    assert abs(U - L.T).max() == 0.0
+
+
+def test_cholesky_rejects_indefinite(schwz):
+    rp = np.array([0, 2, 4], dtype=np.int32)
+    col = np.array([0, 1, 0, 1], dtype=np.int32)
+    val = np.array([1.0, 2.0, 2.0, 1.0])
+    with pytest.raises(schwz.SchwzError) as e:
+        schwz.cholesky(rp, col, val, True)
+    assert e.value.code == schwz.capi.ERR_NOT_SPD
