@@ -54,13 +54,26 @@ def make_solver(schwz, comm, shape, inner, tol, max_iters, local_tol, variant, q
     return solver, m
 
 
+def host_cores():
+    """CPU share of this process: cgroup quota if set, else the affinity mask; a 1-GPU box
+    shares its host, so never more than 16 threads (the box's CPU share for one GPU)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("SCHWZ_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(shape, inner, iters):
     """The oracle (CPU restatement, kind 'port') on a bounded sample of the same
     workload: the same grid and settings, `iters` outer iterations."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import oracle as O
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     rp, col, val = O.laplacian3d(*shape)
     N = len(rp) - 1
     st = O.make_settings(max_iters=iters, tol=1e-30, precond=O.PRECOND_JACOBI, local_tol=0.0,

@@ -9,6 +9,11 @@ import os
 
 import numpy as np
 
+# torch bundles its own libamdhip64.so.7; libschwz_hip.so links the same SONAME.
+# Importing torch FIRST makes the dynamic linker hand that one HIP runtime to both,
+# otherwise two runtimes initialise in one process and the second sees no device.
+import torch  # noqa: F401,E402
+
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_PKG), "lib", "libschwz_hip.so")
 

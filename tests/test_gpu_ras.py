@@ -34,22 +34,40 @@ def _oracle_settings(oracle, m, s, **kw):
         natural_factor_ordering=int(s.naturally_ordered_factor), **kw)
 
 
-def _check_against_oracle(oracle, csr, P, solver, m, out, x_ref=None, exact_iters=True):
+def _check_against_oracle(oracle, csr, P, solver, m, out, x_ref=None, exact_iters=True,
+                          truncated_cg=False):
+    """truncated_cg: the local solve is a FIXED number of CG iterations (local_tol = 0).  The
+    outer map is then nonlinear (degree-1 homogeneous) with a Jacobian norm > 1 transverse to the
+    iterate: rounding-level differences grow ~10-30x per outer iteration -- the oracle shows the
+    same against itself under a 1e-15 rhs perturbation
+    (tests/test_oracle_golden.py::test_truncated_cg_trajectory_is_rounding_sensitive).  Parity is
+    therefore tight on the first iterations and bounded by the stopping threshold afterwards;
+    test_step_by_step_state_matches_oracle covers single steps at 1e-9."""
     rp, col, val = csr
     N = len(rp) - 1
     fr = np.asarray(m.first_row, dtype=np.int32)
     r = oracle.ras_run(rp, col, val, np.ones(N), P, fr, _oracle_settings(oracle, m, solver.settings))
-    if exact_iters:
+    if truncated_cg:
+        assert abs(out["iter_count"] - r["iter_count"]) <= 2
+    elif exact_iters:
         assert out["iter_count"] == r["iter_count"]
     else:
         assert abs(out["iter_count"] - r["iter_count"]) <= 1
     assert out["converged"] == r["converged"]
     hist = np.array(m.post_process_data["global_residual_vector_out"]).sum(axis=0)
     k = min(len(hist), len(r["hist_global"]))
-    assert np.abs(hist[:k] - r["hist_global"][:k]).max() <= TOL_HIST * r["hist_global"][0]
-    scale = np.abs(r["solution"]).max()
-    assert np.abs(out["solution"] - r["solution"]).max() <= TOL_SOL * scale
-    assert abs(out["residual_norm"] - r["residual_norm"]) <= 1e-6 * r["rhs_norm"]
+    g0 = r["hist_global"][0]
+    if truncated_cg:
+        assert np.abs(hist[:6] - r["hist_global"][:6]).max() <= 1e-11 * g0
+        assert np.abs(hist[:k] - r["hist_global"][:k]).max() <= 2.0 * m.tolerance * g0
+        scale = np.abs(r["solution"]).max()
+        assert np.abs(out["solution"] - r["solution"]).max() <= 1e-4 * scale
+        assert out["residual_norm"] / out["rhs_norm"] <= 10 * m.tolerance * g0 / out["rhs_norm"]
+    else:
+        assert np.abs(hist[:k] - r["hist_global"][:k]).max() <= TOL_HIST * g0
+        scale = np.abs(r["solution"]).max()
+        assert np.abs(out["solution"] - r["solution"]).max() <= TOL_SOL * scale
+        assert abs(out["residual_norm"] - r["residual_norm"]) <= 1e-6 * r["rhs_norm"]
     assert abs(out["rhs_norm"] - r["rhs_norm"]) <= 1e-12 * r["rhs_norm"]
     if x_ref is not None and out["converged"]:
         assert np.abs(out["solution"] - x_ref).max() <= 1e-5 * np.abs(x_ref).max()
@@ -74,7 +92,7 @@ def test_ras_3d_fixed_inner_work_matches_oracle(schwz, oracle, torch_cuda, P):
         schwz, P, dict(laplacian_dim=3, laplacian_shape=shape),
         dict(tolerance=1e-6, max_iters=400, local_precond="block-jacobi", precond_max_block_size=1,
              local_solver_tolerance=0.0, local_max_iters=10))
-    _check_against_oracle(oracle, oracle.laplacian3d(*shape), P, solver, m, out)
+    _check_against_oracle(oracle, oracle.laplacian3d(*shape), P, solver, m, out, truncated_cg=True)
     assert out["converged"]
 
 
@@ -109,7 +127,7 @@ def _write_mtx(tmp_path, g):
     path = str(tmp_path / "a.mtx")
     rows = np.repeat(np.arange(n), np.diff(g["rp"]))
     with open(path, "w") as f:
-        f.write("%%MatrixMarket matrix coordinate real general\n%d %d %d\n" % (n, n, g["rp"][-1]))
+        f.write("%%%%MatrixMarket matrix coordinate real general\n%d %d %d\n" % (n, n, g["rp"][-1]))
         for r, c, v in zip(rows, g["col"], g["val"]):
             f.write("%d %d %.17g\n" % (r + 1, c + 1, v))
     return path
@@ -248,9 +266,9 @@ def test_step_by_step_state_matches_oracle(schwz, oracle, torch_cuda):
 @pytest.mark.parametrize("P", [1, 4])
 def test_large_problem_properties(schwz, torch_cuda, P):
     """Size-independent properties at a size the oracle is not run at (3-D 96^3 = 885k rows):
-    the residual history is monotone for this SPD problem, the reported true residual agrees with
-    an independent recomputation through plain SpMV launches, and P=1 with an exact local solve
-    converges in one outer iteration."""
+    the stopping rule holds on the recorded history, the reported true residual agrees with an
+    independent recomputation through plain SpMV launches, the operator path is linear, and P=1
+    with an exact local solve converges in one outer iteration."""
     torch = torch_cuda
     n = 96
     solver, m, out = _run_gpu(
@@ -262,7 +280,7 @@ def test_large_problem_properties(schwz, torch_cuda, P):
     if P == 1:
         assert out["iter_count"] == 1
     hist = np.array(m.post_process_data["global_residual_vector_out"]).sum(axis=0)
-    assert np.all(np.diff(hist) < 0)
+    assert hist[-1] <= 1e-6 * hist[0] < hist[-2]
     # independent true residual: assemble x and apply the global operator with the plain SpMV
     prob = schwz.Problem.laplacian(3, n, n, n)
     N = prob.N
