@@ -88,7 +88,8 @@ int64_t schwz_csr_nnz(const schwz_csr *A);
 
 /* y = alpha*A*x + beta*y : gko Csr::apply(alpha,x,beta,y), call sites
  * source/restricted_schwarz.cpp:1014-1015, source/solve.cpp:834-835,1079-1080.
- * variant: 0 = default (LDS-staged row tiles), 1 = one-row-per-lane baseline. */
+ * variant: 0 = default (LDS-staged row tiles, 16-byte batched loads),
+ * 1 = one-row-per-lane baseline, 2 = first tiled version (scalar loads). */
 int schwz_csr_spmv(const schwz_csr *A, double alpha, const double *d_x,
                    double beta, double *d_y, int variant, schwz_stream stream);
 
@@ -113,6 +114,11 @@ int schwz_pcg_solve(schwz_pcg *s, const double *d_b, double *d_x, double rtol,
  * the reference (its MEASURE_ELAPSED_FUNC_TIME, include/settings.hpp:508-523,
  * times host calls without a device sync). */
 int schwz_profile_begin(int capacity);
+/* STREAM-style probe for the measured HBM ceiling quoted beside the 8 TB/s spec
+ * (SURVEY 8d): mode 0 copies n doubles src->dst, mode 1 reads n doubles and
+ * writes one partial sum per workgroup (dst needs 2048 doubles). */
+int schwz_stream_probe(int64_t n, int mode, const double *d_src, double *d_dst,
+                       schwz_stream stream);
 int schwz_profile_end(double *h_total_ms, int64_t *h_launches);
 
 /* Sparse triangular solves y = P^T L^-T L^-1 P b.

@@ -129,6 +129,132 @@ __global__ __launch_bounds__(kBlock) void spmv_tiled_kernel(CsrView A, SpmvArgs 
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Default (variant 0) tiled SpMV: the same tile table as the first version
+// (spmv_tiled_kernel, kept as variant 2 for A/B runs), but the streaming phase is
+// issued as 16-byte loads (double2 values, int2 columns) and all of a lane's
+// loads are in flight before the first use (8 nonzeros per lane per tile), so a
+// wave keeps ~1.5 KiB outstanding instead of one 12-byte pair.  The tile window
+// starts at the even index below rp[r0]; the at most two foreign entries at the
+// window's ends are multiplied like the others and simply never summed (the
+// arrays carry two padding entries, see schwz_csr_create).
+// ---------------------------------------------------------------------------
+
+constexpr int kPairsPerLane = kTileNnz / (2 * kBlock);  // 4
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void spmv_tiled2_kernel(CsrView A, SpmvArgs a)
+{
+    __shared__ double prod[kTileNnz + 2];
+    __shared__ double red[4];
+    if (MODE == kSpmvDot || MODE == kSpmvResidInit) {
+        if (a.stop_iter && a.it >= *a.stop_iter) return;
+    }
+    const int tid = threadIdx.x;
+    const int xcd = blockIdx.x % kXcds;
+    const int slot = blockIdx.x / kXcds;
+    const int per_xcd = gridDim.x / kXcds;
+    const int chunk = (A.ntiles + kXcds - 1) / kXcds;
+    double acc0 = 0.0, acc1 = 0.0;
+
+    for (int t = slot; t < chunk; t += per_xcd) {
+        const int tile = xcd * chunk + t;
+        if (tile >= A.ntiles) break;
+        const int r0 = A.tile_row[tile], r1 = A.tile_row[tile + 1];
+        const int s = A.rp[r0], e = A.rp[r1];
+        const int cnt = e - s;
+        double sum = 0.0;
+        int row = r0 + tid;
+        bool have_row = false;
+        if (cnt <= kTileNnz - 2) {
+            const int s2 = s & ~1;
+            // own row bounds first: independent of the streaming loads
+            int b0 = 0, b1 = 0;
+            if (row < r1) {
+                b0 = A.rp[row] - s2;
+                b1 = A.rp[row + 1] - s2;
+            }
+            double2 v[kPairsPerLane];
+            int2 c[kPairsPerLane];
+#pragma unroll
+            for (int k = 0; k < kPairsPerLane; ++k) {
+                const int idx = s2 + 2 * (tid + kBlock * k);
+                if (idx < e) {
+                    v[k] = *reinterpret_cast<const double2 *>(A.val + idx);
+                    c[k] = *reinterpret_cast<const int2 *>(A.col + idx);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kPairsPerLane; ++k) {
+                const int idx = s2 + 2 * (tid + kBlock * k);
+                if (idx < e) {
+                    const double x0 = a.x[c[k].x];
+                    const double x1 = a.x[c[k].y];
+                    double2 pr;
+                    pr.x = v[k].x * x0;
+                    pr.y = v[k].y * x1;
+                    *reinterpret_cast<double2 *>(&prod[2 * (tid + kBlock * k)]) = pr;
+                }
+            }
+            __syncthreads();
+            if (row < r1) {
+                have_row = true;
+                for (int j = b0; j < b1; ++j) sum += prod[j];
+            }
+            __syncthreads();
+        } else if (r1 - r0 > 1) {
+            // tile that fits kTileNnz but not the aligned window: plain staging
+            for (int i = tid; i < cnt; i += kBlock) prod[i] = A.val[s + i] * a.x[A.col[s + i]];
+            __syncthreads();
+            if (row < r1) {
+                have_row = true;
+                const int b0 = A.rp[row] - s, b1 = A.rp[row + 1] - s;
+                for (int j = b0; j < b1; ++j) sum += prod[j];
+            }
+            __syncthreads();
+        } else {
+            // a single long row: the whole workgroup reduces it
+            double part = 0.0;
+            for (int i = tid; i < cnt; i += kBlock) part += A.val[s + i] * a.x[A.col[s + i]];
+            part = block_sum(part, red);
+            row = r0;
+            if (tid == 0) {
+                have_row = true;
+                sum = part;
+            }
+        }
+        if (have_row) {
+            if (MODE == kSpmvPlain) {
+                a.y[row] = (a.beta == 0.0) ? a.alpha * sum : a.alpha * sum + a.beta * a.y[row];
+            } else if (MODE == kSpmvDot) {
+                a.y[row] = sum;
+                acc0 += a.x[row] * sum;
+            } else if (MODE == kSpmvResidInit) {
+                const double r = a.b[row] - sum;
+                const double z = a.dinv ? a.dinv[row] * r : r;
+                a.y[row] = r;
+                a.p[row] = z;
+                acc0 += r * z;
+                acc1 += r * r;
+            } else {  // kSpmvResidNorm
+                if (row < a.row_limit) {
+                    const double r = a.b[row] - sum;
+                    acc1 += r * r;
+                }
+            }
+        }
+    }
+    if (MODE != kSpmvPlain) {
+        const double s0 = block_sum(acc0, red);
+        const double s1 = block_sum(acc1, red);
+        if (tid == 0) {
+            a.partials[blockIdx.x] = s0;
+            a.partials[gridDim.x + blockIdx.x] = s1;
+        }
+    }
+}
+
 // Baseline for A/B runs: one row per lane, no staging (what a direct port of a
 // row-parallel CPU loop would do).  Only the plain mode.
 __global__ __launch_bounds__(kBlock) void spmv_rowlane_kernel(CsrView A, SpmvArgs a)
@@ -154,6 +280,21 @@ int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipS
     const int grid = spmv_grid(A);
     if (variant == 1 && mode == kSpmvPlain) {
         hipLaunchKernelGGL(spmv_rowlane_kernel, dim3(kMaxGrid), dim3(kBlock), 0, s, A, a);
+    } else if (variant != 2) {
+        switch (mode) {
+        case kSpmvPlain:
+            hipLaunchKernelGGL(spmv_tiled2_kernel<kSpmvPlain>, dim3(grid), dim3(kBlock), 0, s, A, a);
+            break;
+        case kSpmvDot:
+            hipLaunchKernelGGL(spmv_tiled2_kernel<kSpmvDot>, dim3(grid), dim3(kBlock), 0, s, A, a);
+            break;
+        case kSpmvResidInit:
+            hipLaunchKernelGGL(spmv_tiled2_kernel<kSpmvResidInit>, dim3(grid), dim3(kBlock), 0, s, A, a);
+            break;
+        default:
+            hipLaunchKernelGGL(spmv_tiled2_kernel<kSpmvResidNorm>, dim3(grid), dim3(kBlock), 0, s, A, a);
+            break;
+        }
     } else {
         switch (mode) {
         case kSpmvPlain:
@@ -368,6 +509,29 @@ __global__ void extract_dinv_kernel(CsrView A, double *__restrict__ dinv)
     }
 }
 
+// STREAM-style probes: the measured copy / read ceiling quoted next to the 8 TB/s
+// spec figure in DESIGN.md.
+__global__ __launch_bounds__(kBlock) void stream_copy_kernel(int64_t n2, const double2 *__restrict__ src,
+                                                             double2 *__restrict__ dst)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(kBlock) void stream_read_kernel(int64_t n2, const double2 *__restrict__ src,
+                                                             double *__restrict__ out)
+{
+    __shared__ double red[4];
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    double a = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
+        const double2 v = src[i];
+        a += v.x + v.y;
+    }
+    a = block_sum(a, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = a;
+}
+
 __global__ void final_norm_kernel(const double *partials, int nparts, double *out)
 {
     __shared__ double red[4];
@@ -487,12 +651,14 @@ int schwz_scatter(int64_t n, const schwz_idx *d_idx, const double *d_from, doubl
 
 }  // extern "C"
 
+// `pad` extra zeroed elements follow the data (the 16-byte SpMV loads may touch them)
 template <typename T>
-static int upload(const T *h, size_t count, void **d)
+static int upload(const T *h, size_t count, void **d, size_t pad = 0)
 {
     *d = nullptr;
-    SCHWZ_HIP_TRY(hipMalloc(d, (count ? count : 1) * sizeof(T)));
+    SCHWZ_HIP_TRY(hipMalloc(d, (count + pad ? count + pad : 1) * sizeof(T)));
     if (count) SCHWZ_HIP_TRY(hipMemcpy(*d, h, count * sizeof(T), hipMemcpyHostToDevice));
+    if (pad) SCHWZ_HIP_TRY(hipMemset((char *)*d + count * sizeof(T), 0, pad * sizeof(T)));
     return SCHWZ_OK;
 }
 
@@ -514,7 +680,7 @@ int schwz_csr_create(int64_t nrows, int64_t ncols, const schwz_idx *h_rp, const 
     while (r < nrows) {
         int64_t e = r;
         const int64_t s = h_rp[r];
-        while (e < nrows && e - r < kTileRows && h_rp[e + 1] - s <= kTileNnz) ++e;
+        while (e < nrows && e - r < kTileRows && h_rp[e + 1] - s <= kTileNnz - 2) ++e;
         if (e == r) e = r + 1;  // long row
         tiles.push_back((schwz_idx)e);
         r = e;
@@ -527,8 +693,8 @@ int schwz_csr_create(int64_t nrows, int64_t ncols, const schwz_idx *h_rp, const 
     }
     schwz_csr *A = new schwz_csr();
     int rc;
-    if ((rc = upload(h_rp, (size_t)nrows + 1, &A->d_rp)) || (rc = upload(h_col, (size_t)nnz, &A->d_col)) ||
-        (rc = upload(h_val, (size_t)nnz, &A->d_val)) || (rc = upload(tiles.data(), tiles.size(), &A->d_tile))) {
+    if ((rc = upload(h_rp, (size_t)nrows + 1, &A->d_rp)) || (rc = upload(h_col, (size_t)nnz, &A->d_col, 2)) ||
+        (rc = upload(h_val, (size_t)nnz, &A->d_val, 2)) || (rc = upload(tiles.data(), tiles.size(), &A->d_tile))) {
         schwz_csr_destroy(A);
         return rc;
     }
@@ -566,6 +732,20 @@ int schwz_csr_spmv(const schwz_csr *A, double alpha, const double *d_x, double b
     a.x = d_x;
     a.y = d_y;
     return launch_spmv(A->v, kSpmvPlain, a, variant, (hipStream_t)stream);
+}
+
+int schwz_stream_probe(int64_t n, int mode, const double *d_src, double *d_dst, schwz_stream stream)
+{
+    SCHWZ_REQUIRE(n >= 0 && d_src && d_dst, "schwz_stream_probe: bad arguments");
+    SCHWZ_REQUIRE(mode == 0 || mode == 1, "schwz_stream_probe: mode must be 0 (copy) or 1 (read)");
+    if (mode == 0)
+        hipLaunchKernelGGL(stream_copy_kernel, dim3(kMaxGrid), dim3(kBlock), 0, (hipStream_t)stream, n / 2,
+                           (const double2 *)d_src, (double2 *)d_dst);
+    else
+        hipLaunchKernelGGL(stream_read_kernel, dim3(kMaxGrid), dim3(kBlock), 0, (hipStream_t)stream, n / 2,
+                           (const double2 *)d_src, d_dst);
+    SCHWZ_HIP_TRY(hipGetLastError());
+    return SCHWZ_OK;
 }
 
 // ---- profiling hooks (bench.py roofline leg) ------------------------------------

@@ -29,7 +29,7 @@ SYMBOLS = [
     "schwz_gather", "schwz_scatter",
     "schwz_csr_create", "schwz_csr_destroy", "schwz_csr_nnz", "schwz_csr_spmv",
     "schwz_pcg_create", "schwz_pcg_destroy", "schwz_pcg_solve",
-    "schwz_profile_begin", "schwz_profile_end",
+    "schwz_profile_begin", "schwz_profile_end", "schwz_stream_probe",
     "schwz_trs_create", "schwz_trs_destroy", "schwz_trs_solve",
     "schwz_problem_laplacian", "schwz_problem_from_csr", "schwz_problem_from_matrix_market",
     "schwz_problem_destroy", "schwz_problem_size", "schwz_problem_nnz", "schwz_problem_row",
@@ -104,6 +104,7 @@ _sig("schwz_pcg_destroy", None, [vp])
 _sig("schwz_pcg_solve", i32, [vp, vp, vp, dbl, i32, C.POINTER(C.c_int), C.POINTER(dbl), vp])
 _sig("schwz_profile_begin", i32, [i32])
 _sig("schwz_profile_end", i32, [C.POINTER(dbl), C.POINTER(i64)])
+_sig("schwz_stream_probe", i32, [i64, i32, vp, vp, vp])
 _sig("schwz_trs_create", i32, [i64] + [vp] * 7 + [pvp])
 _sig("schwz_trs_destroy", None, [vp])
 _sig("schwz_trs_solve", i32, [vp, vp, vp, vp])
