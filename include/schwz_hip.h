@@ -262,9 +262,21 @@ int schwz_ras_update_boundary(schwz_subdomain *sd, schwz_stream stream);
  * written to *h_resnorm after a stream sync (the reference copies the scalar
  * to the host at solve.cpp:842-843). */
 int schwz_ras_local_residual(schwz_subdomain *sd, double *h_resnorm, schwz_stream stream);
+/* The same in two halves: launch enqueues the kernels and the scalar copy and
+ * records an event; wait blocks on that event only.  A host layer may enqueue
+ * the local solve between the two, so the GPU never idles while the host reads
+ * the norm and runs the global check (schwz_ras_local_solve does not touch x~,
+ * so a converged verdict simply skips step 4). */
+int schwz_ras_local_residual_launch(schwz_subdomain *sd, schwz_stream stream);
+int schwz_ras_local_residual_wait(schwz_subdomain *sd, double *h_resnorm);
 /* step 3: y = solve(A_loc, b~), warm-started (Solve::local_solve,
  * source/solve.cpp:667-792).  h_inner_iters may be NULL (no sync). */
 int schwz_ras_local_solve(schwz_subdomain *sd, int *h_inner_iters, schwz_stream stream);
+/* steps 2+3 in one enqueue: the check residual of step 2 and the start residual of
+ * the CG solve of step 3 come out of ONE pass over A_loc (two gathers per entry,
+ * one matrix read), the norm's device->host copy is queued right behind it and
+ * the CG iterations behind that.  Follow with schwz_ras_local_residual_wait. */
+int schwz_ras_check_and_solve_launch(schwz_subdomain *sd, schwz_stream stream);
 /* step 4: x~[interior] = y[0:local_size] (Communicate::local_to_global_vector,
  * source/communicate.cpp:65-94) */
 int schwz_ras_restrict(schwz_subdomain *sd, schwz_stream stream);

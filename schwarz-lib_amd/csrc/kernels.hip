@@ -156,7 +156,8 @@ __global__ __launch_bounds__(kBlock) void spmv_tiled2_kernel(CsrView A, SpmvArgs
     const int slot = blockIdx.x / kXcds;
     const int per_xcd = gridDim.x / kXcds;
     const int chunk = (A.ntiles + kXcds - 1) / kXcds;
-    double acc0 = 0.0, acc1 = 0.0;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+    const bool dual = (MODE == kSpmvResidDual) && a.x2 != nullptr;
 
     for (int t = slot; t < chunk; t += per_xcd) {
         const int tile = xcd * chunk + t;
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(kBlock) void spmv_tiled2_kernel(CsrView A, SpmvArgs
         const int r0 = A.tile_row[tile], r1 = A.tile_row[tile + 1];
         const int s = A.rp[r0], e = A.rp[r1];
         const int cnt = e - s;
-        double sum = 0.0;
+        double sum = 0.0, sum2 = 0.0;
         int row = r0 + tid;
         bool have_row = false;
         if (cnt <= kTileNnz - 2) {
@@ -203,23 +204,192 @@ __global__ __launch_bounds__(kBlock) void spmv_tiled2_kernel(CsrView A, SpmvArgs
                 for (int j = b0; j < b1; ++j) sum += prod[j];
             }
             __syncthreads();
+            if (dual) {
+                // second vector, same matrix entries (still in registers)
+#pragma unroll
+                for (int k = 0; k < kPairsPerLane; ++k) {
+                    const int idx = s2 + 2 * (tid + kBlock * k);
+                    if (idx < e) {
+                        double2 pr;
+                        pr.x = v[k].x * a.x2[c[k].x];
+                        pr.y = v[k].y * a.x2[c[k].y];
+                        *reinterpret_cast<double2 *>(&prod[2 * (tid + kBlock * k)]) = pr;
+                    }
+                }
+                __syncthreads();
+                if (row < r1)
+                    for (int j = b0; j < b1; ++j) sum2 += prod[j];
+                __syncthreads();
+            }
         } else if (r1 - r0 > 1) {
             // tile that fits kTileNnz but not the aligned window: plain staging
             for (int i = tid; i < cnt; i += kBlock) prod[i] = A.val[s + i] * a.x[A.col[s + i]];
             __syncthreads();
+            const int b0 = row < r1 ? A.rp[row] - s : 0, b1 = row < r1 ? A.rp[row + 1] - s : 0;
             if (row < r1) {
                 have_row = true;
-                const int b0 = A.rp[row] - s, b1 = A.rp[row + 1] - s;
                 for (int j = b0; j < b1; ++j) sum += prod[j];
             }
             __syncthreads();
+            if (dual) {
+                for (int i = tid; i < cnt; i += kBlock) prod[i] = A.val[s + i] * a.x2[A.col[s + i]];
+                __syncthreads();
+                for (int j = b0; j < b1; ++j) sum2 += prod[j];
+                __syncthreads();
+            }
         } else {
             // a single long row: the whole workgroup reduces it
-            double part = 0.0;
-            for (int i = tid; i < cnt; i += kBlock) part += A.val[s + i] * a.x[A.col[s + i]];
+            double part = 0.0, part2 = 0.0;
+            for (int i = tid; i < cnt; i += kBlock) {
+                part += A.val[s + i] * a.x[A.col[s + i]];
+                if (dual) part2 += A.val[s + i] * a.x2[A.col[s + i]];
+            }
             part = block_sum(part, red);
+            if (dual) part2 = block_sum(part2, red);
             row = r0;
             if (tid == 0) {
+                have_row = true;
+                sum = part;
+                sum2 = part2;
+            }
+        }
+        if (have_row) {
+            if (MODE == kSpmvPlain) {
+                a.y[row] = (a.beta == 0.0) ? a.alpha * sum : a.alpha * sum + a.beta * a.y[row];
+            } else if (MODE == kSpmvDot) {
+                a.y[row] = sum;
+                acc0 += a.x[row] * sum;
+            } else if (MODE == kSpmvResidInit || MODE == kSpmvResidDual) {
+                const double bb = a.b[row];
+                const double r = bb - sum;
+                const double z = a.dinv ? a.dinv[row] * r : r;
+                a.y[row] = r;
+                a.p[row] = z;
+                acc0 += r * z;
+                acc1 += r * r;
+                if (MODE == kSpmvResidDual && row < a.row_limit) {
+                    const double r2 = dual ? bb - sum2 : r;
+                    acc2 += r2 * r2;
+                }
+            } else {  // kSpmvResidNorm
+                if (row < a.row_limit) {
+                    const double r = a.b[row] - sum;
+                    acc1 += r * r;
+                }
+            }
+        }
+    }
+    if (MODE != kSpmvPlain) {
+        const double s0 = block_sum(acc0, red);
+        const double s1 = block_sum(acc1, red);
+        if (tid == 0) {
+            a.partials[blockIdx.x] = s0;
+            a.partials[gridDim.x + blockIdx.x] = s1;
+        }
+        if (MODE == kSpmvResidDual) {
+            const double s2v = block_sum(acc2, red);
+            if (tid == 0) a.partials[2 * gridDim.x + blockIdx.x] = s2v;
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// Wave-tiled SpMV: the same idea with a WAVE as the unit of work.  Each 64-lane
+// wave owns tiles of <= 64 consecutive rows / <= 510 nonzeros, stages the
+// products in its private 4 KiB LDS slice and sums one row per lane.  There is no
+// workgroup barrier in the loop (LDS operations of one wave complete in order),
+// so the four waves of a workgroup -- and the 32 of a CU -- drift apart and keep
+// loads in flight while others are in their LDS phase.
+// NT: matrix entries are read once per SpMV; loading them non-temporally keeps
+// them from evicting the x planes that neighbouring tiles re-read from L2.
+// ---------------------------------------------------------------------------
+
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+
+template <typename T, bool NT>
+__device__ __forceinline__ T stream_load(const T *p)
+{
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int kWavePairs = kWaveTileNnz / 128;  // 16-byte pairs per lane per tile (4)
+
+template <int MODE, bool NT>
+__global__ __launch_bounds__(kBlock) void spmv_wave_kernel(CsrView A, SpmvArgs a)
+{
+    __shared__ double prod_all[kBlock / 64][kWaveTileNnz + 2];
+    __shared__ double red[4];
+    if (MODE == kSpmvDot || MODE == kSpmvResidInit) {
+        if (a.stop_iter && a.it >= *a.stop_iter) return;
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    double *prod = prod_all[wave];
+    const int xcd = blockIdx.x % kXcds;
+    const int slot = (blockIdx.x / kXcds) * (kBlock / 64) + wave;
+    const int per_xcd = (gridDim.x / kXcds) * (kBlock / 64);
+    const int chunk = (A.nwtiles + kXcds - 1) / kXcds;
+    double acc0 = 0.0, acc1 = 0.0;
+
+    for (int t = slot; t < chunk; t += per_xcd) {
+        const int tile = xcd * chunk + t;
+        if (tile >= A.nwtiles) break;
+        const int r0 = A.wtile_row[tile], r1 = A.wtile_row[tile + 1];
+        const int s = A.rp[r0], e = A.rp[r1];
+        const int cnt = e - s;
+        double sum = 0.0;
+        int row = r0 + lane;
+        bool have_row = false;
+        if (cnt <= kWaveTileNnz - 2) {
+            const int s2 = s & ~1;
+            int b0 = 0, b1 = 0;
+            if (row < r1) {
+                b0 = A.rp[row] - s2;
+                b1 = A.rp[row + 1] - s2;
+            }
+            v2d v[kWavePairs];
+            v2i c[kWavePairs];
+#pragma unroll
+            for (int k = 0; k < kWavePairs; ++k) {
+                const int idx = s2 + 2 * (lane + 64 * k);
+                if (idx < e) {
+                    v[k] = stream_load<v2d, NT>(reinterpret_cast<const v2d *>(A.val + idx));
+                    c[k] = stream_load<v2i, NT>(reinterpret_cast<const v2i *>(A.col + idx));
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kWavePairs; ++k) {
+                const int idx = s2 + 2 * (lane + 64 * k);
+                if (idx < e) {
+                    v2d pr;
+                    pr.x = v[k].x * a.x[c[k].x];
+                    pr.y = v[k].y * a.x[c[k].y];
+                    *reinterpret_cast<v2d *>(&prod[2 * (lane + 64 * k)]) = pr;
+                }
+            }
+            wave_lds_sync();
+            if (row < r1) {
+                have_row = true;
+                for (int j = b0; j < b1; ++j) sum += prod[j];
+            }
+            wave_lds_sync();
+        } else {
+            // a single row longer than a wave tile: the wave reduces it
+            double part = 0.0;
+            for (int i = lane; i < cnt; i += 64) part += A.val[s + i] * a.x[A.col[s + i]];
+            part = wave_sum(part);
+            row = r0;
+            if (lane == 0) {
                 have_row = true;
                 sum = part;
             }
@@ -248,7 +418,7 @@ __global__ __launch_bounds__(kBlock) void spmv_tiled2_kernel(CsrView A, SpmvArgs
     if (MODE != kSpmvPlain) {
         const double s0 = block_sum(acc0, red);
         const double s1 = block_sum(acc1, red);
-        if (tid == 0) {
+        if (threadIdx.x == 0) {
             a.partials[blockIdx.x] = s0;
             a.partials[gridDim.x + blockIdx.x] = s1;
         }
@@ -267,9 +437,11 @@ __global__ __launch_bounds__(kBlock) void spmv_rowlane_kernel(CsrView A, SpmvArg
     }
 }
 
-int spmv_grid(const CsrView &A)
+int spmv_grid(const CsrView &A, int variant)
 {
-    int g = A.ntiles < kMaxGrid ? A.ntiles : kMaxGrid;
+    // wave variants: four wave tiles per workgroup
+    const int units = (variant == 3 || variant == 5) ? (A.nwtiles + 3) / 4 : A.ntiles;
+    int g = units < kMaxGrid ? units : kMaxGrid;
     g = ((g + kXcds - 1) / kXcds) * kXcds;
     return g < kXcds ? kXcds : g;
 }
@@ -277,8 +449,34 @@ int spmv_grid(const CsrView &A)
 int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipStream_t s)
 {
     if (A.nrows == 0) return SCHWZ_OK;
-    const int grid = spmv_grid(A);
-    if (variant == 1 && mode == kSpmvPlain) {
+    if (mode == kSpmvResidDual && variant != 0) {
+        set_error("launch_spmv: the fused dual-residual mode exists for variant 0 only");
+        return SCHWZ_ERR_INVALID;
+    }
+    const int grid = spmv_grid(A, variant);
+#define SCHWZ_LAUNCH_WAVE(NTV)                                                                          \
+    switch (mode) {                                                                                    \
+    case kSpmvPlain:                                                                                   \
+        hipLaunchKernelGGL((spmv_wave_kernel<kSpmvPlain, NTV>), dim3(wgrid), dim3(kBlock), 0, s, A, a); \
+        break;                                                                                         \
+    case kSpmvDot:                                                                                     \
+        hipLaunchKernelGGL((spmv_wave_kernel<kSpmvDot, NTV>), dim3(wgrid), dim3(kBlock), 0, s, A, a);   \
+        break;                                                                                         \
+    case kSpmvResidInit:                                                                               \
+        hipLaunchKernelGGL((spmv_wave_kernel<kSpmvResidInit, NTV>), dim3(wgrid), dim3(kBlock), 0, s, A, a); \
+        break;                                                                                         \
+    default:                                                                                           \
+        hipLaunchKernelGGL((spmv_wave_kernel<kSpmvResidNorm, NTV>), dim3(wgrid), dim3(kBlock), 0, s, A, a); \
+        break;                                                                                         \
+    }
+    if (variant == 3 || variant == 5) {
+        const int wgrid = spmv_grid(A, variant);
+        if (variant == 3) {
+            SCHWZ_LAUNCH_WAVE(false)
+        } else {
+            SCHWZ_LAUNCH_WAVE(true)
+        }
+    } else if (variant == 1 && mode == kSpmvPlain) {
         hipLaunchKernelGGL(spmv_rowlane_kernel, dim3(kMaxGrid), dim3(kBlock), 0, s, A, a);
     } else if (variant != 2) {
         switch (mode) {
@@ -290,6 +488,9 @@ int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipS
             break;
         case kSpmvResidInit:
             hipLaunchKernelGGL(spmv_tiled2_kernel<kSpmvResidInit>, dim3(grid), dim3(kBlock), 0, s, A, a);
+            break;
+        case kSpmvResidDual:
+            hipLaunchKernelGGL(spmv_tiled2_kernel<kSpmvResidDual>, dim3(grid), dim3(kBlock), 0, s, A, a);
             break;
         default:
             hipLaunchKernelGGL(spmv_tiled2_kernel<kSpmvResidNorm>, dim3(grid), dim3(kBlock), 0, s, A, a);
@@ -320,11 +521,16 @@ int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipS
 // Scalars live in CgState in HBM; nothing returns to the host inside the loop.
 // ---------------------------------------------------------------------------
 
-__global__ void cg_init_finalize_kernel(CgState *st, const double *partials, int nparts, double rtol)
+__global__ void cg_init_finalize_kernel(CgState *st, const double *partials, int nparts, double rtol,
+                                        double *norm_sq_out)
 {
     __shared__ double red[4];
     const double rho = fold_partials(partials, nparts, red);
     const double rr = fold_partials(partials + nparts, nparts, red);
+    if (norm_sq_out) {
+        const double n2 = fold_partials(partials + 2 * nparts, nparts, red);
+        if (threadIdx.x == 0) norm_sq_out[0] = n2;
+    }
     if (threadIdx.x == 0) {
         st->rho[0] = rho;
         st->rho[1] = 0.0;
@@ -685,6 +891,18 @@ int schwz_csr_create(int64_t nrows, int64_t ncols, const schwz_idx *h_rp, const 
         tiles.push_back((schwz_idx)e);
         r = e;
     }
+    std::vector<schwz_idx> wtiles;
+    wtiles.reserve((size_t)(nrows / 32 + 2));
+    wtiles.push_back(0);
+    r = 0;
+    while (r < nrows) {
+        int64_t e = r;
+        const int64_t s = h_rp[r];
+        while (e < nrows && e - r < 64 && h_rp[e + 1] - s <= kWaveTileNnz - 2) ++e;
+        if (e == r) e = r + 1;  // long row
+        wtiles.push_back((schwz_idx)e);
+        r = e;
+    }
     for (int64_t i = 0; i < nnz; ++i) {
         if (h_col[i] < 0 || h_col[i] >= ncols) {
             set_error("schwz_csr_create: column index out of range");
@@ -694,7 +912,8 @@ int schwz_csr_create(int64_t nrows, int64_t ncols, const schwz_idx *h_rp, const 
     schwz_csr *A = new schwz_csr();
     int rc;
     if ((rc = upload(h_rp, (size_t)nrows + 1, &A->d_rp)) || (rc = upload(h_col, (size_t)nnz, &A->d_col, 2)) ||
-        (rc = upload(h_val, (size_t)nnz, &A->d_val, 2)) || (rc = upload(tiles.data(), tiles.size(), &A->d_tile))) {
+        (rc = upload(h_val, (size_t)nnz, &A->d_val, 2)) || (rc = upload(tiles.data(), tiles.size(), &A->d_tile)) ||
+        (rc = upload(wtiles.data(), wtiles.size(), &A->d_wtile))) {
         schwz_csr_destroy(A);
         return rc;
     }
@@ -706,6 +925,8 @@ int schwz_csr_create(int64_t nrows, int64_t ncols, const schwz_idx *h_rp, const 
     A->v.val = (const double *)A->d_val;
     A->v.ntiles = (int)tiles.size() - 1;
     A->v.tile_row = (const schwz_idx *)A->d_tile;
+    A->v.nwtiles = (int)wtiles.size() - 1;
+    A->v.wtile_row = (const schwz_idx *)A->d_wtile;
     *out = A;
     return SCHWZ_OK;
 }
@@ -717,6 +938,7 @@ void schwz_csr_destroy(schwz_csr *A)
     (void)hipFree(A->d_col);
     (void)hipFree(A->d_val);
     (void)hipFree(A->d_tile);
+    (void)hipFree(A->d_wtile);
     delete A;
 }
 
@@ -809,7 +1031,8 @@ int schwz_pcg_create(const schwz_csr *A, int precond, schwz_pcg **out)
     SCHWZ_HIP_TRY(hipMalloc((void **)&s->r, nb));
     SCHWZ_HIP_TRY(hipMalloc((void **)&s->p, nb));
     SCHWZ_HIP_TRY(hipMalloc((void **)&s->q, nb));
-    SCHWZ_HIP_TRY(hipMalloc((void **)&s->partials, sizeof(double) * 4 * kMaxGrid));
+    SCHWZ_HIP_TRY(hipMalloc((void **)&s->partials, sizeof(double) * 5 * kMaxGrid));
+    SCHWZ_HIP_TRY(hipMalloc((void **)&s->d_norm_sq, sizeof(double) * 2));
     SCHWZ_HIP_TRY(hipMalloc((void **)&s->state, sizeof(CgState)));
     SCHWZ_HIP_TRY(hipHostMalloc((void **)&s->h_state, 2 * sizeof(CgState), hipHostMallocDefault));
     SCHWZ_HIP_TRY(hipEventCreateWithFlags(&s->ev[0], hipEventDisableTiming));
@@ -834,6 +1057,7 @@ void schwz_pcg_destroy(schwz_pcg *s)
     (void)hipFree(s->q);
     (void)hipFree(s->dinv);
     (void)hipFree(s->partials);
+    (void)hipFree(s->d_norm_sq);
     (void)hipFree(s->state);
     (void)hipHostFree(s->h_state);
     if (s->ev[0]) (void)hipEventDestroy(s->ev[0]);
@@ -841,39 +1065,46 @@ void schwz_pcg_destroy(schwz_pcg *s)
     delete s;
 }
 
-int schwz_pcg_solve(schwz_pcg *s, const double *d_b, double *d_x, double rtol, int max_iters,
-                    int *h_iters, double *h_resnorm, schwz_stream stream)
+}  // extern "C"
+
+namespace schwz {
+
+// First half of a solve: r = b - A x, p = M^-1 r, rho, ||r||^2 -> CgState.  With
+// `fused` the same pass over the matrix also yields ||b - A x2||^2 over the rows
+// below row_limit in s->d_norm_sq[0] (x2 == nullptr: x2 is x).
+int pcg_begin(schwz_pcg *s, const double *d_b, double *d_x, double rtol, bool fused, const double *d_x2,
+              int64_t row_limit, hipStream_t st)
 {
-    SCHWZ_REQUIRE(s && d_b && d_x, "schwz_pcg_solve: null argument");
-    SCHWZ_REQUIRE(max_iters >= 0, "schwz_pcg_solve: negative max_iters");
-    SCHWZ_REQUIRE((reinterpret_cast<uintptr_t>(d_x) & 15) == 0, "schwz_pcg_solve: x must be 16-byte aligned");
-    hipStream_t st = (hipStream_t)stream;
+    const CsrView &A = s->A->v;
+    const int gs = spmv_grid(A, s->variant);
+    SpmvArgs a;
+    a.x = d_x;
+    a.x2 = d_x2;
+    a.b = d_b;
+    a.y = s->r;
+    a.p = s->p;
+    a.dinv = s->dinv;
+    a.partials = s->partials;
+    a.row_limit = row_limit;
+    int rc = launch_spmv(A, fused ? kSpmvResidDual : kSpmvResidInit, a, s->variant, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(cg_init_finalize_kernel, dim3(1), dim3(kBlock), 0, st, s->state, s->partials, gs, rtol,
+                       fused ? s->d_norm_sq : nullptr);
+    SCHWZ_HIP_TRY(hipGetLastError());
+    return SCHWZ_OK;
+}
+
+// Second half: up to max_iters CG updates.  With a positive tolerance the host
+// looks at the state every `chunk` iterations, one chunk behind the launches, so
+// the queue never drains.
+int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream_t st)
+{
     const CsrView &A = s->A->v;
     const int64_t n = s->n;
-    if (n == 0) {
-        if (h_iters) *h_iters = 0;
-        if (h_resnorm) *h_resnorm = 0.0;
-        return SCHWZ_OK;
-    }
-    const int gs = spmv_grid(A);
+    const int gs = spmv_grid(A, s->variant);
     const int gv = grid_for((n + 1) / 2);
-    double *part_spmv = s->partials;             // [2][gs]
-    double *part_vec = s->partials + 2 * kMaxGrid;  // [2][gv]
-    // r = b - A x ; p = M^-1 r ; rho, rr
-    {
-        SpmvArgs a;
-        a.x = d_x;
-        a.b = d_b;
-        a.y = s->r;
-        a.p = s->p;
-        a.dinv = s->dinv;
-        a.partials = part_spmv;
-        int rc = launch_spmv(A, kSpmvResidInit, a, s->variant, st);
-        if (rc) return rc;
-        hipLaunchKernelGGL(cg_init_finalize_kernel, dim3(1), dim3(kBlock), 0, st, s->state, part_spmv, gs, rtol);
-    }
-    // With a positive tolerance the host looks at the state every `chunk`
-    // iterations, one chunk behind the launches, so the queue never drains.
+    double *part_spmv = s->partials;                // [3][gs]
+    double *part_vec = s->partials + 3 * kMaxGrid;  // [2][gv]
     const bool poll = rtol > 0.0;
     int chunk = 16;
     int it = 0, pending = -1, bank = 0;
@@ -913,6 +1144,28 @@ int schwz_pcg_solve(schwz_pcg *s, const double *d_b, double *d_x, double rtol, i
             if (chunk < 64) chunk *= 2;
         }
     }
+    return SCHWZ_OK;
+}
+
+}  // namespace schwz
+
+extern "C" {
+
+int schwz_pcg_solve(schwz_pcg *s, const double *d_b, double *d_x, double rtol, int max_iters,
+                    int *h_iters, double *h_resnorm, schwz_stream stream)
+{
+    SCHWZ_REQUIRE(s && d_b && d_x, "schwz_pcg_solve: null argument");
+    SCHWZ_REQUIRE(max_iters >= 0, "schwz_pcg_solve: negative max_iters");
+    SCHWZ_REQUIRE((reinterpret_cast<uintptr_t>(d_x) & 15) == 0, "schwz_pcg_solve: x must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (s->n == 0) {
+        if (h_iters) *h_iters = 0;
+        if (h_resnorm) *h_resnorm = 0.0;
+        return SCHWZ_OK;
+    }
+    int rc = pcg_begin(s, d_b, d_x, rtol, false, nullptr, 0, st);
+    if (rc) return rc;
+    if ((rc = pcg_iterate(s, d_x, rtol, max_iters, st))) return rc;
     if (h_iters || h_resnorm) {
         SCHWZ_HIP_TRY(hipMemcpyAsync(&s->h_state[0], s->state, sizeof(CgState), hipMemcpyDeviceToHost, st));
         SCHWZ_HIP_TRY(hipStreamSynchronize(st));

@@ -40,6 +40,7 @@ constexpr int kTileNnz = 2048;   // products staged in LDS per tile (16 KiB fp64
 constexpr int kTileRows = 256;   // one lane per row in the reduction phase
 constexpr int kMaxGrid = 2048;   // 256 CUs x 8 workgroups, grid-stride beyond
 constexpr int kXcds = 8;
+constexpr int kWaveTileNnz = 512;  // products staged per wave (4 KiB fp64)
 
 struct CsrView {
     int64_t nrows = 0, ncols = 0, nnz = 0;
@@ -48,6 +49,8 @@ struct CsrView {
     const double *val = nullptr;
     int ntiles = 0;
     const schwz_idx *tile_row = nullptr;  // ntiles+1 row boundaries
+    int nwtiles = 0;                        // wave tiles: <= 64 rows, <= kWaveTileNnz-2 nnz
+    const schwz_idx *wtile_row = nullptr;
 };
 
 // epilogues of the tiled SpMV kernel
@@ -55,23 +58,28 @@ enum SpmvMode {
     kSpmvPlain = 0,      // y = alpha*A*x + beta*y
     kSpmvDot = 1,        // y = A*x ; partial[b] = sum x_i*y_i
     kSpmvResidInit = 2,  // r = b - A*x ; p = dinv*r ; partials sum r*z, sum r*r
-    kSpmvResidNorm = 3   // partial sum (b - A*x)^2, nothing stored
+    kSpmvResidNorm = 3,  // partial sum (b - A*x)^2, nothing stored
+    // kSpmvResidInit on x plus, in the same pass over the matrix, the partial sum
+    // (b - A*x2)^2 over rows < row_limit (third partial bank): the convergence-check
+    // residual (solve.cpp:834-841) and the CG start residual share one matrix read
+    kSpmvResidDual = 4
 };
 
 struct SpmvArgs {
     double alpha = 1.0, beta = 0.0;
     const double *x = nullptr;
+    const double *x2 = nullptr;  // kSpmvResidDual: second vector (nullptr: same as x)
     double *y = nullptr;        // out vector (y / q / r)
     const double *b = nullptr;  // rhs for the residual modes
     double *p = nullptr;        // kSpmvResidInit: search direction out
     const double *dinv = nullptr;
-    double *partials = nullptr;  // [2][grid]
+    double *partials = nullptr;  // [2][grid] ([3][grid] for kSpmvResidDual)
     const int *stop_iter = nullptr;  // device flag checked by CG launches
     int it = 0;
     int64_t row_limit = 0;  // rows >= row_limit are skipped in kSpmvResidNorm
 };
 
-int spmv_grid(const CsrView &A);
+int spmv_grid(const CsrView &A, int variant);
 int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipStream_t s);
 
 // device-side CG scalar state
@@ -85,11 +93,18 @@ struct CgState {
 
 }  // namespace schwz
 
+struct schwz_pcg;
+namespace schwz {
+int pcg_begin(schwz_pcg *s, const double *d_b, double *d_x, double rtol, bool fused, const double *d_x2,
+              int64_t row_limit, hipStream_t st);
+int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream_t st);
+}  // namespace schwz
+
 // ---- opaque ABI types -------------------------------------------------------
 
 struct schwz_csr {
     schwz::CsrView v;
-    void *d_rp = nullptr, *d_col = nullptr, *d_val = nullptr, *d_tile = nullptr;
+    void *d_rp = nullptr, *d_col = nullptr, *d_val = nullptr, *d_tile = nullptr, *d_wtile = nullptr;
 };
 
 struct schwz_pcg {
@@ -97,7 +112,8 @@ struct schwz_pcg {
     int precond = 0;
     int64_t n = 0;
     double *r = nullptr, *p = nullptr, *q = nullptr, *dinv = nullptr;
-    double *partials = nullptr;  // 2 * kMaxGrid * 2 (two banks)
+    double *partials = nullptr;  // 3 * kMaxGrid (SpMV banks) + 2 * kMaxGrid (vector banks)
+    double *d_norm_sq = nullptr; // kSpmvResidDual result
     schwz::CgState *state = nullptr;
     schwz::CgState *h_state = nullptr;  // pinned
     hipEvent_t ev[2] = {nullptr, nullptr};
@@ -168,4 +184,5 @@ struct schwz_subdomain {
     double *d_y = nullptr;       // init_guess / solve result
     double *d_partials = nullptr;
     double *h_scalar = nullptr;  // pinned
+    hipEvent_t ev_scalar = nullptr;
 };

@@ -52,6 +52,7 @@ void schwz_subdomain_destroy(schwz_subdomain *sd)
                         sd->d_rhs, sd->d_btilde, sd->d_y, sd->d_partials};
         for (void *p : ptrs) (void)hipFree(p);
         if (sd->h_scalar) (void)hipHostFree(sd->h_scalar);
+        if (sd->ev_scalar) (void)hipEventDestroy(sd->ev_scalar);
     }
     delete sd;
 }
@@ -103,6 +104,7 @@ int schwz_subdomain_to_device(schwz_subdomain *sd, const double *h_local_rhs, co
     if ((rc = dev_upload(rhs, &sd->d_rhs)) || (rc = dev_upload(rhs, &sd->d_btilde))) return rc;
     SCHWZ_HIP_TRY(hipMalloc((void **)&sd->d_partials, sizeof(double) * (2 * kMaxGrid + 2)));
     SCHWZ_HIP_TRY(hipHostMalloc((void **)&sd->h_scalar, 4 * sizeof(double), hipHostMallocDefault));
+    SCHWZ_HIP_TRY(hipEventCreateWithFlags(&sd->ev_scalar, hipEventDisableTiming));
     if (opt->local_solver == SCHWZ_SOLVER_ITERATIVE) {
         if ((rc = schwz_pcg_create(sd->A, opt->precond, &sd->cg))) return rc;
         sd->cg->variant = opt->spmv_variant;
@@ -157,38 +159,51 @@ int schwz_ras_update_boundary(schwz_subdomain *sd, schwz_stream stream)
                                    sd->d_x, sd->d_rhs, sd->d_btilde, (hipStream_t)stream);
 }
 
-static int residual_norm_sq(schwz_subdomain *sd, const double *b, int64_t row_limit, double *h_out,
-                            hipStream_t st)
+// Launches the residual-norm kernels and the 8-byte device->host copy, then records
+// an event: the host can wait for the scalar alone while later launches (the local
+// solve) already run behind it on the same stream.
+static int residual_norm_sq_launch(schwz_subdomain *sd, const double *b, int64_t row_limit, hipStream_t st)
 {
     SpmvArgs a;
     a.x = sd->d_x;
     a.b = b;
     a.partials = sd->d_partials;
     a.row_limit = row_limit;
-    int rc = launch_spmv(sd->A->v, kSpmvResidNorm, a, 0, st);
+    int rc = launch_spmv(sd->A->v, kSpmvResidNorm, a, sd->opt.spmv_variant, st);
     if (rc) return rc;
-    const int g = spmv_grid(sd->A->v);
+    const int g = spmv_grid(sd->A->v, sd->opt.spmv_variant);
     double *d_out = sd->d_partials + 2 * kMaxGrid;
     if ((rc = launch_final_norm(sd->d_partials + g, g, d_out, st))) return rc;
     SCHWZ_HIP_TRY(hipMemcpyAsync(sd->h_scalar, d_out, sizeof(double), hipMemcpyDeviceToHost, st));
-    SCHWZ_HIP_TRY(hipStreamSynchronize(st));
-    *h_out = sd->h_scalar[0];
+    SCHWZ_HIP_TRY(hipEventRecord(sd->ev_scalar, st));
+    return SCHWZ_OK;
+}
+
+int schwz_ras_local_residual_launch(schwz_subdomain *sd, schwz_stream stream)
+{
+    REQUIRE_DEVICE(sd, "schwz_ras_local_residual_launch");
+    if (sd->local_size_x == 0) return SCHWZ_OK;
+    return residual_norm_sq_launch(sd, sd->d_btilde, sd->local_size_x, (hipStream_t)stream);
+}
+
+int schwz_ras_local_residual_wait(schwz_subdomain *sd, double *h_resnorm)
+{
+    REQUIRE_DEVICE(sd, "schwz_ras_local_residual_wait");
+    SCHWZ_REQUIRE(h_resnorm, "schwz_ras_local_residual_wait: null output");
+    if (sd->local_size_x == 0) {
+        *h_resnorm = 0.0;
+        return SCHWZ_OK;
+    }
+    SCHWZ_HIP_TRY(hipEventSynchronize(sd->ev_scalar));
+    *h_resnorm = std::sqrt(sd->h_scalar[0]);
     return SCHWZ_OK;
 }
 
 int schwz_ras_local_residual(schwz_subdomain *sd, double *h_resnorm, schwz_stream stream)
 {
-    REQUIRE_DEVICE(sd, "schwz_ras_local_residual");
-    SCHWZ_REQUIRE(h_resnorm, "schwz_ras_local_residual: null output");
-    if (sd->local_size_x == 0) {
-        *h_resnorm = 0.0;
-        return SCHWZ_OK;
-    }
-    double sq = 0.0;
-    int rc = residual_norm_sq(sd, sd->d_btilde, sd->local_size_x, &sq, (hipStream_t)stream);
+    int rc = schwz_ras_local_residual_launch(sd, stream);
     if (rc) return rc;
-    *h_resnorm = std::sqrt(sq);
-    return SCHWZ_OK;
+    return schwz_ras_local_residual_wait(sd, h_resnorm);
 }
 
 int schwz_ras_true_residual_sq(schwz_subdomain *sd, double *h_out, schwz_stream stream)
@@ -199,7 +214,11 @@ int schwz_ras_true_residual_sq(schwz_subdomain *sd, double *h_out, schwz_stream 
         *h_out = 0.0;
         return SCHWZ_OK;
     }
-    return residual_norm_sq(sd, sd->d_rhs, sd->local_size, h_out, (hipStream_t)stream);
+    int rc = residual_norm_sq_launch(sd, sd->d_rhs, sd->local_size, (hipStream_t)stream);
+    if (rc) return rc;
+    SCHWZ_HIP_TRY(hipEventSynchronize(sd->ev_scalar));
+    *h_out = sd->h_scalar[0];
+    return SCHWZ_OK;
 }
 
 int schwz_ras_local_solve(schwz_subdomain *sd, int *h_inner_iters, schwz_stream stream)
@@ -213,6 +232,29 @@ int schwz_ras_local_solve(schwz_subdomain *sd, int *h_inner_iters, schwz_stream 
     const int maxit = sd->opt.local_max_iters == -1 ? (int)n : sd->opt.local_max_iters;
     return schwz_pcg_solve(sd->cg, sd->d_btilde, sd->d_y, sd->opt.local_tol, maxit, h_inner_iters, nullptr,
                            stream);
+}
+
+int schwz_ras_check_and_solve_launch(schwz_subdomain *sd, schwz_stream stream)
+{
+    REQUIRE_DEVICE(sd, "schwz_ras_check_and_solve_launch");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = sd->local_size_x;
+    if (n == 0) return SCHWZ_OK;
+    if (sd->opt.local_solver != SCHWZ_SOLVER_ITERATIVE || sd->opt.spmv_variant != 0) {
+        // no fused kernel for this configuration: the two steps back to back
+        int rc = schwz_ras_local_residual_launch(sd, stream);
+        if (rc) return rc;
+        return schwz_ras_local_solve(sd, nullptr, stream);
+    }
+    // x~ and y coincide on [interior|overlap] when there is no overlap at all
+    // (single subdomain): the check residual is then the CG start residual.
+    const double *x2 = (sd->overlap_size == 0) ? nullptr : sd->d_x;
+    const int maxit = sd->opt.local_max_iters == -1 ? (int)n : sd->opt.local_max_iters;
+    int rc = pcg_begin(sd->cg, sd->d_btilde, sd->d_y, sd->opt.local_tol, true, x2, n, st);
+    if (rc) return rc;
+    SCHWZ_HIP_TRY(hipMemcpyAsync(sd->h_scalar, sd->cg->d_norm_sq, sizeof(double), hipMemcpyDeviceToHost, st));
+    SCHWZ_HIP_TRY(hipEventRecord(sd->ev_scalar, st));
+    return pcg_iterate(sd->cg, sd->d_y, sd->opt.local_tol, maxit, st);
 }
 
 int schwz_ras_restrict(schwz_subdomain *sd, schwz_stream stream)

@@ -42,7 +42,8 @@ SYMBOLS = [
     "schwz_subdomain_send_offset", "schwz_subdomain_recv_offset",
     "schwz_cholesky", "schwz_free",
     "schwz_subdomain_to_device", "schwz_ras_pack", "schwz_ras_unpack",
-    "schwz_ras_update_boundary", "schwz_ras_local_residual", "schwz_ras_local_solve",
+    "schwz_ras_update_boundary", "schwz_ras_local_residual", "schwz_ras_local_residual_launch",
+    "schwz_ras_local_residual_wait", "schwz_ras_local_solve", "schwz_ras_check_and_solve_launch",
     "schwz_ras_restrict", "schwz_ras_vector", "schwz_ras_get_interior",
     "schwz_ras_true_residual_sq", "schwz_ras_algorithmic_bytes",
 ]
@@ -137,6 +138,9 @@ _sig("schwz_ras_pack", i32, [vp, vp, vp])
 _sig("schwz_ras_unpack", i32, [vp, vp, vp])
 _sig("schwz_ras_update_boundary", i32, [vp, vp])
 _sig("schwz_ras_local_residual", i32, [vp, C.POINTER(dbl), vp])
+_sig("schwz_ras_local_residual_launch", i32, [vp, vp])
+_sig("schwz_ras_local_residual_wait", i32, [vp, C.POINTER(dbl)])
+_sig("schwz_ras_check_and_solve_launch", i32, [vp, vp])
 _sig("schwz_ras_local_solve", i32, [vp, C.POINTER(C.c_int), vp])
 _sig("schwz_ras_restrict", i32, [vp, vp])
 _sig("schwz_ras_vector", i32, [vp, i32, pvp, C.POINTER(i64)])

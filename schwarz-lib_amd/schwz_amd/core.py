@@ -345,6 +345,17 @@ class Subdomain:
         check(lib.schwz_ras_local_residual(self.h, C.byref(out), _stream_arg(stream)))
         return out.value
 
+    def local_residual_launch(self, stream=0):
+        check(lib.schwz_ras_local_residual_launch(self.h, _stream_arg(stream)))
+
+    def check_and_solve_launch(self, stream=0):
+        check(lib.schwz_ras_check_and_solve_launch(self.h, _stream_arg(stream)))
+
+    def local_residual_wait(self):
+        out = C.c_double(0.0)
+        check(lib.schwz_ras_local_residual_wait(self.h, C.byref(out)))
+        return out.value
+
     def local_solve(self, stream=0, want_iters=False):
         it = C.c_int(0)
         check(lib.schwz_ras_local_solve(self.h, C.byref(it) if want_iters else None,

@@ -210,6 +210,7 @@ class SolverRAS:
         metadata.comm_size = self.comm.size
         metadata.my_rank = self.comm.rank
         self.subdomains = {}
+        self.speculative_solve = True
         self.problem = None
         self.result = None
 
@@ -371,10 +372,23 @@ class SolverRAS:
         for _, sd in locals_:
             sd.update_boundary(stream)
         t2 = time.perf_counter()
-        # 2 convergence check (solve.cpp:959-1005)
+        # 2 convergence check (solve.cpp:959-1005).  The residual kernels are enqueued, then
+        # the local solve (step 3) is enqueued right behind them BEFORE the host waits for
+        # the 8-byte norm: the GPU keeps working while the host runs the global check.  The
+        # solve only writes y (and CG work vectors); if the verdict is "converged" its result
+        # is simply not written back (step 4 is skipped), exactly like the reference.
+        spec = self.speculative_solve and hasattr(locals_[0][1], "local_residual_launch")
+        if tol >= 0.0 and spec:
+            for _, sd in locals_:
+                sd.check_and_solve_launch(stream)
         lres = {}
         for me, sd in locals_:
-            lres[me] = sd.local_residual(stream) if tol >= 0.0 else -1.0
+            if tol < 0.0:
+                lres[me] = -1.0
+            elif spec:
+                lres[me] = sd.local_residual_wait()
+            else:
+                lres[me] = sd.local_residual(stream)
             if self._lres0[me] < 0.0:
                 self._lres0[me] = lres[me]
             if np.isnan(lres[me]):
@@ -417,9 +431,10 @@ class SolverRAS:
         tm[2].append(t3 - t2)
         if self._num_converged == P:
             return True
-        # 3 local solve
-        for _, sd in locals_:
-            sd.local_solve(stream)
+        # 3 local solve (already enqueued above in speculative mode)
+        if not (tol >= 0.0 and spec):
+            for _, sd in locals_:
+                sd.local_solve(stream)
         t4 = time.perf_counter()
         # 4 restricted write-back
         for _, sd in locals_:

@@ -57,7 +57,7 @@ def _ragged_matrix(rng, n, max_len, long_row=None):
     return rp, col, val
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5])
 @pytest.mark.parametrize("case", ["lap2d", "lap3d", "ragged", "longrow", "tiny"])
 def test_spmv_matches_oracle(schwz, oracle, torch_cuda, case, variant):
     torch = torch_cuda

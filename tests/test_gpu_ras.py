@@ -302,3 +302,25 @@ def test_large_problem_properties(schwz, torch_cuda, P):
     A.spmv(x2.data_ptr(), y2.data_ptr())
     torch.cuda.synchronize()
     assert torch.equal(2.0 * y1, y2)
+
+
+@pytest.mark.parametrize("P", [1, 3])
+def test_fused_check_and_solve_equals_separate_steps(schwz, torch_cuda, P):
+    """schwz_ras_check_and_solve_launch (one pass over A_loc for the check residual and the CG
+    start residual, local solve enqueued before the host reads the norm) must reproduce the
+    separate step-2 / step-3 entry points bit for bit."""
+    shape = (20, 16, 18)
+    hist, sols = [], []
+    for speculative in (True, False):
+        s = schwz.Settings(laplacian_dim=3, laplacian_shape=shape)
+        m = schwz.Metadata(num_subdomains=P, tolerance=1e-7, max_iters=200, local_precond="block-jacobi",
+                           precond_max_block_size=1, local_solver_tolerance=0.0, local_max_iters=7)
+        solver = schwz.SolverRAS(s, m, comm=schwz.InProcessComm(P), quiet=True)
+        solver.speculative_solve = speculative
+        solver.initialize()
+        out = solver.run()
+        assert out["converged"]
+        hist.append(np.array(m.post_process_data["global_residual_vector_out"]))
+        sols.append(out["solution"])
+    assert hist[0].shape == hist[1].shape and np.array_equal(hist[0], hist[1])
+    assert np.array_equal(sols[0], sols[1])

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 passes written by tools/profile_bench.sh into the files
+committed under profiles/:
+
+    python tools/summarize_profile.py gpurun_out/prof_r01 r01
+
+  profiles/<tag>_kernel_stats.csv   copy of rocprofv3 --stats per-kernel summary
+  profiles/<tag>_summary.json       per kernel: calls, avg ns, FETCH_SIZE/WRITE_SIZE per launch
+  profiles/traffic.json             HBM bytes per launch of the dominant kernel (read by bench.py)
+
+Counter handling follows /opt/skills/guides/MI355X_MICROARCH.md "HBM": FETCH_SIZE and
+WRITE_SIZE are collected in separate passes and are in KiB; on gfx950 FETCH_SIZE reports
+half of the bytes of a wide coalesced streaming read, so it is doubled; WRITE_SIZE is exact
+for 16-byte-per-lane streaming stores.
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+DOMINANT = "spmv_tiled2_kernel<1>"
+
+
+def read_counter(dirname, counter):
+    acc = defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(os.path.join(dirname, "**", "*_counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] != counter:
+                continue
+            a = acc[row["Kernel_Name"]]
+            a[0] += float(row["Counter_Value"])
+            a[1] += 1
+    return {k: v[0] / v[1] for k, v in acc.items() if v[1]}
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, "profiles")
+    os.makedirs(out, exist_ok=True)
+    stats = glob.glob(os.path.join(src, "stats", "**", "*_kernel_stats.csv"), recursive=True)[0]
+    shutil.copy(stats, os.path.join(out, tag + "_kernel_stats.csv"))
+    fetch = read_counter(os.path.join(src, "fetch"), "FETCH_SIZE")
+    write = read_counter(os.path.join(src, "write"), "WRITE_SIZE")
+    summary = {}
+    for row in csv.DictReader(open(stats)):
+        name = row["Name"]
+        f_kib, w_kib = fetch.get(name), write.get(name)
+        entry = dict(calls=int(row["Calls"]), avg_ns=float(row["AverageNs"]),
+                     pct=float(row["Percentage"]),
+                     fetch_size_kib_raw=f_kib, write_size_kib=w_kib)
+        if f_kib is not None and w_kib is not None:
+            entry["hbm_bytes_per_launch"] = (2.0 * f_kib + w_kib) * 1024.0
+            entry["hbm_GBs"] = entry["hbm_bytes_per_launch"] / entry["avg_ns"]
+        summary[name] = entry
+    json.dump(summary, open(os.path.join(out, tag + "_summary.json"), "w"), indent=1, sort_keys=True)
+    dom = [v for k, v in summary.items() if DOMINANT in k]
+    if dom and "hbm_bytes_per_launch" in dom[0]:
+        tpath = os.path.join(out, "traffic.json")
+        tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        key = sys.argv[3] if len(sys.argv) > 3 else "256x256x256"
+        tj[key] = dict(kernel=DOMINANT, hbm_bytes_per_launch=dom[0]["hbm_bytes_per_launch"],
+                       avg_ns=dom[0]["avg_ns"], source=tag + "_summary.json",
+                       note="(2*FETCH_SIZE + WRITE_SIZE) KiB per launch, separate --pmc passes")
+        json.dump(tj, open(tpath, "w"), indent=1, sort_keys=True)
+    for k, v in sorted(summary.items(), key=lambda kv: -kv[1]["pct"])[:8]:
+        print("%-60s calls %4d avg %9.1f us  hbm %s" % (
+            k[:60], v["calls"], v["avg_ns"] / 1e3,
+            ("%.3f GB (%.0f GB/s)" % (v["hbm_bytes_per_launch"] / 1e9, v["hbm_GBs"]))
+            if "hbm_bytes_per_launch" in v else "n/a"))
+
+
+if __name__ == "__main__":
+    main()
