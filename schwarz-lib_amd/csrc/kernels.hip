@@ -529,7 +529,10 @@ __global__ void cg_init_finalize_kernel(CgState *st, const double *partials, int
     const double rr = fold_partials(partials + nparts, nparts, red);
     if (norm_sq_out) {
         const double n2 = fold_partials(partials + 2 * nparts, nparts, red);
-        if (threadIdx.x == 0) norm_sq_out[0] = n2;
+        if (threadIdx.x == 0) {
+            norm_sq_out[0] = n2;  // may be mapped host memory
+            __threadfence_system();
+        }
     }
     if (threadIdx.x == 0) {
         st->rho[0] = rho;
@@ -738,11 +741,25 @@ __global__ __launch_bounds__(kBlock) void stream_read_kernel(int64_t n2, const d
     if (threadIdx.x == 0) out[blockIdx.x] = a;
 }
 
+__global__ __launch_bounds__(kBlock) void copy_kernel(int64_t n, const double *__restrict__ src,
+                                                      double *__restrict__ dst)
+{
+    const int64_t n2 = n >> 1;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const double2 *s2 = reinterpret_cast<const double2 *>(src);
+    double2 *d2 = reinterpret_cast<double2 *>(dst);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) d2[i] = s2[i];
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[n - 1] = src[n - 1];
+}
+
 __global__ void final_norm_kernel(const double *partials, int nparts, double *out)
 {
     __shared__ double red[4];
     const double s = fold_partials(partials, nparts, red);
-    if (threadIdx.x == 0) out[0] = s;
+    if (threadIdx.x == 0) {
+        out[0] = s;  // may be mapped host memory
+        __threadfence_system();
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1290,6 +1307,16 @@ int launch_interface_update(int64_t nrows, int64_t row0, const schwz_idx *rp, co
     if (nrows == 0) return SCHWZ_OK;
     hipLaunchKernelGGL(interface_update_kernel, dim3(grid_for(nrows)), dim3(kBlock), 0, s, nrows, row0, rp,
                        col, val, x, b, bt);
+    SCHWZ_HIP_TRY(hipGetLastError());
+    return SCHWZ_OK;
+}
+
+// dst[0:n] = src[0:n]; both 16-byte aligned.  A plain kernel instead of
+// hipMemcpyAsync: the runtime's copy path leaves a 20-40 us hole in the stream.
+int launch_copy(int64_t n, const double *src, double *dst, hipStream_t s)
+{
+    if (n == 0) return SCHWZ_OK;
+    hipLaunchKernelGGL(copy_kernel, dim3(grid_for((n + 1) / 2)), dim3(kBlock), 0, s, n, src, dst);
     SCHWZ_HIP_TRY(hipGetLastError());
     return SCHWZ_OK;
 }

@@ -183,6 +183,7 @@ struct schwz_subdomain {
     double *d_btilde = nullptr;  // b~ = local_solution on entry of the solve
     double *d_y = nullptr;       // init_guess / solve result
     double *d_partials = nullptr;
-    double *h_scalar = nullptr;  // pinned
+    double *h_scalar = nullptr;  // pinned, mapped
+    double *d_h_scalar = nullptr;  // device alias of h_scalar
     hipEvent_t ev_scalar = nullptr;
 };

@@ -18,6 +18,7 @@ namespace schwz {
 int launch_interface_update(int64_t nrows, int64_t row0, const schwz_idx *rp, const schwz_idx *col,
                             const double *val, const double *x, const double *b, double *bt, hipStream_t s);
 int launch_final_norm(const double *partials, int nparts, double *out, hipStream_t s);
+int launch_copy(int64_t n, const double *src, double *dst, hipStream_t s);
 }  // namespace schwz
 
 using namespace schwz;
@@ -103,7 +104,8 @@ int schwz_subdomain_to_device(schwz_subdomain *sd, const double *h_local_rhs, co
     std::vector<double> rhs(h_local_rhs, h_local_rhs + n);
     if ((rc = dev_upload(rhs, &sd->d_rhs)) || (rc = dev_upload(rhs, &sd->d_btilde))) return rc;
     SCHWZ_HIP_TRY(hipMalloc((void **)&sd->d_partials, sizeof(double) * (2 * kMaxGrid + 2)));
-    SCHWZ_HIP_TRY(hipHostMalloc((void **)&sd->h_scalar, 4 * sizeof(double), hipHostMallocDefault));
+    SCHWZ_HIP_TRY(hipHostMalloc((void **)&sd->h_scalar, 4 * sizeof(double), hipHostMallocMapped));
+    SCHWZ_HIP_TRY(hipHostGetDevicePointer((void **)&sd->d_h_scalar, sd->h_scalar, 0));
     SCHWZ_HIP_TRY(hipEventCreateWithFlags(&sd->ev_scalar, hipEventDisableTiming));
     if (opt->local_solver == SCHWZ_SOLVER_ITERATIVE) {
         if ((rc = schwz_pcg_create(sd->A, opt->precond, &sd->cg))) return rc;
@@ -172,9 +174,9 @@ static int residual_norm_sq_launch(schwz_subdomain *sd, const double *b, int64_t
     int rc = launch_spmv(sd->A->v, kSpmvResidNorm, a, sd->opt.spmv_variant, st);
     if (rc) return rc;
     const int g = spmv_grid(sd->A->v, sd->opt.spmv_variant);
-    double *d_out = sd->d_partials + 2 * kMaxGrid;
-    if ((rc = launch_final_norm(sd->d_partials + g, g, d_out, st))) return rc;
-    SCHWZ_HIP_TRY(hipMemcpyAsync(sd->h_scalar, d_out, sizeof(double), hipMemcpyDeviceToHost, st));
+    // the scalar lands in mapped pinned host memory straight from the kernel: no
+    // copy engine hop between this kernel and the next one in the stream
+    if ((rc = launch_final_norm(sd->d_partials + g, g, sd->d_h_scalar, st))) return rc;
     SCHWZ_HIP_TRY(hipEventRecord(sd->ev_scalar, st));
     return SCHWZ_OK;
 }
@@ -250,9 +252,11 @@ int schwz_ras_check_and_solve_launch(schwz_subdomain *sd, schwz_stream stream)
     // (single subdomain): the check residual is then the CG start residual.
     const double *x2 = (sd->overlap_size == 0) ? nullptr : sd->d_x;
     const int maxit = sd->opt.local_max_iters == -1 ? (int)n : sd->opt.local_max_iters;
+    double *keep = sd->cg->d_norm_sq;
+    sd->cg->d_norm_sq = sd->d_h_scalar;  // mapped pinned host memory, written by the kernel
     int rc = pcg_begin(sd->cg, sd->d_btilde, sd->d_y, sd->opt.local_tol, true, x2, n, st);
+    sd->cg->d_norm_sq = keep;
     if (rc) return rc;
-    SCHWZ_HIP_TRY(hipMemcpyAsync(sd->h_scalar, sd->cg->d_norm_sq, sizeof(double), hipMemcpyDeviceToHost, st));
     SCHWZ_HIP_TRY(hipEventRecord(sd->ev_scalar, st));
     return pcg_iterate(sd->cg, sd->d_y, sd->opt.local_tol, maxit, st);
 }
@@ -261,9 +265,7 @@ int schwz_ras_restrict(schwz_subdomain *sd, schwz_stream stream)
 {
     REQUIRE_DEVICE(sd, "schwz_ras_restrict");
     if (sd->local_size == 0) return SCHWZ_OK;
-    SCHWZ_HIP_TRY(hipMemcpyAsync(sd->d_x, sd->d_y, (size_t)sd->local_size * sizeof(double),
-                                 hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    return SCHWZ_OK;
+    return launch_copy(sd->local_size, sd->d_y, sd->d_x, (hipStream_t)stream);
 }
 
 int schwz_ras_vector(schwz_subdomain *sd, int which, double **d_ptr, int64_t *len)
