@@ -6,7 +6,9 @@
 // Wavefronts are 64 lanes; workgroups are 256 threads (4 waves).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <climits>
+#include <cstdlib>
 
 #include "schwz_internal.hpp"
 
@@ -35,6 +37,16 @@ __device__ __forceinline__ double block_sum(double v, double *red)
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a
+// workgroup-scope release/acquire fence over ALL address spaces, i.e. an
+// s_waitcnt vmcnt(0): every global load or store still in flight (the prefetched
+// matrix entries of the next tile, the y stores of the previous one) would have
+// to land before the barrier.  The tiles only hand LDS data between waves.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Every workgroup folds the per-workgroup partial sums of the previous launch
 // itself (fixed order): no extra launch and no atomics on the critical path.
 __device__ __forceinline__ double fold_partials(const double *part, int count, double *red)
@@ -52,6 +64,27 @@ __device__ __forceinline__ double fold_partials(const double *part, int count, d
 // matrix: the x entries a tile shares with its neighbours (i+-1, i+-nx, i+-nx*ny
 // for the Poisson stencils) stay in that XCD's 4 MiB L2.
 // ---------------------------------------------------------------------------
+
+// Tile dealt to XCD `xcd` as its j-th one.  Tiles go to the eight XCDs in runs of
+// A.xcd_block (block-cyclic): with the run length set to 1/8 of the matrix
+// bandwidth (in tiles) every XCD sweeps one strip of each grid plane, plane after
+// plane, so the x lines a tile shares with its +-nx*ny neighbours are reused after
+// ~xcd_block tiles instead of after a whole plane of matrix stream (which is
+// larger than the 4 MiB L2 and used to evict them: 3.5 HBM fetches per x line).
+// Returns -1 past the end.
+__device__ __forceinline__ int xcd_tile(const CsrView &A, int xcd, int j)
+{
+    const int B = A.xcd_block;
+    const int tile = (j / B) * (kXcds * B) + xcd * B + (j % B);
+    return tile < A.ntiles ? tile : -1;
+}
+
+// number of sequence slots per XCD
+__device__ __forceinline__ int xcd_slots(const CsrView &A)
+{
+    const int B = A.xcd_block;
+    return ((A.ntiles + kXcds * B - 1) / (kXcds * B)) * B;
+}
 
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void spmv_tiled_kernel(CsrView A, SpmvArgs a)
@@ -155,14 +188,15 @@ __global__ __launch_bounds__(kBlock) void spmv_tiled2_kernel(CsrView A, SpmvArgs
     const int xcd = blockIdx.x % kXcds;
     const int slot = blockIdx.x / kXcds;
     const int per_xcd = gridDim.x / kXcds;
-    const int chunk = (A.ntiles + kXcds - 1) / kXcds;
+    const int chunk = xcd_slots(A);
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
     const bool dual = (MODE == kSpmvResidDual) && a.x2 != nullptr;
 
     for (int t = slot; t < chunk; t += per_xcd) {
-        const int tile = xcd * chunk + t;
-        if (tile >= A.ntiles) break;
-        const int r0 = A.tile_row[tile], r1 = A.tile_row[tile + 1];
+        const int tile = xcd_tile(A, xcd, t);
+        if (tile < 0) continue;
+        const int tl = A.tile_order ? A.tile_order[tile] : tile;
+        const int r0 = A.tile_row[tl], r1 = A.tile_row[tl + 1];
         const int s = A.rp[r0], e = A.rp[r1];
         const int cnt = e - s;
         double sum = 0.0, sum2 = 0.0;
@@ -176,66 +210,70 @@ __global__ __launch_bounds__(kBlock) void spmv_tiled2_kernel(CsrView A, SpmvArgs
                 b0 = A.rp[row] - s2;
                 b1 = A.rp[row + 1] - s2;
             }
+            // no per-pair bounds branch: lanes past the tile re-read its last pair
+            // (their products land in LDS slots no row sums)
+            const int last = max((e - 1) & ~1, s2);
             double2 v[kPairsPerLane];
             int2 c[kPairsPerLane];
 #pragma unroll
             for (int k = 0; k < kPairsPerLane; ++k) {
-                const int idx = s2 + 2 * (tid + kBlock * k);
-                if (idx < e) {
-                    v[k] = *reinterpret_cast<const double2 *>(A.val + idx);
-                    c[k] = *reinterpret_cast<const int2 *>(A.col + idx);
-                }
+                const int idx = min(s2 + 2 * (tid + kBlock * k), last);
+                v[k] = *reinterpret_cast<const double2 *>(A.val + idx);
+                c[k] = *reinterpret_cast<const int2 *>(A.col + idx);
+            }
+            double xg[2 * kPairsPerLane];
+#pragma unroll
+            for (int k = 0; k < kPairsPerLane; ++k) {
+                xg[2 * k] = a.x[c[k].x];
+                xg[2 * k + 1] = a.x[c[k].y];
             }
 #pragma unroll
             for (int k = 0; k < kPairsPerLane; ++k) {
-                const int idx = s2 + 2 * (tid + kBlock * k);
-                if (idx < e) {
-                    const double x0 = a.x[c[k].x];
-                    const double x1 = a.x[c[k].y];
-                    double2 pr;
-                    pr.x = v[k].x * x0;
-                    pr.y = v[k].y * x1;
-                    *reinterpret_cast<double2 *>(&prod[2 * (tid + kBlock * k)]) = pr;
-                }
+                double2 pr;
+                pr.x = v[k].x * xg[2 * k];
+                pr.y = v[k].y * xg[2 * k + 1];
+                *reinterpret_cast<double2 *>(&prod[2 * (tid + kBlock * k)]) = pr;
             }
-            __syncthreads();
+            lds_barrier();
             if (row < r1) {
                 have_row = true;
                 for (int j = b0; j < b1; ++j) sum += prod[j];
             }
-            __syncthreads();
+            lds_barrier();
             if (dual) {
                 // second vector, same matrix entries (still in registers)
 #pragma unroll
                 for (int k = 0; k < kPairsPerLane; ++k) {
-                    const int idx = s2 + 2 * (tid + kBlock * k);
-                    if (idx < e) {
-                        double2 pr;
-                        pr.x = v[k].x * a.x2[c[k].x];
-                        pr.y = v[k].y * a.x2[c[k].y];
-                        *reinterpret_cast<double2 *>(&prod[2 * (tid + kBlock * k)]) = pr;
-                    }
+                    xg[2 * k] = a.x2[c[k].x];
+                    xg[2 * k + 1] = a.x2[c[k].y];
                 }
-                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < kPairsPerLane; ++k) {
+                    double2 pr;
+                    pr.x = v[k].x * xg[2 * k];
+                    pr.y = v[k].y * xg[2 * k + 1];
+                    *reinterpret_cast<double2 *>(&prod[2 * (tid + kBlock * k)]) = pr;
+                }
+                lds_barrier();
                 if (row < r1)
                     for (int j = b0; j < b1; ++j) sum2 += prod[j];
-                __syncthreads();
+                lds_barrier();
             }
         } else if (r1 - r0 > 1) {
             // tile that fits kTileNnz but not the aligned window: plain staging
             for (int i = tid; i < cnt; i += kBlock) prod[i] = A.val[s + i] * a.x[A.col[s + i]];
-            __syncthreads();
+            lds_barrier();
             const int b0 = row < r1 ? A.rp[row] - s : 0, b1 = row < r1 ? A.rp[row + 1] - s : 0;
             if (row < r1) {
                 have_row = true;
                 for (int j = b0; j < b1; ++j) sum += prod[j];
             }
-            __syncthreads();
+            lds_barrier();
             if (dual) {
                 for (int i = tid; i < cnt; i += kBlock) prod[i] = A.val[s + i] * a.x2[A.col[s + i]];
-                __syncthreads();
+                lds_barrier();
                 for (int j = b0; j < b1; ++j) sum2 += prod[j];
-                __syncthreads();
+                lds_barrier();
             }
         } else {
             // a single long row: the whole workgroup reduces it
@@ -293,6 +331,308 @@ __global__ __launch_bounds__(kBlock) void spmv_tiled2_kernel(CsrView A, SpmvArgs
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Software-pipelined tiled SpMV (variant 4; measured no faster than variant 0).  Same tiles and arithmetic
+// as spmv_tiled2_kernel, but a workgroup's tile loop is a two-stage pipeline:
+// as soon as the products of tile t are in LDS, the 16-byte loads of tile t+1 are
+// issued into the SAME registers, so they fly during the barrier / row-sum / store
+// phase of tile t; the tile descriptors (row range, nonzero range) are fetched one
+// tile ahead as well.  Each workgroup thus always has ~24 KiB of matrix stream in
+// flight instead of stalling through a load -> gather -> LDS -> barrier chain.
+// ---------------------------------------------------------------------------
+
+struct TileDesc {
+    int r0, r1, s, e;
+    bool valid, regular;
+};
+
+__device__ __forceinline__ TileDesc tile_desc(const CsrView &A, int xcd, int chunk, int t)
+{
+    TileDesc d;
+    d.r0 = d.r1 = d.s = d.e = 0;
+    d.regular = false;
+    const int tile = t < chunk ? xcd_tile(A, xcd, t) : -1;
+    d.valid = tile >= 0;
+    if (d.valid) {
+        const int tl = A.tile_order ? A.tile_order[tile] : tile;
+        d.r0 = A.tile_row[tl];
+        d.r1 = A.tile_row[tl + 1];
+        d.s = A.rp[d.r0];
+        d.e = A.rp[d.r1];
+        d.regular = (d.e - d.s) <= kTileNnz - 2;
+    }
+    return d;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void spmv_pipe_kernel(CsrView A, SpmvArgs a)
+{
+    __shared__ double prod[kTileNnz + 2];
+    __shared__ double red[4];
+    if (MODE == kSpmvDot || MODE == kSpmvResidInit) {
+        if (a.stop_iter && a.it >= *a.stop_iter) return;
+    }
+    const int tid = threadIdx.x;
+    const int xcd = blockIdx.x % kXcds;
+    const int slot = blockIdx.x / kXcds;
+    const int per_xcd = gridDim.x / kXcds;
+    const int chunk = xcd_slots(A);
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+    const bool dual = (MODE == kSpmvResidDual) && a.x2 != nullptr;
+
+    double2 v[kPairsPerLane];
+    int2 c[kPairsPerLane];
+    // No per-pair bounds branch: a lane whose pair lies past the tile re-reads the
+    // tile's last pair instead (its product lands in an LDS slot no row sums), so
+    // all loads of a phase issue back to back and one wait covers them.
+#define SCHWZ_ISSUE_LOADS(D)                                                     \
+    {                                                                            \
+        const int s2_ = (D).s & ~1;                                              \
+        const int last_ = max(((D).e - 1) & ~1, s2_);                            \
+        _Pragma("unroll") for (int k = 0; k < kPairsPerLane; ++k)                \
+        {                                                                        \
+            const int idx = min(s2_ + 2 * (tid + kBlock * k), last_);            \
+            v[k] = *reinterpret_cast<const double2 *>(A.val + idx);              \
+            c[k] = *reinterpret_cast<const int2 *>(A.col + idx);                 \
+        }                                                                        \
+    }
+#define SCHWZ_PRODUCTS(XV, D)                                                    \
+    {                                                                            \
+        double xg[2 * kPairsPerLane];                                            \
+        _Pragma("unroll") for (int k = 0; k < kPairsPerLane; ++k)                \
+        {                                                                        \
+            xg[2 * k] = (XV)[c[k].x];                                            \
+            xg[2 * k + 1] = (XV)[c[k].y];                                        \
+        }                                                                        \
+        _Pragma("unroll") for (int k = 0; k < kPairsPerLane; ++k)                \
+        {                                                                        \
+            double2 pr;                                                          \
+            pr.x = v[k].x * xg[2 * k];                                           \
+            pr.y = v[k].y * xg[2 * k + 1];                                       \
+            *reinterpret_cast<double2 *>(&prod[2 * (tid + kBlock * k)]) = pr;    \
+        }                                                                        \
+    }
+
+    // past-the-end slots only occur in the last run of the block-cyclic deal
+    int t = slot;
+    while (t < chunk && xcd_tile(A, xcd, t) < 0) t += per_xcd;
+    TileDesc cur = tile_desc(A, xcd, chunk, t);
+    if (cur.valid && cur.regular) SCHWZ_ISSUE_LOADS(cur)
+    while (cur.valid) {
+        t += per_xcd;
+        while (t < chunk && xcd_tile(A, xcd, t) < 0) t += per_xcd;
+        const TileDesc nxt = tile_desc(A, xcd, chunk, t);
+        const int r0 = cur.r0, r1 = cur.r1, s = cur.s, e = cur.e;
+        const int cnt = e - s;
+        double sum = 0.0, sum2 = 0.0;
+        int row = r0 + tid;
+        bool have_row = false;
+        if (cur.regular) {
+            const int s2 = s & ~1;
+            int b0 = 0, b1 = 0;
+            if (row < r1) {
+                b0 = A.rp[row] - s2;
+                b1 = A.rp[row + 1] - s2;
+            }
+            SCHWZ_PRODUCTS(a.x, cur)
+            if (!dual && nxt.valid && nxt.regular) SCHWZ_ISSUE_LOADS(nxt)
+            lds_barrier();
+            if (row < r1) {
+                have_row = true;
+                for (int j = b0; j < b1; ++j) sum += prod[j];
+            }
+            lds_barrier();
+            if (dual) {
+                SCHWZ_PRODUCTS(a.x2, cur)
+                if (nxt.valid && nxt.regular) SCHWZ_ISSUE_LOADS(nxt)
+                lds_barrier();
+                if (row < r1)
+                    for (int j = b0; j < b1; ++j) sum2 += prod[j];
+                lds_barrier();
+            }
+        } else {
+            if (r1 - r0 > 1) {
+                // fits kTileNnz but not the aligned window: plain staging
+                for (int i = tid; i < cnt; i += kBlock) prod[i] = A.val[s + i] * a.x[A.col[s + i]];
+                lds_barrier();
+                const int b0 = row < r1 ? A.rp[row] - s : 0, b1 = row < r1 ? A.rp[row + 1] - s : 0;
+                if (row < r1) {
+                    have_row = true;
+                    for (int j = b0; j < b1; ++j) sum += prod[j];
+                }
+                lds_barrier();
+                if (dual) {
+                    for (int i = tid; i < cnt; i += kBlock) prod[i] = A.val[s + i] * a.x2[A.col[s + i]];
+                    lds_barrier();
+                    for (int j = b0; j < b1; ++j) sum2 += prod[j];
+                    lds_barrier();
+                }
+            } else {
+                // a single long row: the whole workgroup reduces it
+                double part = 0.0, part2 = 0.0;
+                for (int i = tid; i < cnt; i += kBlock) {
+                    part += A.val[s + i] * a.x[A.col[s + i]];
+                    if (dual) part2 += A.val[s + i] * a.x2[A.col[s + i]];
+                }
+                part = block_sum(part, red);
+                if (dual) part2 = block_sum(part2, red);
+                row = r0;
+                if (tid == 0) {
+                    have_row = true;
+                    sum = part;
+                    sum2 = part2;
+                }
+            }
+            if (nxt.valid && nxt.regular) SCHWZ_ISSUE_LOADS(nxt)
+        }
+        if (have_row) {
+            if (MODE == kSpmvPlain) {
+                a.y[row] = (a.beta == 0.0) ? a.alpha * sum : a.alpha * sum + a.beta * a.y[row];
+            } else if (MODE == kSpmvDot) {
+                a.y[row] = sum;
+                acc0 += a.x[row] * sum;
+            } else if (MODE == kSpmvResidInit || MODE == kSpmvResidDual) {
+                const double bb = a.b[row];
+                const double r = bb - sum;
+                const double z = a.dinv ? a.dinv[row] * r : r;
+                a.y[row] = r;
+                a.p[row] = z;
+                acc0 += r * z;
+                acc1 += r * r;
+                if (MODE == kSpmvResidDual && row < a.row_limit) {
+                    const double r2 = dual ? bb - sum2 : r;
+                    acc2 += r2 * r2;
+                }
+            } else {  // kSpmvResidNorm
+                if (row < a.row_limit) {
+                    const double r = a.b[row] - sum;
+                    acc1 += r * r;
+                }
+            }
+        }
+        cur = nxt;
+    }
+#undef SCHWZ_ISSUE_LOADS
+#undef SCHWZ_PRODUCTS
+    if (MODE != kSpmvPlain) {
+        const double s0 = block_sum(acc0, red);
+        const double s1 = block_sum(acc1, red);
+        if (tid == 0) {
+            a.partials[blockIdx.x] = s0;
+            a.partials[gridDim.x + blockIdx.x] = s1;
+        }
+        if (MODE == kSpmvResidDual) {
+            const double s2v = block_sum(acc2, red);
+            if (tid == 0) a.partials[2 * gridDim.x + blockIdx.x] = s2v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Ablation build of the tiled kernel (plain mode only, WRONG results on purpose):
+// used by tools/spmv_probe.py --variants 10.. to price the pieces of a tile.
+//   bit 0: no x gather (x := 1)      bit 1: no LDS staging / barriers / row sums
+//   bit 2: no y store                bit 3: no column-index stream
+// ---------------------------------------------------------------------------
+template <int WHAT>
+__global__ __launch_bounds__(kBlock) void spmv_ablate_kernel(CsrView A, SpmvArgs a)
+{
+    __shared__ double prod[kTileNnz + 2];
+    const int tid = threadIdx.x;
+    const int xcd = blockIdx.x % kXcds;
+    const int slot = blockIdx.x / kXcds;
+    const int per_xcd = gridDim.x / kXcds;
+    const int chunk = xcd_slots(A);
+    double keep = 0.0;
+    for (int t = slot; t < chunk; t += per_xcd) {
+        const int tile = xcd_tile(A, xcd, t);
+        if (tile < 0) continue;
+        const int r0 = A.tile_row[tile], r1 = A.tile_row[tile + 1];
+        const int s = A.rp[r0], e = A.rp[r1];
+        if (e - s > kTileNnz - 2) continue;
+        const int row = r0 + tid;
+        const int s2 = (WHAT & 32) ? s : (s & ~1);
+        int b0 = 0, b1 = 0;
+        if (row < r1) {
+            b0 = A.rp[row] - s2;
+            b1 = A.rp[row + 1] - s2;
+        }
+        double sum = 0.0;
+        if (WHAT & 32) {
+            // consecutive lanes take consecutive entries (8-byte / 4-byte loads)
+            const int last = max(e - 1, s);
+            double v[2 * kPairsPerLane];
+            int c[2 * kPairsPerLane];
+#pragma unroll
+            for (int k = 0; k < 2 * kPairsPerLane; ++k) {
+                const int idx = min(s + tid + kBlock * k, last);
+                v[k] = A.val[idx];
+                c[k] = A.col[idx];
+            }
+            double xg[2 * kPairsPerLane];
+#pragma unroll
+            for (int k = 0; k < 2 * kPairsPerLane; ++k) xg[k] = a.x[c[k]];
+#pragma unroll
+            for (int k = 0; k < 2 * kPairsPerLane; ++k) prod[tid + kBlock * k] = v[k] * xg[k];
+            lds_barrier();
+            if (row < r1)
+                for (int j = b0; j < b1; ++j) sum += prod[j];
+            lds_barrier();
+        } else {
+            const int last = max((e - 1) & ~1, s2);
+            double2 v[kPairsPerLane];
+            int2 c[kPairsPerLane];
+#pragma unroll
+            for (int k = 0; k < kPairsPerLane; ++k) {
+                const int idx = min(s2 + 2 * (tid + kBlock * k), last);
+                v[k] = *reinterpret_cast<const double2 *>(A.val + idx);
+                if (WHAT & 8) {
+                    c[k].x = idx & 1023;
+                    c[k].y = (idx + 1) & 1023;
+                } else {
+                    c[k] = *reinterpret_cast<const int2 *>(A.col + idx);
+                }
+            }
+            double xg[2 * kPairsPerLane];
+#pragma unroll
+            for (int k = 0; k < kPairsPerLane; ++k) {
+                if (WHAT & 1) {
+                    xg[2 * k] = 1.0 + c[k].x;
+                    xg[2 * k + 1] = 1.0 + c[k].y;
+                } else {
+                    xg[2 * k] = a.x[c[k].x];
+                    xg[2 * k + 1] = a.x[c[k].y];
+                }
+            }
+            if (WHAT & 2) {
+#pragma unroll
+                for (int k = 0; k < kPairsPerLane; ++k) sum += v[k].x * xg[2 * k] + v[k].y * xg[2 * k + 1];
+                sum += b0 + b1;
+            } else {
+#pragma unroll
+                for (int k = 0; k < kPairsPerLane; ++k) {
+                    double2 pr;
+                    pr.x = v[k].x * xg[2 * k];
+                    pr.y = v[k].y * xg[2 * k + 1];
+                    *reinterpret_cast<double2 *>(&prod[2 * (tid + kBlock * k)]) = pr;
+                }
+                lds_barrier();
+                if (row < r1)
+                    for (int j = b0; j < b1; ++j) sum += prod[j];
+                lds_barrier();
+            }
+        }
+        if (WHAT & 4) {
+            keep += sum;
+        } else if (WHAT & 16) {
+            if (row < r1) __builtin_nontemporal_store(sum, &a.y[row]);
+        } else if (row < r1) {
+            a.y[row] = sum;
+        }
+    }
+    if ((WHAT & 4) && keep == 123.456) a.y[0] = keep;
+}
 
 // ---------------------------------------------------------------------------
 // Wave-tiled SpMV: the same idea with a WAVE as the unit of work.  Each 64-lane
@@ -449,8 +789,8 @@ int spmv_grid(const CsrView &A, int variant)
 int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipStream_t s)
 {
     if (A.nrows == 0) return SCHWZ_OK;
-    if (mode == kSpmvResidDual && variant != 0) {
-        set_error("launch_spmv: the fused dual-residual mode exists for variant 0 only");
+    if (mode == kSpmvResidDual && variant != 0 && variant != 4) {
+        set_error("launch_spmv: the fused dual-residual mode exists for variants 0 and 4 only");
         return SCHWZ_ERR_INVALID;
     }
     const int grid = spmv_grid(A, variant);
@@ -469,7 +809,16 @@ int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipS
         hipLaunchKernelGGL((spmv_wave_kernel<kSpmvResidNorm, NTV>), dim3(wgrid), dim3(kBlock), 0, s, A, a); \
         break;                                                                                         \
     }
-    if (variant == 3 || variant == 5) {
+    if (variant >= 10 && variant < 74 && mode == kSpmvPlain) {
+        switch (variant - 10) {
+#define SCHWZ_ABL(W) \
+    case W: hipLaunchKernelGGL(spmv_ablate_kernel<W>, dim3(grid), dim3(kBlock), 0, s, A, a); break;
+            SCHWZ_ABL(0) SCHWZ_ABL(1) SCHWZ_ABL(2) SCHWZ_ABL(3) SCHWZ_ABL(4) SCHWZ_ABL(5) SCHWZ_ABL(6) SCHWZ_ABL(7)
+            SCHWZ_ABL(8) SCHWZ_ABL(9) SCHWZ_ABL(10) SCHWZ_ABL(11) SCHWZ_ABL(12) SCHWZ_ABL(13) SCHWZ_ABL(14) SCHWZ_ABL(15)
+            SCHWZ_ABL(16) SCHWZ_ABL(32) SCHWZ_ABL(48) SCHWZ_ABL(36)
+#undef SCHWZ_ABL
+        }
+    } else if (variant == 3 || variant == 5) {
         const int wgrid = spmv_grid(A, variant);
         if (variant == 3) {
             SCHWZ_LAUNCH_WAVE(false)
@@ -478,6 +827,24 @@ int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipS
         }
     } else if (variant == 1 && mode == kSpmvPlain) {
         hipLaunchKernelGGL(spmv_rowlane_kernel, dim3(kMaxGrid), dim3(kBlock), 0, s, A, a);
+    } else if (variant == 4) {
+        switch (mode) {
+        case kSpmvPlain:
+            hipLaunchKernelGGL(spmv_pipe_kernel<kSpmvPlain>, dim3(grid), dim3(kBlock), 0, s, A, a);
+            break;
+        case kSpmvDot:
+            hipLaunchKernelGGL(spmv_pipe_kernel<kSpmvDot>, dim3(grid), dim3(kBlock), 0, s, A, a);
+            break;
+        case kSpmvResidInit:
+            hipLaunchKernelGGL(spmv_pipe_kernel<kSpmvResidInit>, dim3(grid), dim3(kBlock), 0, s, A, a);
+            break;
+        case kSpmvResidDual:
+            hipLaunchKernelGGL(spmv_pipe_kernel<kSpmvResidDual>, dim3(grid), dim3(kBlock), 0, s, A, a);
+            break;
+        default:
+            hipLaunchKernelGGL(spmv_pipe_kernel<kSpmvResidNorm>, dim3(grid), dim3(kBlock), 0, s, A, a);
+            break;
+        }
     } else if (variant != 2) {
         switch (mode) {
         case kSpmvPlain:
@@ -908,6 +1275,53 @@ int schwz_csr_create(int64_t nrows, int64_t ncols, const schwz_idx *h_rp, const 
         tiles.push_back((schwz_idx)e);
         r = e;
     }
+    // Visiting order of the tiles.  Every XCD sweeps one contiguous eighth of the
+    // tile list with all its resident workgroups side by side, so a tile's x
+    // entries are shared with the tiles that run at about the same time only if
+    // "adjacent in the sweep" means "adjacent in the matrix graph".  In the natural
+    // order of a 3-D grid the +-nx*ny neighbours are a whole plane of tiles away
+    // and their x lines are evicted from the 4 MiB L2 by the matrix stream before
+    // they are reused (rocprofv3: FETCH_SIZE 13 % above the algorithmic bytes).  A
+    // breadth-first order of the tile graph inside each eighth shortens that
+    // distance to one BFS level; matrices whose natural order is already local
+    // (small bandwidth) are left almost unchanged.  SCHWZ_TILE_ORDER=0 disables it, =2 forces it for small matrices too.
+    std::vector<schwz_idx> order;
+    const char *ord_env = std::getenv("SCHWZ_TILE_ORDER");
+    const int ntl = (int)tiles.size() - 1;
+    const bool ord_force = ord_env && ord_env[0] == '2';  // also for small matrices (tests)
+    const bool ord_on = ord_env && (ord_env[0] == '1' || ord_force);  // measured slower than the
+    // block-cyclic deal below on the 3-D Poisson matrices, hence off by default
+    if (ord_on && (ntl >= 4 * kMaxGrid || (ord_force && ntl > 1)) && nrows == ncols) {
+        std::vector<schwz_idx> tile_of((size_t)nrows);
+        for (int t = 0; t < ntl; ++t)
+            for (schwz_idx rr = tiles[t]; rr < tiles[t + 1]; ++rr) tile_of[(size_t)rr] = t;
+        const int chunk = (ntl + kXcds - 1) / kXcds;
+        order.reserve((size_t)ntl);
+        std::vector<char> seen((size_t)ntl, 0);
+        std::vector<schwz_idx> nb;
+        for (int x = 0; x < kXcds; ++x) {
+            const int lo = x * chunk, hi = std::min(ntl, lo + chunk);
+            size_t head = order.size();
+            for (int start = lo; start < hi; ++start) {
+                if (seen[(size_t)start]) continue;
+                seen[(size_t)start] = 1;
+                order.push_back(start);
+                while (head < order.size()) {
+                    const int t = order[head++];
+                    nb.clear();
+                    for (int64_t j = h_rp[tiles[t]]; j < h_rp[tiles[t + 1]]; ++j) {
+                        const int u = tile_of[(size_t)h_col[j]];
+                        if (u >= lo && u < hi && !seen[(size_t)u]) {
+                            seen[(size_t)u] = 1;
+                            nb.push_back(u);
+                        }
+                    }
+                    std::sort(nb.begin(), nb.end());
+                    order.insert(order.end(), nb.begin(), nb.end());
+                }
+            }
+        }
+    }
     std::vector<schwz_idx> wtiles;
     wtiles.reserve((size_t)(nrows / 32 + 2));
     wtiles.push_back(0);
@@ -930,7 +1344,8 @@ int schwz_csr_create(int64_t nrows, int64_t ncols, const schwz_idx *h_rp, const 
     int rc;
     if ((rc = upload(h_rp, (size_t)nrows + 1, &A->d_rp)) || (rc = upload(h_col, (size_t)nnz, &A->d_col, 2)) ||
         (rc = upload(h_val, (size_t)nnz, &A->d_val, 2)) || (rc = upload(tiles.data(), tiles.size(), &A->d_tile)) ||
-        (rc = upload(wtiles.data(), wtiles.size(), &A->d_wtile))) {
+        (rc = upload(wtiles.data(), wtiles.size(), &A->d_wtile)) ||
+        (!order.empty() && (rc = upload(order.data(), order.size(), &A->d_order)))) {
         schwz_csr_destroy(A);
         return rc;
     }
@@ -942,6 +1357,29 @@ int schwz_csr_create(int64_t nrows, int64_t ncols, const schwz_idx *h_rp, const 
     A->v.val = (const double *)A->d_val;
     A->v.ntiles = (int)tiles.size() - 1;
     A->v.tile_row = (const schwz_idx *)A->d_tile;
+    A->v.tile_order = order.empty() ? nullptr : (const schwz_idx *)A->d_order;
+    {
+        // run length of the block-cyclic deal: 1/8 of the matrix bandwidth in tiles
+        // (SCHWZ_XCD_BLOCK overrides; >= tiles/8 reproduces one contiguous eighth per XCD)
+        // median over sampled rows: robust against the few rows of a subdomain matrix
+        // whose overlap columns sit at the far end of the local numbering
+        std::vector<int64_t> bws;
+        const int64_t step = nrows > 4096 ? nrows / 4096 : 1;
+        for (int64_t i = 0; i < nrows; i += step)
+            if (h_rp[i + 1] > h_rp[i])
+                bws.push_back(std::max<int64_t>(i - h_col[h_rp[i]], h_col[h_rp[i + 1] - 1] - i));
+        int64_t bw = 0;
+        if (!bws.empty()) {
+            std::nth_element(bws.begin(), bws.begin() + bws.size() / 2, bws.end());
+            bw = std::max<int64_t>(0, bws[bws.size() / 2]);
+        }
+        const int64_t rows_per_tile = std::max<int64_t>(1, nrows / std::max(1, ntl));
+        int64_t B = bw / rows_per_tile / kXcds;
+        const char *be = std::getenv("SCHWZ_XCD_BLOCK");
+        if (be && std::atoi(be) > 0) B = std::atoi(be);
+        const int64_t cap = (ntl + kXcds - 1) / kXcds;
+        A->v.xcd_block = (int)std::max<int64_t>(1, std::min<int64_t>(B, cap));
+    }
     A->v.nwtiles = (int)wtiles.size() - 1;
     A->v.wtile_row = (const schwz_idx *)A->d_wtile;
     *out = A;
@@ -956,6 +1394,7 @@ void schwz_csr_destroy(schwz_csr *A)
     (void)hipFree(A->d_val);
     (void)hipFree(A->d_tile);
     (void)hipFree(A->d_wtile);
+    (void)hipFree(A->d_order);
     delete A;
 }
 

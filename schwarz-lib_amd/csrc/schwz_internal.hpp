@@ -49,6 +49,8 @@ struct CsrView {
     const double *val = nullptr;
     int ntiles = 0;
     const schwz_idx *tile_row = nullptr;  // ntiles+1 row boundaries
+    const schwz_idx *tile_order = nullptr;  // optional BFS visiting order (SCHWZ_TILE_ORDER=1)
+    int xcd_block = 0;  // tiles are dealt to the 8 XCDs block-cyclically in runs of this many
     int nwtiles = 0;                        // wave tiles: <= 64 rows, <= kWaveTileNnz-2 nnz
     const schwz_idx *wtile_row = nullptr;
 };
@@ -104,7 +106,7 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
 
 struct schwz_csr {
     schwz::CsrView v;
-    void *d_rp = nullptr, *d_col = nullptr, *d_val = nullptr, *d_tile = nullptr, *d_wtile = nullptr;
+    void *d_rp = nullptr, *d_col = nullptr, *d_val = nullptr, *d_tile = nullptr, *d_wtile = nullptr, *d_order = nullptr;
 };
 
 struct schwz_pcg {

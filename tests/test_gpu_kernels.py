@@ -57,7 +57,7 @@ def _ragged_matrix(rng, n, max_len, long_row=None):
     return rp, col, val
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("case", ["lap2d", "lap3d", "ragged", "longrow", "tiny"])
 def test_spmv_matches_oracle(schwz, oracle, torch_cuda, case, variant):
     torch = torch_cuda
@@ -184,3 +184,28 @@ def test_direct_solve_matches_oracle(schwz, oracle, torch_cuda, case, natural):
     torch.cuda.synchronize()
     got = d_y.cpu().numpy()
     assert np.abs(got - exp).max() <= 1e-10 * np.abs(exp).max()
+
+
+@pytest.mark.parametrize("case", ["lap3d", "ragged"])
+def test_spmv_with_forced_tile_order(schwz, oracle, torch_cuda, case, monkeypatch):
+    """The BFS visiting order of the row tiles (a locality permutation of the launch schedule,
+    not of the data) must not change a single bit of the result."""
+    torch = torch_cuda
+    rng = np.random.default_rng(11)
+    if case == "lap3d":
+        rp, col, val = oracle.laplacian3d(31, 29, 23)
+    else:
+        rp, col, val = _ragged_matrix(rng, 20000, 24, long_row=3000)
+    n = len(rp) - 1
+    x = _dev(torch, rng.standard_normal(n))
+    ys = []
+    for mode in ("0", "2"):
+        monkeypatch.setenv("SCHWZ_TILE_ORDER", mode)
+        A = schwz.Csr(rp, col, val)
+        y = torch.zeros(n, dtype=torch.float64, device="cuda")
+        A.spmv(x.data_ptr(), y.data_ptr())
+        torch.cuda.synchronize()
+        ys.append(y.cpu().numpy())
+    assert np.array_equal(ys[0], ys[1])
+    exp = oracle.spmv(rp, col, val, x.cpu().numpy())
+    assert np.abs(ys[1] - exp).max() <= 1e-12 * max(np.abs(exp).max(), 1.0)
