@@ -38,7 +38,8 @@ def parse():
     ap.add_argument("--spmv-variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ttr", action="store_true", help="skip the time-to-residual run")
-    ap.add_argument("--cpu-iters", type=int, default=3, help="outer iterations of the CPU sample")
+    ap.add_argument("--cpu-iters", type=int, default=30,
+                    help="outer iterations of the CPU sample (about 10-30 s of CPU work)")
     return ap.parse_args()
 
 

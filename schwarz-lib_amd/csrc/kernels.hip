@@ -889,13 +889,13 @@ int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipS
 // ---------------------------------------------------------------------------
 
 __global__ void cg_init_finalize_kernel(CgState *st, const double *partials, int nparts, double rtol,
-                                        double *norm_sq_out)
+                                        double *norm_sq_out, int norm_bank)
 {
     __shared__ double red[4];
     const double rho = fold_partials(partials, nparts, red);
     const double rr = fold_partials(partials + nparts, nparts, red);
     if (norm_sq_out) {
-        const double n2 = fold_partials(partials + 2 * nparts, nparts, red);
+        const double n2 = fold_partials(partials + norm_bank * nparts, nparts, red);
         if (threadIdx.x == 0) {
             norm_sq_out[0] = n2;  // may be mapped host memory
             __threadfence_system();
@@ -1542,10 +1542,12 @@ int pcg_begin(schwz_pcg *s, const double *d_b, double *d_x, double rtol, bool fu
     a.dinv = s->dinv;
     a.partials = s->partials;
     a.row_limit = row_limit;
-    int rc = launch_spmv(A, fused ? kSpmvResidDual : kSpmvResidInit, a, s->variant, st);
+    // x2 == x over all rows: the check residual IS the start residual (rr bank)
+    const bool same = fused && d_x2 == nullptr && row_limit >= s->n;
+    int rc = launch_spmv(A, (fused && !same) ? kSpmvResidDual : kSpmvResidInit, a, s->variant, st);
     if (rc) return rc;
     hipLaunchKernelGGL(cg_init_finalize_kernel, dim3(1), dim3(kBlock), 0, st, s->state, s->partials, gs, rtol,
-                       fused ? s->d_norm_sq : nullptr);
+                       fused ? s->d_norm_sq : nullptr, same ? 1 : 2);
     SCHWZ_HIP_TRY(hipGetLastError());
     return SCHWZ_OK;
 }

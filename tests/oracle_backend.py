@@ -1,0 +1,158 @@
+"""TEST-ONLY backend for schwz_amd.SolverRAS: the per-subdomain steps are executed by the
+CPU oracle on host memory.  It exists so that the multi-process host path (index handshake,
+halo exchange order, global convergence rule, solution gather over torch.distributed) can be
+exercised with the gloo backend on a machine without GPUs.  Never imported by the product."""
+import ctypes
+
+import numpy as np
+import torch
+
+import oracle as O
+
+
+def _view(ptr, n):
+    if n == 0:
+        return np.zeros(0)
+    return np.ctypeslib.as_array((ctypes.c_double * n).from_address(int(ptr)))
+
+
+class OracleProblem:
+    def __init__(self, rp, col, val):
+        self.rp, self.col, self.val = rp, col, val
+        self.N = len(rp) - 1
+        self.nnz = int(rp[-1])
+
+    def permute(self, part, P):
+        perm, iperm, fr, rp, col, val = O.apply_partition(self.rp, self.col, self.val, part, P)
+        return OracleProblem(rp, col, val), perm.astype(np.int64), fr.astype(np.int64)
+
+    def to_csr(self):
+        return self.rp, self.col, self.val
+
+
+class OracleSubdomain:
+    def __init__(self, problem, P, me, overlap, first_row):
+        self.problem = problem
+        self.overlap = overlap
+        self.sd = O.Subdomain(problem.rp, problem.col, problem.val, P, me, overlap,
+                              np.asarray(first_row, dtype=np.int32))
+        self.state = None
+        self._refresh()
+
+    def _refresh(self):
+        for k in ("local_size", "local_size_x", "overlap_size", "halo_size", "nnz_local",
+                  "nnz_interface", "num_neighbors_in", "num_neighbors_out", "num_recv", "num_send"):
+            setattr(self, k, getattr(self.sd, k))
+
+    @property
+    def local_to_global(self):
+        return self.sd.local_to_global.astype(np.int64)
+
+    def get_lists(self):
+        return [(r, ids.astype(np.int64)) for r, ids in self.sd.get_lists()]
+
+    def put_lists(self):
+        return [(r, ids.astype(np.int64)) for r, ids in self.sd.put_lists()]
+
+    def add_put_list(self, p, ids):
+        self.sd.add_put_list(p, np.asarray(ids, dtype=np.int32))
+        self._refresh()
+
+    def _offsets(self, lists):
+        off = [0]
+        for _, ids in lists:
+            off.append(off[-1] + len(ids))
+        return off
+
+    def send_offsets(self):
+        return self._offsets(self.sd.put_lists())
+
+    def recv_offsets(self):
+        return self._offsets(self.sd.get_lists())
+
+    def local_rhs(self, rhs_fn):
+        return np.ascontiguousarray(rhs_fn(self.local_to_global[:self.local_size_x]))
+
+    def to_device(self, local_rhs, local_solver=0, precond=0, local_tol=1e-12, local_max_iters=-1,
+                  natural_factor_ordering=False, spmv_variant=0):
+        # the oracle state extracts the local rhs from a global vector; rhs is all ones
+        assert np.all(np.asarray(local_rhs) == 1.0)
+        s = O.make_settings(overlap=self.overlap, local_solver=local_solver, precond=precond,
+                            local_tol=local_tol, local_max_iters=local_max_iters,
+                            natural_factor_ordering=int(natural_factor_ordering))
+        self._settings = s
+        self.state = O.State(self.sd, np.ones(self.sd.N), s)
+
+    def pack(self, d_send, stream=0):
+        buf = _view(d_send, self.num_send)
+        off = self.send_offsets()
+        for k in range(self.num_neighbors_out):
+            buf[off[k]:off[k + 1]] = self.state.pack(k)
+
+    def unpack(self, d_recv, stream=0):
+        buf = _view(d_recv, self.num_recv)
+        off = self.recv_offsets()
+        for k in range(self.num_neighbors_in):
+            self.state.unpack(k, buf[off[k]:off[k + 1]].copy())
+
+    def update_boundary(self, stream=0):
+        self.state.update_boundary()
+
+    def local_residual(self, stream=0):
+        return self.state.local_residual()
+
+    def local_solve(self, stream=0, want_iters=False):
+        return self.state.local_solve()
+
+    def restrict(self, stream=0):
+        self.state.restrict()
+
+    def get_interior(self, stream=0):
+        g = self.state.global_solution()
+        lo = int(self.sd.local_to_global[0]) if self.local_size else 0
+        return g[lo:lo + self.local_size].copy()
+
+    def true_residual_sq(self, stream=0):
+        rp, col, val = self.sd.local_matrix()
+        x = self.state.global_solution()[self.sd.local_to_global[:self.local_size_x]]
+        ax = O.spmv(rp, col, val, x)
+        r = 1.0 - ax[:self.local_size]
+        return float(np.dot(r, r))
+
+    def algorithmic_bytes(self, which=0):
+        return 0
+
+
+class OracleBackend:
+    name = "oracle-test"
+    device = torch.device("cpu")
+
+    def stream(self):
+        return 0
+
+    def empty(self, n):
+        return torch.zeros(max(int(n), 1), dtype=torch.float64)
+
+    def synchronize(self):
+        pass
+
+    @staticmethod
+    def problem_laplacian(dim, nx, ny=None, nz=None):
+        if dim == 2:
+            return OracleProblem(*O.laplacian2d(nx))
+        return OracleProblem(*O.laplacian3d(nx, ny, nz))
+
+    @staticmethod
+    def problem_from_matrix_market(path):
+        return OracleProblem(*O.read_matrix_market(path))
+
+    @staticmethod
+    def partition_regular(N, P):
+        return O.first_rows_regular(N, P).astype(np.int64)
+
+    @staticmethod
+    def partition_regular2d(n1d, P):
+        return O.partition_regular2d(n1d, P)
+
+    def subdomain(self, problem, P, me, overlap, first_row):
+        return OracleSubdomain(problem, P, me, overlap, first_row)

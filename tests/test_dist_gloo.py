@@ -1,0 +1,120 @@
+"""Multi-process CPU tests of the N>1 host path (one subdomain per process over
+torch.distributed/gloo): the index handshake, the grouped halo send/recv, the all-gathered
+global convergence rule and the solution gather of schwz_amd.SolverRAS + TorchDistComm.
+Compute is done by the test-only oracle backend, so the distributed run must reproduce the
+oracle's single-process lockstep run bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, case, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "1"
+    for p in (HERE, os.path.join(os.path.dirname(HERE), "schwarz-lib_amd"),
+              os.path.join(os.path.dirname(HERE), "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import schwz_amd as S
+    from oracle_backend import OracleBackend
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s = S.Settings(**case["settings"])
+        if case.get("onesided"):
+            s.comm_settings.enable_onesided = True
+            s.convergence_settings.enable_global_simple_tree = True
+        m = S.Metadata(**case["metadata"])
+        solver = S.SolverRAS(s, m, comm=S.TorchDistComm(), backend=OracleBackend(), quiet=True)
+        assert m.num_subdomains == world and m.my_rank == rank
+        solver.initialize()
+        out = solver.run()
+        if rank == 0:
+            hist = np.array(m.post_process_data["global_residual_vector_out"])
+            np.savez(out_path, solution=out["solution"], iter_count=out["iter_count"],
+                     converged=out["converged"], residual_norm=out["residual_norm"],
+                     rhs_norm=out["rhs_norm"], hist=hist, first_row=np.asarray(m.first_row))
+        else:
+            assert out["solution"] is None
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, case, tmp_path):
+    out_path = str(tmp_path / "out.npz")
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, out_path)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+        assert p.exitcode == 0, "worker failed with exit code %s" % p.exitcode
+    return np.load(out_path)
+
+
+CASES = {
+    "lap2d_cg_jacobi": dict(
+        world=2, settings=dict(),
+        metadata=dict(oned_laplacian_size=20, tolerance=1e-8, max_iters=300,
+                      local_precond="block-jacobi", precond_max_block_size=1)),
+    "lap3d_truncated_cg": dict(
+        world=3, settings=dict(laplacian_dim=3, laplacian_shape=(6, 5, 9)),
+        metadata=dict(tolerance=1e-6, max_iters=300, local_precond="block-jacobi",
+                      precond_max_block_size=1, local_solver_tolerance=0.0, local_max_iters=5)),
+    "lap2d_direct_overlap3": dict(
+        world=2, settings=dict(local_solver="direct-ginkgo", overlap=3),
+        metadata=dict(oned_laplacian_size=16, tolerance=1e-9, max_iters=300)),
+    "lap2d_onesided": dict(
+        world=2, settings=dict(), onesided=True,
+        metadata=dict(oned_laplacian_size=16, tolerance=1e-6, max_iters=300)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_distributed_run_reproduces_lockstep_oracle(oracle, name, tmp_path):
+    case = dict(CASES[name])
+    world = case.pop("world")
+    got = _run(world, case, tmp_path)
+    st, md = case["settings"], case["metadata"]
+    if st.get("laplacian_dim") == 3:
+        rp, col, val = oracle.laplacian3d(*st["laplacian_shape"])
+    else:
+        rp, col, val = oracle.laplacian2d(md["oned_laplacian_size"])
+    N = len(rp) - 1
+    s = oracle.make_settings(
+        max_iters=md["max_iters"], tol=md["tolerance"], overlap=st.get("overlap", 2),
+        local_solver=oracle.SOLVER_DIRECT if st.get("local_solver", "").startswith("direct") else 0,
+        precond=1 if md.get("local_precond") == "block-jacobi" else 0,
+        local_tol=md.get("local_solver_tolerance", 1e-12), local_max_iters=md.get("local_max_iters", -1),
+        enable_onesided=int(bool(case.get("onesided"))))
+    fr = oracle.first_rows_regular(N, world)
+    assert np.array_equal(got["first_row"], fr)
+    ref = oracle.ras_run(rp, col, val, np.ones(N), world, fr, s)
+    assert bool(got["converged"]) and ref["converged"]
+    assert int(got["iter_count"]) == ref["iter_count"]
+    # same arithmetic in the same order: bit-identical
+    assert np.array_equal(got["solution"], ref["solution"])
+    if not case.get("onesided"):
+        assert np.array_equal(got["hist"].sum(axis=0), ref["hist_global"])
+        assert np.array_equal(got["hist"].T, ref["hist_local"])
+    assert abs(float(got["residual_norm"]) - ref["residual_norm"]) <= 1e-10 * ref["rhs_norm"]
+    assert abs(float(got["rhs_norm"]) - ref["rhs_norm"]) <= 1e-12 * ref["rhs_norm"]
