@@ -1,0 +1,481 @@
+// Host side of schwz::SchwarzBase / SolverRAS on top of the C ABI (include/schwz_hip.h).
+//
+// One MPI rank = one subdomain = one GPU, as in the reference (source/initialization.cpp:72-74,
+// source/schwarz_base.cpp:102-109).  MPI carries only host data here: the index handshake, the
+// per-iteration residual norms and -- in this C++ layer -- the halo values staged through pinned
+// host buffers (the reference's `stage_through_host` mode, restricted_schwarz.cpp:878-882).  The
+// multi-GPU product path with RCCL send/recv over xGMI is the Python host (schwz_amd/comm.py),
+// which is what bench.py measures.
+#include <schwarz_base.hpp>
+
+#include <hip/hip_runtime_api.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <iostream>
+#include <numeric>
+#include <sstream>
+
+#include <restricted_schwarz.hpp>
+
+#include "schwz_hip.h"
+
+namespace schwz {
+
+namespace {
+
+[[noreturn]] void throw_status(int rc, const char *file, int line, const char *func)
+{
+    const std::string msg = schwz_last_error();
+    switch (rc) {
+    case SCHWZ_ERR_NOT_IMPLEMENTED:
+        throw ::NotImplemented(file, line, std::string(func) + " (" + msg + ")");
+    case SCHWZ_ERR_HIP:
+        throw ::HipError(file, line, func, msg);
+    case SCHWZ_ERR_INVALID:
+        throw ::BadDimension(file, line, func, msg);
+    default:
+        throw ::Error(file, line, std::string(func) + ": " + msg);
+    }
+}
+
+#define SCHWZ_CALL(expr)                                            \
+    do {                                                            \
+        int rc_ = (expr);                                           \
+        if (rc_ != SCHWZ_OK) throw_status(rc_, __FILE__, __LINE__, #expr); \
+    } while (0)
+
+#define HIP_CALL(expr)                                                                        \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) throw ::HipError(__FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+const char *const kTimingNames[5] = {"boundary_exchange", "boundary_update", "convergence_check",
+                                     "local_solve", "expand_local_vec"};
+
+double now()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+template <typename ValueType, typename IndexType, typename MixedValueType>
+struct SchwarzBase<ValueType, IndexType, MixedValueType>::Impl {
+    schwz_problem *problem = nullptr;
+    schwz_subdomain *sd = nullptr;
+    int64_t sizes[10] = {0};
+    std::vector<int> nbr_in, nbr_out;
+    std::vector<int64_t> recv_off, send_off;
+    double *d_send = nullptr, *d_recv = nullptr;
+    double *h_send = nullptr, *h_recv = nullptr;  // pinned staging
+    hipStream_t stream = nullptr;
+    int device = 0;
+
+    ~Impl()
+    {
+        if (sd) schwz_subdomain_destroy(sd);
+        if (problem) schwz_problem_destroy(problem);
+        (void)hipFree(d_send);
+        (void)hipFree(d_recv);
+        if (h_send) (void)hipHostFree(h_send);
+        if (h_recv) (void)hipHostFree(h_recv);
+    }
+};
+
+template <typename V, typename I, typename M>
+SchwarzBase<V, I, M>::SchwarzBase(Settings &settings, Metadata<V, I> &metadata)
+    : settings(settings), metadata(metadata), impl_(new Impl())
+{
+    // Initialize ctor (initialization.cpp:67-75)
+    MPI_Comm_rank(MPI_COMM_WORLD, &metadata.my_rank);
+    MPI_Comm_size(MPI_COMM_WORLD, &metadata.comm_size);
+    metadata.num_subdomains = metadata.comm_size;
+    // node-local rank -> device (utils.cpp:41-78, schwarz_base.cpp:102-109)
+    MPI_Comm local;
+    MPI_Comm_split_type(MPI_COMM_WORLD, MPI_COMM_TYPE_SHARED, 0, MPI_INFO_NULL, &local);
+    MPI_Comm_rank(local, &metadata.my_local_rank);
+    MPI_Comm_size(local, &metadata.local_num_procs);
+    MPI_Comm_free(&local);
+    if (settings.executor_string == "hip" || settings.executor_string == "cuda") {
+        const int ndev = schwz_device_count();
+        if (ndev < 1) {
+            std::cerr << " No HIP device found on rank " << metadata.my_rank << std::endl;
+            std::exit(-1);  // utils.cpp:164-168
+        }
+        impl_->device = metadata.my_local_rank % ndev;
+        SCHWZ_CALL(schwz_set_device(impl_->device));
+        settings.executor = gko::HipExecutor::create(impl_->device, gko::ReferenceExecutor::create());
+        if (metadata.my_rank == 0)
+            std::cout << " Rank " << metadata.my_rank << " with local rank " << metadata.my_local_rank
+                      << " has " << ndev << " HIP device(s); using device " << impl_->device << std::endl;
+    } else {
+        // "reference" and "omp" are CPU executors in the reference; this build has no CPU path
+        throw ::NotImplemented(__FILE__, __LINE__,
+                               "executor '" + settings.executor_string +
+                                   "' (only --executor=hip exists; there is no CPU fallback)");
+    }
+    MPI_Barrier(MPI_COMM_WORLD);
+}
+
+template <typename V, typename I, typename M>
+SchwarzBase<V, I, M>::~SchwarzBase() = default;
+
+template <typename V, typename I, typename M>
+void SchwarzBase<V, I, M>::initialize()
+{
+    auto &m = metadata;
+    auto &s = settings;
+    Impl &im = *impl_;
+    const int P = (int)m.num_subdomains;
+    const int me = m.my_rank;
+
+    // ---- options the GPU path does not provide ------------------------------------------
+    if (s.non_symmetric_matrix) throw ::NotImplemented(__FILE__, __LINE__, "GMRES (non_symmetric_matrix)");
+    if (s.enable_random_rhs) throw ::NotImplemented(__FILE__, __LINE__, "enable_random_rhs");
+    schwz_solver_options opt{};
+    switch (s.local_solver) {
+    case Settings::local_solver_settings::iterative_solver_ginkgo:
+        opt.local_solver = SCHWZ_SOLVER_ITERATIVE;
+        break;
+    case Settings::local_solver_settings::direct_solver_ginkgo:
+    case Settings::local_solver_settings::direct_solver_cholmod:
+        opt.local_solver = SCHWZ_SOLVER_DIRECT;
+        break;
+    default:
+        SCHWARZ_NOT_IMPLEMENTED;
+    }
+    if (m.local_precond == "null" || m.local_precond.empty()) {
+        opt.precond = SCHWZ_PRECOND_NONE;
+    } else if (m.local_precond == "block-jacobi" && m.precond_max_block_size == 1) {
+        opt.precond = SCHWZ_PRECOND_JACOBI;
+    } else {
+        throw ::NotImplemented(__FILE__, __LINE__,
+                               "local_precond '" + m.local_precond +
+                                   "' (available: null, block-jacobi with precond_max_block_size=1)");
+    }
+    opt.local_tol = m.local_solver_tolerance;
+    opt.local_max_iters = (int)m.local_max_iters;
+    opt.natural_factor_ordering = s.naturally_ordered_factor;
+
+    // ---- Initialize::setup_global_matrix (initialization.cpp:197-272) ----------------------
+    // extension: "--matrix_filename=poisson3d:NX[xNYxNZ]" or SCHWZ_LAPLACIAN_DIM=3 select the 3-D
+    // 7-point generator (the reference only has the 2-D one)
+    if (s.matrix_filename.rfind("poisson3d:", 0) == 0) {
+        long long nx = 0, ny = 0, nz = 0;
+        std::string spec = s.matrix_filename.substr(10);
+        for (auto &ch : spec)
+            if (ch == 'x' || ch == 'X') ch = ' ';
+        std::istringstream ss(spec);
+        ss >> nx;
+        if (!(ss >> ny)) ny = nx;
+        if (!(ss >> nz)) nz = nx;
+        SCHWZ_CALL(schwz_problem_laplacian(3, nx, ny, nz, &im.problem));
+        if (me == 0) std::cout << "Laplacian 3D Matrix " << nx << "x" << ny << "x" << nz << " (generated in house) " << std::endl;
+    } else if (s.matrix_filename != "null") {
+        int rc = schwz_problem_from_matrix_market(s.matrix_filename.c_str(), &im.problem);
+        if (rc == SCHWZ_ERR_IO)
+            std::cerr << "Could not find the file \"" << s.matrix_filename
+                      << "\", which is required for this test.\n";
+        SCHWZ_CALL(rc);
+        if (me == 0) std::cout << "Matrix from file " << s.matrix_filename << std::endl;
+    } else if (s.explicit_laplacian) {
+        const char *dim_env = std::getenv("SCHWZ_LAPLACIAN_DIM");
+        const long long n = (long long)m.oned_laplacian_size;
+        if (dim_env && std::atoi(dim_env) == 3) {
+            SCHWZ_CALL(schwz_problem_laplacian(3, n, n, n, &im.problem));
+            if (me == 0) std::cout << "Laplacian 3D Matrix (generated in house) " << std::endl;
+        } else {
+            SCHWZ_CALL(schwz_problem_laplacian(2, n, n, 1, &im.problem));
+            if (me == 0) std::cout << "Laplacian 2D Matrix (generated in house) " << std::endl;
+        }
+    } else {
+        std::cerr << " Need to provide a matrix or enable the default laplacian matrix." << std::endl;
+        std::exit(-1);
+    }
+    m.global_size = (gko::size_type)schwz_problem_size(im.problem);
+    const int64_t N = (int64_t)m.global_size;
+
+    // ---- Initialize::partition + ownership (initialization.cpp:278-329,
+    //      restricted_schwarz.cpp:84-152) ----------------------------------------------------
+    std::vector<int64_t> first_row((size_t)P + 1);
+    SCHWZ_CALL(schwz_partition_regular(N, P, first_row.data()));
+    if (s.partition == Settings::partition_settings::partition_regular) {
+        if (me == 0) std::cout << " Regular 1D partition" << std::endl;
+    } else if (s.partition == Settings::partition_settings::partition_regular2d ||
+               s.partition == Settings::partition_settings::partition_metis) {
+        const bool is2d = s.partition == Settings::partition_settings::partition_regular2d;
+        if (me == 0) std::cout << (is2d ? " Regular 2D partition" : " METIS partition") << std::endl;
+        if (P > 1) {
+            std::vector<uint32_t> part((size_t)N);
+            if (is2d)
+                SCHWZ_CALL(schwz_partition_regular2d((int64_t)std::llround(std::sqrt((double)N)), P, part.data()));
+            else
+                SCHWZ_CALL(schwz_partition_graph(im.problem, P, part.data()));
+            std::vector<int64_t> perm((size_t)N);
+            schwz_problem *permuted = nullptr;
+            SCHWZ_CALL(schwz_problem_permute(im.problem, P, part.data(), perm.data(), first_row.data(), &permuted));
+            schwz_problem_destroy(im.problem);
+            im.problem = permuted;
+            m.permutation.assign(perm.begin(), perm.end());
+        }
+    } else {
+        SCHWARZ_NOT_IMPLEMENTED;
+    }
+    m.first_row.assign(first_row.begin(), first_row.end());
+
+    // ---- SolverRAS::setup_local_matrices / setup_comm_buffers ------------------------------
+    SCHWZ_CALL(schwz_subdomain_setup(im.problem, P, me, s.overlap, first_row.data(), &im.sd));
+    SCHWZ_CALL(schwz_subdomain_sizes(im.sd, im.sizes));
+    const int n_in = (int)im.sizes[6];
+    // index handshake (restricted_schwarz.cpp:400-472): counts by all-to-all, ids point to point
+    std::vector<long long> want((size_t)P, 0), give((size_t)P, 0);
+    std::vector<std::vector<int64_t>> get_ids((size_t)n_in);
+    im.nbr_in.resize((size_t)n_in);
+    for (int k = 0; k < n_in; ++k) {
+        int64_t cnt = 0;
+        SCHWZ_CALL(schwz_subdomain_get_list(im.sd, k, &im.nbr_in[(size_t)k], &cnt, nullptr));
+        get_ids[(size_t)k].resize((size_t)cnt);
+        SCHWZ_CALL(schwz_subdomain_get_list(im.sd, k, nullptr, nullptr, get_ids[(size_t)k].data()));
+        want[(size_t)im.nbr_in[(size_t)k]] = cnt;
+    }
+    MPI_Alltoall(want.data(), 1, MPI_LONG_LONG, give.data(), 1, MPI_LONG_LONG, MPI_COMM_WORLD);
+    std::vector<MPI_Request> reqs;
+    std::vector<std::vector<int64_t>> put_ids((size_t)P);
+    for (int k = 0; k < n_in; ++k) {
+        reqs.emplace_back();
+        MPI_Isend(get_ids[(size_t)k].data(), (int)get_ids[(size_t)k].size(), MPI_INT64_T, im.nbr_in[(size_t)k], 2,
+                  MPI_COMM_WORLD, &reqs.back());
+    }
+    for (int p = 0; p < P; ++p) {
+        if (give[(size_t)p] > 0) {
+            put_ids[(size_t)p].resize((size_t)give[(size_t)p]);
+            reqs.emplace_back();
+            MPI_Irecv(put_ids[(size_t)p].data(), (int)give[(size_t)p], MPI_INT64_T, p, 2, MPI_COMM_WORLD,
+                      &reqs.back());
+        }
+    }
+    MPI_Waitall((int)reqs.size(), reqs.data(), MPI_STATUSES_IGNORE);
+    for (int p = 0; p < P; ++p)
+        if (give[(size_t)p] > 0)
+            SCHWZ_CALL(schwz_subdomain_add_put_list(im.sd, p, give[(size_t)p], put_ids[(size_t)p].data()));
+    SCHWZ_CALL(schwz_subdomain_sizes(im.sd, im.sizes));
+    const int n_out = (int)im.sizes[7];
+    im.nbr_out.resize((size_t)n_out);
+    im.send_off.resize((size_t)n_out + 1);
+    im.recv_off.resize((size_t)n_in + 1);
+    for (int k = 0; k < n_out; ++k)
+        SCHWZ_CALL(schwz_subdomain_put_list(im.sd, k, &im.nbr_out[(size_t)k], nullptr, nullptr));
+    for (int k = 0; k <= n_out; ++k) SCHWZ_CALL(schwz_subdomain_send_offset(im.sd, k, &im.send_off[(size_t)k]));
+    for (int k = 0; k <= n_in; ++k) SCHWZ_CALL(schwz_subdomain_recv_offset(im.sd, k, &im.recv_off[(size_t)k]));
+
+    // ---- Initialize::setup_vectors: rhs = 1 (schwarz_base.cpp:169) ---------------------------
+    m.local_size = (gko::size_type)im.sizes[0];
+    m.local_size_x = (gko::size_type)im.sizes[1];
+    m.overlap_size = (gko::size_type)im.sizes[2];
+    m.local_size_o = m.global_size;
+    local_rhs = gko::share(gko::matrix::Dense<V>::create(s.executor->get_master(), gko::dim<2>(m.local_size_x, 1)));
+    local_solution = gko::share(gko::matrix::Dense<V>::create(s.executor->get_master(), gko::dim<2>(m.local_size_x, 1)));
+    std::vector<double> rhs((size_t)m.local_size_x, 1.0);
+    for (size_t i = 0; i < rhs.size(); ++i) local_rhs->at(i) = (V)rhs[i];
+    SCHWZ_CALL(schwz_subdomain_to_device(im.sd, rhs.data(), &opt));
+
+    const size_t nsend = (size_t)std::max<int64_t>(im.sizes[9], 1), nrecv = (size_t)std::max<int64_t>(im.sizes[8], 1);
+    HIP_CALL(hipMalloc((void **)&im.d_send, nsend * sizeof(double)));
+    HIP_CALL(hipMalloc((void **)&im.d_recv, nrecv * sizeof(double)));
+    HIP_CALL(hipHostMalloc((void **)&im.h_send, nsend * sizeof(double), hipHostMallocDefault));
+    HIP_CALL(hipHostMalloc((void **)&im.h_recv, nrecv * sizeof(double), hipHostMallocDefault));
+
+    // gather_comm_data (schwarz_base.cpp:275-319): one entry per subdomain, only mine is filled
+    m.comm_data_struct.assign((size_t)P, {});
+    {
+        std::vector<std::tuple<int, int>> in((size_t)P, std::make_tuple(0, 0)), out((size_t)P, std::make_tuple(0, 0));
+        for (int p = 0; p < P; ++p) in[(size_t)p] = out[(size_t)p] = std::make_tuple(p, 0);
+        for (int k = 0; k < n_in; ++k)
+            in[(size_t)im.nbr_in[(size_t)k]] = std::make_tuple(im.nbr_in[(size_t)k], (int)(im.recv_off[(size_t)k + 1] - im.recv_off[(size_t)k]));
+        for (int k = 0; k < n_out; ++k)
+            out[(size_t)im.nbr_out[(size_t)k]] = std::make_tuple(im.nbr_out[(size_t)k], (int)(im.send_off[(size_t)k + 1] - im.send_off[(size_t)k]));
+        m.comm_data_struct[(size_t)me] = std::make_tuple(me, in, out, n_in, n_out);
+    }
+    if (me == 0) {
+        std::cout << " Problem size: " << m.global_size << " subdomains: " << P << " local size (rank 0): "
+                  << m.local_size << " with overlap rows: " << m.overlap_size << std::endl;
+        if (opt.local_solver == SCHWZ_SOLVER_ITERATIVE) {
+            const long long lmi = m.local_max_iters == -1 ? (long long)m.local_size_x : (long long)m.local_max_iters;
+            std::cout << " Local max iters " << lmi << " with restart iter " << s.restart_iter << std::endl;
+        } else {
+            std::cout << " Local direct solve with HIP TRS" << std::endl;
+        }
+    }
+}
+
+template <typename V, typename I, typename M>
+void SchwarzBase<V, I, M>::run(std::shared_ptr<gko::matrix::Dense<V>> &solution)
+{
+    auto &m = metadata;
+    auto &s = settings;
+    Impl &im = *impl_;
+    if (!im.sd) throw ::Error(__FILE__, __LINE__, "run() called before initialize()");
+    const int P = (int)m.num_subdomains;
+    const int me = m.my_rank;
+    const auto &cs = s.comm_settings;
+    const auto &cv = s.convergence_settings;
+    if (!solution.get())
+        solution = gko::share(gko::matrix::Dense<V>::create(s.executor->get_master(), gko::dim<2>(m.global_size, 1)));
+    if (me == 0) std::cout << " MixedValueType: " << typeid(M).name() << " ValueType: " << typeid(V).name() << std::endl;
+    if (cs.enable_onesided && !(cv.enable_global_simple_tree || cv.enable_decentralized_leader_election)) {
+        std::cout << "Global Convergence check type unspecified" << std::endl;
+        std::exit(-1);  // solve.cpp:939-943
+    }
+    const int n_in = (int)im.nbr_in.size(), n_out = (int)im.nbr_out.size();
+    std::vector<MPI_Request> reqs((size_t)(n_in + n_out));
+
+    // halo exchange staged through pinned host memory (see the file comment)
+    auto exchange = [&]() {
+        SCHWZ_CALL(schwz_ras_pack(im.sd, im.d_send, im.stream));
+        if (im.sizes[9] > 0) {
+            HIP_CALL(hipMemcpyAsync(im.h_send, im.d_send, (size_t)im.sizes[9] * sizeof(double), hipMemcpyDeviceToHost, im.stream));
+            HIP_CALL(hipStreamSynchronize(im.stream));
+        }
+        int r = 0;
+        for (int k = 0; k < n_in; ++k)
+            MPI_Irecv(im.h_recv + im.recv_off[(size_t)k], (int)(im.recv_off[(size_t)k + 1] - im.recv_off[(size_t)k]),
+                      MPI_DOUBLE, im.nbr_in[(size_t)k], 0, MPI_COMM_WORLD, &reqs[(size_t)r++]);
+        for (int k = 0; k < n_out; ++k)
+            MPI_Isend(im.h_send + im.send_off[(size_t)k], (int)(im.send_off[(size_t)k + 1] - im.send_off[(size_t)k]),
+                      MPI_DOUBLE, im.nbr_out[(size_t)k], 0, MPI_COMM_WORLD, &reqs[(size_t)r++]);
+        MPI_Waitall(r, reqs.data(), MPI_STATUSES_IGNORE);  // receives complete before the scatter (F8)
+        if (im.sizes[8] > 0)
+            HIP_CALL(hipMemcpyAsync(im.d_recv, im.h_recv, (size_t)im.sizes[8] * sizeof(double), hipMemcpyHostToDevice, im.stream));
+        SCHWZ_CALL(schwz_ras_unpack(im.sd, im.d_recv, im.stream));
+    };
+
+    std::vector<std::vector<V>> timings(5);
+    auto &ppd = m.post_process_data;
+    ppd.global_residual_vector_out.assign((size_t)P, {});
+    V local_res = -1.0, local_res0 = -1.0, global_res = 0.0, global_res0 = -1.0;
+    int num_converged = 0;
+    bool flag = false;
+    std::vector<double> all((size_t)P);
+    const V tol = m.tolerance;
+    m.iter_count = 0;
+    HIP_CALL(hipDeviceSynchronize());
+    MPI_Barrier(MPI_COMM_WORLD);
+    m.init_mpi_wtime = MPI_Wtime();
+    const double start = now();
+    for (; m.iter_count < m.max_iters; ++m.iter_count) {
+        const auto it = m.iter_count;
+        const double t0 = now();
+        if (!(cs.enable_onesided && it == 0)) exchange();  // restricted_schwarz.cpp:725
+        const double t1 = now();
+        SCHWZ_CALL(schwz_ras_update_boundary(im.sd, im.stream));
+        const double t2 = now();
+        // steps 2+3 are enqueued together; the host reads the norm while the solve runs
+        local_res = -1.0;
+        if (tol >= 0.0) {
+            SCHWZ_CALL(schwz_ras_check_and_solve_launch(im.sd, im.stream));
+            double r = 0.0;
+            SCHWZ_CALL(schwz_ras_local_residual_wait(im.sd, &r));
+            local_res = (V)r;
+            if (local_res0 < 0.0) local_res0 = local_res;
+        } else {
+            SCHWZ_CALL(schwz_ras_local_solve(im.sd, nullptr, im.stream));
+        }
+        if (std::isnan(local_res)) std::exit(-1);  // solve.cpp:982-984
+        ppd.local_residual_vector_out.push_back(local_res);
+        ppd.local_converged_resnorm.push_back(local_res / local_res0);
+        m.current_residual_norm = local_res;
+        m.min_residual_norm = it == 0 ? local_res : std::min(local_res, m.min_residual_norm);
+        const bool iter_cond = cv.enable_global_check_iter_offset ? ((it > m.max_iters * 0.05) || m.max_iters < 1000) : true;
+        if (tol > 0.0 && iter_cond) {
+            if (cv.enable_global_check && !cs.enable_onesided) {
+                double mine = local_res;
+                MPI_Allgather(&mine, 1, MPI_DOUBLE, all.data(), 1, MPI_DOUBLE, MPI_COMM_WORLD);  // solve.cpp:890
+                global_res = 0.0;
+                for (int j = 0; j < P; ++j) {
+                    ppd.global_residual_vector_out[(size_t)j].push_back((V)all[(size_t)j]);
+                    global_res += (V)all[(size_t)j];  // sum of the norms (solve.cpp:895-905)
+                }
+                if (global_res0 < 0.0) global_res0 = global_res;
+                num_converged = (global_res / global_res0 <= tol) ? P : 0;
+            } else if (cs.enable_onesided) {
+                // local test (solve.cpp:913-915) + monotone flags (conv_tools.hpp:249-251)
+                if (local_res / local_res0 <= tol) flag = true;
+                double mine = flag ? 1.0 : 0.0;
+                MPI_Allgather(&mine, 1, MPI_DOUBLE, all.data(), 1, MPI_DOUBLE, MPI_COMM_WORLD);
+                num_converged = (int)std::accumulate(all.begin(), all.end(), 0.0);
+            } else {
+                num_converged = 0;  // never converges on this branch
+            }
+        }
+        const double t3 = now();
+        if (std::isnan(global_res) || global_res > 1e12) {
+            std::cout << " Rank " << me << " diverged in " << it << " iters " << std::endl;
+            std::exit(-1);  // schwarz_base.cpp:424-428
+        }
+        timings[0].push_back((V)(t1 - t0));
+        timings[1].push_back((V)(t2 - t1));
+        timings[2].push_back((V)(t3 - t2));
+        if (num_converged == P) break;
+        const double t4 = now();  // the solve was enqueued with the check
+        SCHWZ_CALL(schwz_ras_restrict(im.sd, im.stream));
+        const double t5 = now();
+        timings[3].push_back((V)(t4 - t3));
+        timings[4].push_back((V)(t5 - t4));
+    }
+    HIP_CALL(hipDeviceSynchronize());
+    MPI_Barrier(MPI_COMM_WORLD);
+    const double elapsed = now() - start;
+    m.time_struct.clear();
+    for (int i = 0; i < 5; ++i)
+        m.time_struct.emplace_back(i, me, (int)timings[(size_t)i].size(), kTimingNames[i], timings[(size_t)i]);
+
+    // Solve::compute_residual_norm (solve.cpp:1025-1085): fresh overlap values, then the true
+    // residual over the interior rows, ||b|| and the assembled solution on rank 0
+    const bool converged = num_converged == P;
+    if (!converged) {
+        std::cout << "Rank " << me << " did not converge in " << m.iter_count << " iterations." << std::endl;
+    } else {
+        std::cout << " Rank " << me << " converged in " << m.iter_count << " iterations " << std::endl;
+    }
+    exchange();
+    double part = 0.0, res_sq = 0.0, rhs_sq_loc = (double)m.local_size, rhs_sq = 0.0;
+    SCHWZ_CALL(schwz_ras_true_residual_sq(im.sd, &part, im.stream));
+    MPI_Allreduce(&part, &res_sq, 1, MPI_DOUBLE, MPI_SUM, MPI_COMM_WORLD);
+    MPI_Allreduce(&rhs_sq_loc, &rhs_sq, 1, MPI_DOUBLE, MPI_SUM, MPI_COMM_WORLD);
+    std::vector<double> interior((size_t)std::max<gko::size_type>(m.local_size, 1));
+    SCHWZ_CALL(schwz_ras_get_interior(im.sd, interior.data(), im.stream));
+    std::vector<int> counts((size_t)P), displs((size_t)P);
+    for (int p = 0; p < P; ++p) {
+        counts[(size_t)p] = (int)(m.first_row[(size_t)p + 1] - m.first_row[(size_t)p]);
+        displs[(size_t)p] = (int)m.first_row[(size_t)p];
+    }
+    std::vector<double> gathered(me == 0 ? (size_t)m.global_size : 1);
+    MPI_Gatherv(interior.data(), (int)m.local_size, MPI_DOUBLE, gathered.data(), counts.data(), displs.data(), MPI_DOUBLE,
+                0, MPI_COMM_WORLD);
+    if (converged && me == 0) {
+        const double residual_norm = std::sqrt(res_sq), rhs_norm = std::sqrt(rhs_sq);
+        std::cout << " residual norm " << residual_norm << "\n"
+                  << " relative residual norm of solution " << residual_norm / rhs_norm << "\n"
+                  << " Time taken for solve " << elapsed << std::endl;
+    }
+    if (me == 0) {
+        if (solution->get_size()[0] != m.global_size)
+            solution = gko::share(gko::matrix::Dense<V>::create(s.executor->get_master(), gko::dim<2>(m.global_size, 1)));
+        for (gko::size_type i = 0; i < m.global_size; ++i) solution->at(i) = (V)gathered[i];
+    }
+}
+
+#define SCHWZ_INSTANTIATE(V, I, M)          \
+    template class SchwarzBase<V, I, M>;    \
+    template class SolverRAS<V, I, M>
+
+// the reference instantiates (double, int32|int64, float|double) (settings.hpp:533-537)
+SCHWZ_INSTANTIATE(double, gko::int32, double);
+SCHWZ_INSTANTIATE(double, gko::int32, float);
+SCHWZ_INSTANTIATE(double, gko::int64, double);
+SCHWZ_INSTANTIATE(double, gko::int64, float);
+
+}  // namespace schwz
