@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--inner", type=int, default=10, help="CG iterations per local solve")
     ap.add_argument("--size", type=int, default=256, help="1-GPU grid edge (256 = configs[1])")
+    ap.add_argument("--slab", default="512,512,64",
+                    help="N>1: per-GPU slab nx,ny,nz (grid = nx x ny x nz*N; default = configs[2] at N=8)")
     ap.add_argument("--spmv-variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ttr", action="store_true", help="skip the time-to-residual run")
@@ -97,12 +99,22 @@ def main():
         import torch.distributed as dist
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # SCHWZ_DIST_BACKEND=gloo: several ranks may share one GPU (halos staged through host);
+        # used to rehearse the N>1 path on a 1-GPU box.  The product backend is nccl (= RCCL).
+        backend = os.environ.get("SCHWZ_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % torch.cuda.device_count()
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend)
         comm = schwz.TorchDistComm(device=torch.device("cuda", local_rank))
         comm.device_index = local_rank
         assert comm.size == N, "--gpus must equal the launched world size"
-        shape = (512, 512, 64 * N)
-        workload = "3D Poisson 512x512x%d, %d z-slab subdomains (16.8M rows/GPU), overlap 2" % (64 * N, N)
+        sx, sy, sz = [int(t) for t in a.slab.split(",")]
+        shape = (sx, sy, sz * N)
+        workload = "3D Poisson %dx%dx%d, %d z-slab subdomains (%.1fM rows/GPU), overlap 2" % (
+            sx, sy, sz * N, N, sx * sy * sz / 1e6)
     else:
         comm = schwz.InProcessComm(1)
         shape = (a.size, a.size, a.size)
@@ -141,10 +153,8 @@ def main():
     tot_ms, launches = ctypes.c_double(0.0), ctypes.c_int64(0)
     schwz.capi.check(schwz.capi.lib.schwz_profile_end(ctypes.byref(tot_ms), ctypes.byref(launches)))
     if N > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = max(comm.allgather_scalars({rank: elapsed}))
+        elapsed_instrumented = max(comm.allgather_scalars({rank: elapsed_instrumented}))
     iters_per_s = a.steps / elapsed
     alg_spmv = sd.algorithmic_bytes(0)
     avg_ms = tot_ms.value / max(launches.value, 1)
@@ -204,7 +214,7 @@ def main():
         print(json.dumps(line), flush=True)
     if N > 1:
         import torch.distributed as dist
-        dist.barrier()
+        comm.barrier()
         dist.destroy_process_group()
 
 

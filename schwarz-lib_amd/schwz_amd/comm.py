@@ -58,7 +58,15 @@ class InProcessComm:
 
 
 class TorchDistComm:
-    """One subdomain per rank.  `device` is where halo buffers live."""
+    """One subdomain per rank.
+
+    Halo values travel on the default process group: with the `nccl` backend that is
+    ncclSend/ncclRecv (RCCL over xGMI) on device buffers, grouped per iteration.  Everything
+    that is host data anyway -- the index handshake, the P residual norms per iteration, the
+    final solution pieces -- goes through a gloo group, so those small collectives never
+    serialise against the GPU stream the local solve is running on.  When the default backend
+    itself is gloo (CPU tests, or several ranks sharing one GPU) device halo buffers are staged
+    through host memory (the reference's `stage_through_host`)."""
 
     def __init__(self, device=None, group=None):
         import torch
@@ -73,68 +81,90 @@ class TorchDistComm:
         self.local_ranks = [self.rank]
         self.is_root = self.rank == 0
         self.device = device if device is not None else torch.device("cpu")
+        self.backend = dist.get_backend(group)
+        self.host_group = group if self.backend == "gloo" else dist.new_group(backend="gloo")
+        self.stage_through_host = self.backend == "gloo" and self.device.type != "cpu"
+        self._stage = {}
 
     def handshake(self, get_lists):
-        """Counts and ids travel as int64 tensors (tags 1 and 2 of the
-        reference become one all_gather of counts + point-to-point ids)."""
+        """Counts and ids travel as int64 host tensors (tags 1 and 2 of the reference become
+        one all_gather of counts + point-to-point id lists)."""
         torch, dist = self._torch, self._dist
         mine = get_lists[self.rank]
         counts = torch.zeros(self.size, dtype=torch.int64)
         for p, ids in mine:
             counts[p] = len(ids)
-        counts = counts.to(self.device)
-        all_counts = [torch.zeros(self.size, dtype=torch.int64, device=self.device)
-                      for _ in range(self.size)]
-        dist.all_gather(all_counts, counts, group=self.group)  # setup only
-        all_counts = [t.cpu() for t in all_counts]
+        all_counts = [torch.zeros(self.size, dtype=torch.int64) for _ in range(self.size)]
+        dist.all_gather(all_counts, counts, group=self.host_group)
         ops, keep = [], []
         for p, ids in mine:
-            t = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int64)).to(self.device)
+            t = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int64))
             keep.append(t)
-            ops.append(dist.P2POp(dist.isend, t, p, group=self.group))
+            ops.append(dist.P2POp(dist.isend, t, p, group=self.host_group))
         incoming = []
         for q in range(self.size):
             c = int(all_counts[q][self.rank])
             if q != self.rank and c > 0:
-                buf = torch.empty(c, dtype=torch.int64, device=self.device)
+                buf = torch.empty(c, dtype=torch.int64)
                 incoming.append((q, buf))
-                ops.append(dist.P2POp(dist.irecv, buf, q, group=self.group))
+                ops.append(dist.P2POp(dist.irecv, buf, q, group=self.host_group))
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
-        return {self.rank: [(q, buf.cpu().numpy()) for q, buf in incoming]}
+        return {self.rank: [(q, buf.numpy()) for q, buf in incoming]}
+
+    def _host_copy(self, key, buf):
+        t = self._stage.get(key)
+        if t is None or t.numel() != buf.numel():
+            t = self._torch.empty(buf.numel(), dtype=buf.dtype).pin_memory()
+            self._stage[key] = t
+        return t
 
     def start_exchange(self, sends, recvs):
-        """Grouped send/recv (ncclGroupStart..End under the nccl backend)."""
+        """Grouped send/recv of the packed halo buffers ({(src, dst): 1-D tensor})."""
         dist = self._dist
-        ops = []
-        for (src, dst), buf in sorted(sends.items()):
-            ops.append(dist.P2POp(dist.isend, buf, dst, group=self.group))
-        for (src, dst), buf in sorted(recvs.items()):
-            ops.append(dist.P2POp(dist.irecv, buf, src, group=self.group))
-        return dist.batch_isend_irecv(ops) if ops else []
+        ops, post = [], []
+        if self.stage_through_host:
+            for (src, dst), buf in sorted(sends.items()):
+                h = self._host_copy(("s", src, dst), buf)
+                h.copy_(buf)  # synchronous device->host copy on the current stream
+                ops.append(dist.P2POp(dist.isend, h, dst, group=self.group))
+            for (src, dst), buf in sorted(recvs.items()):
+                h = self._host_copy(("r", src, dst), buf)
+                ops.append(dist.P2POp(dist.irecv, h, src, group=self.group))
+                post.append((buf, h))
+        else:
+            for (src, dst), buf in sorted(sends.items()):
+                ops.append(dist.P2POp(dist.isend, buf, dst, group=self.group))
+            for (src, dst), buf in sorted(recvs.items()):
+                ops.append(dist.P2POp(dist.irecv, buf, src, group=self.group))
+        works = dist.batch_isend_irecv(ops) if ops else []
+        return works, post
 
     def finish_exchange(self, handle):
-        for w in handle or []:
+        works, post = handle
+        for w in works:
             w.wait()
+        for buf, h in post:
+            buf.copy_(h, non_blocking=True)
 
     def exchange(self, sends, recvs):
         self.finish_exchange(self.start_exchange(sends, recvs))
 
     def allgather_scalars(self, values):
         torch, dist = self._torch, self._dist
-        mine = torch.tensor([float(values[self.rank])], dtype=torch.float64, device=self.device)
-        out = [torch.zeros(1, dtype=torch.float64, device=self.device) for _ in range(self.size)]
-        dist.all_gather(out, mine, group=self.group)
-        return [float(t.item()) for t in out]
+        mine = torch.tensor([float(values[self.rank])], dtype=torch.float64)
+        out = [torch.zeros(1, dtype=torch.float64) for _ in range(self.size)]
+        dist.all_gather(out, mine, group=self.host_group)
+        return [float(t[0]) for t in out]
 
     def gather_vectors(self, pieces):
         dist = self._dist
         objs = [None] * self.size if self.is_root else None
-        dist.gather_object(pieces[self.rank], objs, dst=0, group=self.group)
+        dist.gather_object(pieces[self.rank], objs, dst=0, group=self.host_group)
         if self.is_root:
             return np.concatenate(objs)
         return None
 
     def barrier(self):
-        self._dist.barrier(group=self.group)
+        self._dist.barrier(group=self.host_group)
