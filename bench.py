@@ -98,11 +98,11 @@ def main():
     if N > 1 or world > 1:
         import torch.distributed as dist
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        torch.cuda.set_device(local_rank)
         # SCHWZ_DIST_BACKEND=gloo: several ranks may share one GPU (halos staged through host);
         # used to rehearse the N>1 path on a 1-GPU box.  The product backend is nccl (= RCCL).
         backend = os.environ.get("SCHWZ_DIST_BACKEND", "nccl")
         if backend == "nccl":
+            torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             local_rank = local_rank % torch.cuda.device_count()

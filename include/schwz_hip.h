@@ -88,7 +88,9 @@ int64_t schwz_csr_nnz(const schwz_csr *A);
 
 /* y = alpha*A*x + beta*y : gko Csr::apply(alpha,x,beta,y), call sites
  * source/restricted_schwarz.cpp:1014-1015, source/solve.cpp:834-835,1079-1080.
- * variant: 0 = default (LDS-staged row tiles, 16-byte batched loads),
+ * variant: 0 = default: dictionary-coded tiles where the matrix allows it (lossless,
+ * bit-identical results; see csrc/spmv_dict.hip), else 6; 6 = plain CSR, LDS-staged row tiles
+ * with 16-byte batched loads,
  * 1 = one-row-per-lane baseline, 2 = first tiled version (scalar loads), 3/5 = wave-private
  * tiles (5: non-temporal matrix loads), 4 = software-pipelined tiles; 10.. = ablation builds
  * for tools/spmv_probe.py (deliberately wrong results). */

@@ -11,50 +11,9 @@
 #include <cstdlib>
 
 #include "schwz_internal.hpp"
+#include "device_utils.hpp"
 
 namespace schwz {
-
-// ---------------------------------------------------------------------------
-// reductions
-// ---------------------------------------------------------------------------
-
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
-// Sum over the 256-thread workgroup; result valid in every thread.
-// `red` must hold 4 doubles.  Fixed order => bitwise reproducible.
-__device__ __forceinline__ double block_sum(double v, double *red)
-{
-    v = wave_sum(v);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    __syncthreads();  // protect `red` from a previous use
-    if (lane == 0) red[w] = v;
-    __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
-}
-
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a
-// workgroup-scope release/acquire fence over ALL address spaces, i.e. an
-// s_waitcnt vmcnt(0): every global load or store still in flight (the prefetched
-// matrix entries of the next tile, the y stores of the previous one) would have
-// to land before the barrier.  The tiles only hand LDS data between waves.
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-// Every workgroup folds the per-workgroup partial sums of the previous launch
-// itself (fixed order): no extra launch and no atomics on the critical path.
-__device__ __forceinline__ double fold_partials(const double *part, int count, double *red)
-{
-    double s = 0.0;
-    for (int i = threadIdx.x; i < count; i += kBlock) s += part[i];
-    return block_sum(s, red);
-}
 
 // ---------------------------------------------------------------------------
 // CSR SpMV, tiled: each workgroup owns a run of consecutive rows whose nonzeros
@@ -64,27 +23,6 @@ __device__ __forceinline__ double fold_partials(const double *part, int count, d
 // matrix: the x entries a tile shares with its neighbours (i+-1, i+-nx, i+-nx*ny
 // for the Poisson stencils) stay in that XCD's 4 MiB L2.
 // ---------------------------------------------------------------------------
-
-// Tile dealt to XCD `xcd` as its j-th one.  Tiles go to the eight XCDs in runs of
-// A.xcd_block (block-cyclic): with the run length set to 1/8 of the matrix
-// bandwidth (in tiles) every XCD sweeps one strip of each grid plane, plane after
-// plane, so the x lines a tile shares with its +-nx*ny neighbours are reused after
-// ~xcd_block tiles instead of after a whole plane of matrix stream (which is
-// larger than the 4 MiB L2 and used to evict them: 3.5 HBM fetches per x line).
-// Returns -1 past the end.
-__device__ __forceinline__ int xcd_tile(const CsrView &A, int xcd, int j)
-{
-    const int B = A.xcd_block;
-    const int tile = (j / B) * (kXcds * B) + xcd * B + (j % B);
-    return tile < A.ntiles ? tile : -1;
-}
-
-// number of sequence slots per XCD
-__device__ __forceinline__ int xcd_slots(const CsrView &A)
-{
-    const int B = A.xcd_block;
-    return ((A.ntiles + kXcds * B - 1) / (kXcds * B)) * B;
-}
 
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void spmv_tiled_kernel(CsrView A, SpmvArgs a)
@@ -789,8 +727,8 @@ int spmv_grid(const CsrView &A, int variant)
 int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipStream_t s)
 {
     if (A.nrows == 0) return SCHWZ_OK;
-    if (mode == kSpmvResidDual && variant != 0 && variant != 4) {
-        set_error("launch_spmv: the fused dual-residual mode exists for variants 0 and 4 only");
+    if (mode == kSpmvResidDual && variant != 0 && variant != 4 && variant != 6) {
+        set_error("launch_spmv: the fused dual-residual mode exists for variants 0, 4 and 6 only");
         return SCHWZ_ERR_INVALID;
     }
     const int grid = spmv_grid(A, variant);
@@ -809,6 +747,7 @@ int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipS
         hipLaunchKernelGGL((spmv_wave_kernel<kSpmvResidNorm, NTV>), dim3(wgrid), dim3(kBlock), 0, s, A, a); \
         break;                                                                                         \
     }
+    if (variant == 0 && A.code) return launch_spmv_dict(A, mode, a, grid, s);
     if (variant >= 10 && variant < 74 && mode == kSpmvPlain) {
         switch (variant - 10) {
 #define SCHWZ_ABL(W) \
@@ -1382,6 +1321,10 @@ int schwz_csr_create(int64_t nrows, int64_t ncols, const schwz_idx *h_rp, const 
     }
     A->v.nwtiles = (int)wtiles.size() - 1;
     A->v.wtile_row = (const schwz_idx *)A->d_wtile;
+    if ((rc = build_spmv_dict(A, h_rp, h_col, h_val, tiles))) {
+        schwz_csr_destroy(A);
+        return rc;
+    }
     *out = A;
     return SCHWZ_OK;
 }
@@ -1395,6 +1338,7 @@ void schwz_csr_destroy(schwz_csr *A)
     (void)hipFree(A->d_tile);
     (void)hipFree(A->d_wtile);
     (void)hipFree(A->d_order);
+    free_spmv_dict(A);
     delete A;
 }
 

@@ -53,6 +53,13 @@ struct CsrView {
     int xcd_block = 0;  // tiles are dealt to the 8 XCDs block-cyclically in runs of this many
     int nwtiles = 0;                        // wave tiles: <= 64 rows, <= kWaveTileNnz-2 nnz
     const schwz_idx *wtile_row = nullptr;
+    // dictionary-coded copy of (val, col) for the tiles that allow it (spmv_dict.hip):
+    // code[j] = value code | delta code << 8 ; per tile a value and a (col - row) dictionary
+    const uint16_t *code = nullptr;
+    const schwz_idx *vdict_ptr = nullptr;   // ntiles+1 ; vdict_ptr[t] == vdict_ptr[t+1] => raw tile
+    const schwz_idx *ddict_ptr = nullptr;   // ntiles+1
+    const double *vdict = nullptr;
+    const schwz_idx *ddict = nullptr;
 };
 
 // epilogues of the tiled SpMV kernel
@@ -83,6 +90,7 @@ struct SpmvArgs {
 
 int spmv_grid(const CsrView &A, int variant);
 int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipStream_t s);
+int launch_spmv_dict(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s);
 
 // device-side CG scalar state
 struct CgState {
@@ -93,6 +101,14 @@ struct CgState {
     int stop_iter;
 };
 
+}  // namespace schwz
+
+struct schwz_csr;
+namespace schwz {
+// builds the dictionary coding on the host and uploads it (no-op + SCHWZ_OK when it does not pay)
+int build_spmv_dict(schwz_csr *A, const schwz_idx *h_rp, const schwz_idx *h_col, const double *h_val,
+                    const std::vector<schwz_idx> &tiles);
+void free_spmv_dict(schwz_csr *A);
 }  // namespace schwz
 
 struct schwz_pcg;
@@ -107,6 +123,8 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
 struct schwz_csr {
     schwz::CsrView v;
     void *d_rp = nullptr, *d_col = nullptr, *d_val = nullptr, *d_tile = nullptr, *d_wtile = nullptr, *d_order = nullptr;
+    void *d_code = nullptr, *d_vptr = nullptr, *d_dptr = nullptr, *d_vdict = nullptr, *d_ddict = nullptr;
+    double dict_fraction = 0.0;  // share of the nonzeros that are dictionary coded
 };
 
 struct schwz_pcg {

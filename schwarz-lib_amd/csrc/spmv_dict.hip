@@ -1,0 +1,315 @@
+// Dictionary-coded CSR tiles: a lossless re-encoding of (val, col) built once at upload.
+//
+// Many matrices on this path (the Poisson stencils, FEM operators on regular meshes) repeat a
+// handful of values and a handful of (column - row) offsets inside every run of 256 rows.  For
+// each row tile whose entries use at most 256 distinct values and 256 distinct offsets the 12
+// bytes per nonzero of CSR become 2: one byte indexing a per-tile value dictionary, one byte
+// indexing a per-tile offset dictionary.
+// Tiles that do not qualify keep using val/col.  The arithmetic is unchanged -- the same
+// products are summed in the same (ascending column) order -- so results are bit-identical to
+// the plain CSR kernels; only the HBM traffic differs.
+//
+// Kernel: the tile's codes (<= 4 KiB) and dictionaries are staged in LDS with coalesced loads;
+// then ONE LANE PER ROW decodes its entries and gathers x.  Consecutive lanes hold consecutive
+// rows, so for banded matrices each gather instruction reads one contiguous run of x (the k-th
+// neighbour of 64 consecutive rows) instead of the ~20 scattered lines of an entry-parallel
+// gather.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <unordered_map>
+
+#include "device_utils.hpp"
+#include "schwz_internal.hpp"
+
+namespace schwz {
+
+constexpr int kDictMax = 256;
+constexpr int kChunk = 8;  // gathers issued back to back per lane
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void spmv_dict_kernel(CsrView A, SpmvArgs a)
+{
+    __shared__ uint16_t codes[kTileNnz + 8];
+    __shared__ double vdict[kDictMax];
+    __shared__ int ddict[kDictMax];
+    __shared__ double red[4];
+    if (MODE == kSpmvDot || MODE == kSpmvResidInit) {
+        if (a.stop_iter && a.it >= *a.stop_iter) return;
+    }
+    const int tid = threadIdx.x;
+    const int xcd = blockIdx.x % kXcds;
+    const int slot = blockIdx.x / kXcds;
+    const int per_xcd = gridDim.x / kXcds;
+    const int chunk = xcd_slots(A);
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+    const bool dual = (MODE == kSpmvResidDual) && a.x2 != nullptr;
+
+    for (int t = slot; t < chunk; t += per_xcd) {
+        const int tile = xcd_tile(A, xcd, t);
+        if (tile < 0) continue;
+        const int r0 = A.tile_row[tile], r1 = A.tile_row[tile + 1];
+        const int s = A.rp[r0], e = A.rp[r1];
+        const int v0 = A.vdict_ptr[tile], nv = A.vdict_ptr[tile + 1] - v0;
+        const int d0 = A.ddict_ptr[tile], nd = A.ddict_ptr[tile + 1] - d0;
+        const int row = r0 + tid;
+        const bool have_row = (r1 - r0 > 1) ? row < r1 : tid == 0;
+        double sum = 0.0, sum2 = 0.0;
+        if (nd > 0) {
+            // ---- coded tile ------------------------------------------------------------------
+            const int s4 = s & ~3;  // 8-byte aligned window of 2-byte codes
+            int b0 = 0, b1 = 0;
+            if (row < r1) {
+                b0 = A.rp[row] - s4;
+                b1 = A.rp[row + 1] - s4;
+            }
+            const int last = max((e - 1) & ~3, s4);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int idx = min(s4 + 4 * (tid + kBlock * k), last);
+                *reinterpret_cast<uint2 *>(&codes[4 * (tid + kBlock * k)]) =
+                    *reinterpret_cast<const uint2 *>(A.code + idx);
+            }
+            if (tid < nv) vdict[tid] = A.vdict[v0 + tid];
+            if (tid < nd) ddict[tid] = A.ddict[d0 + tid];
+            lds_barrier();
+            if (row < r1) {
+                for (int j = b0; j < b1; j += kChunk) {
+                    double v[kChunk], xg[kChunk], xg2[kChunk];
+                    int c[kChunk];
+                    const int jl = b1 - 1;
+#pragma unroll
+                    for (int k = 0; k < kChunk; ++k) {
+                        const unsigned cd = codes[min(j + k, jl)];
+                        v[k] = vdict[cd & 255u];
+                        c[k] = row + ddict[cd >> 8];
+                    }
+#pragma unroll
+                    for (int k = 0; k < kChunk; ++k) xg[k] = a.x[c[k]];
+                    if (dual) {
+#pragma unroll
+                        for (int k = 0; k < kChunk; ++k) xg2[k] = a.x2[c[k]];
+                    }
+#pragma unroll
+                    for (int k = 0; k < kChunk; ++k) {
+                        if (j + k < b1) {
+                            sum += v[k] * xg[k];
+                            if (dual) sum2 += v[k] * xg2[k];
+                        }
+                    }
+                }
+            }
+            lds_barrier();
+        } else if (r1 - r0 > 1) {
+            // ---- raw tile: one lane per row straight from val/col --------------------------------
+            if (row < r1) {
+                for (int j = A.rp[row]; j < A.rp[row + 1]; ++j) {
+                    const double vv = A.val[j];
+                    const int cc = A.col[j];
+                    sum += vv * a.x[cc];
+                    if (dual) sum2 += vv * a.x2[cc];
+                }
+            }
+        } else {
+            // ---- a single long row: the whole workgroup reduces it ------------------------------
+            double part = 0.0, part2 = 0.0;
+            for (int i = s + tid; i < e; i += kBlock) {
+                part += A.val[i] * a.x[A.col[i]];
+                if (dual) part2 += A.val[i] * a.x2[A.col[i]];
+            }
+            sum = block_sum(part, red);
+            if (dual) sum2 = block_sum(part2, red);
+        }
+        if (have_row) {
+            const int rw = (r1 - r0 > 1) ? row : r0;
+            if (MODE == kSpmvPlain) {
+                a.y[rw] = (a.beta == 0.0) ? a.alpha * sum : a.alpha * sum + a.beta * a.y[rw];
+            } else if (MODE == kSpmvDot) {
+                a.y[rw] = sum;
+                acc0 += a.x[rw] * sum;
+            } else if (MODE == kSpmvResidInit || MODE == kSpmvResidDual) {
+                const double bb = a.b[rw];
+                const double r = bb - sum;
+                const double z = a.dinv ? a.dinv[rw] * r : r;
+                a.y[rw] = r;
+                a.p[rw] = z;
+                acc0 += r * z;
+                acc1 += r * r;
+                if (MODE == kSpmvResidDual && rw < a.row_limit) {
+                    const double r2 = dual ? bb - sum2 : r;
+                    acc2 += r2 * r2;
+                }
+            } else {  // kSpmvResidNorm
+                if (rw < a.row_limit) {
+                    const double r = a.b[rw] - sum;
+                    acc1 += r * r;
+                }
+            }
+        }
+    }
+    if (MODE != kSpmvPlain) {
+        const double s0 = block_sum(acc0, red);
+        const double s1 = block_sum(acc1, red);
+        if (tid == 0) {
+            a.partials[blockIdx.x] = s0;
+            a.partials[gridDim.x + blockIdx.x] = s1;
+        }
+        if (MODE == kSpmvResidDual) {
+            const double s2v = block_sum(acc2, red);
+            if (tid == 0) a.partials[2 * gridDim.x + blockIdx.x] = s2v;
+        }
+    }
+}
+
+int launch_spmv_dict(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s)
+{
+    switch (mode) {
+    case kSpmvPlain:
+        hipLaunchKernelGGL(spmv_dict_kernel<kSpmvPlain>, dim3(grid), dim3(kBlock), 0, s, A, a);
+        break;
+    case kSpmvDot:
+        hipLaunchKernelGGL(spmv_dict_kernel<kSpmvDot>, dim3(grid), dim3(kBlock), 0, s, A, a);
+        break;
+    case kSpmvResidInit:
+        hipLaunchKernelGGL(spmv_dict_kernel<kSpmvResidInit>, dim3(grid), dim3(kBlock), 0, s, A, a);
+        break;
+    case kSpmvResidDual:
+        hipLaunchKernelGGL(spmv_dict_kernel<kSpmvResidDual>, dim3(grid), dim3(kBlock), 0, s, A, a);
+        break;
+    default:
+        hipLaunchKernelGGL(spmv_dict_kernel<kSpmvResidNorm>, dim3(grid), dim3(kBlock), 0, s, A, a);
+        break;
+    }
+    SCHWZ_HIP_TRY(hipGetLastError());
+    return SCHWZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host: build the coding
+// ---------------------------------------------------------------------------------------------
+
+namespace {
+
+template <typename T>
+int up(const std::vector<T> &h, void **d, size_t pad = 0)
+{
+    *d = nullptr;
+    SCHWZ_HIP_TRY(hipMalloc(d, (h.size() + pad ? h.size() + pad : 1) * sizeof(T)));
+    if (!h.empty()) SCHWZ_HIP_TRY(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    if (pad) SCHWZ_HIP_TRY(hipMemset((char *)*d + h.size() * sizeof(T), 0, pad * sizeof(T)));
+    return SCHWZ_OK;
+}
+
+// small open-addressing map from a 64-bit key to a code < 256, reset per tile
+struct TinyMap {
+    uint64_t key[512];
+    int16_t code[512];
+    int used[256];
+    int n = 0;
+    TinyMap() { std::memset(code, -1, sizeof(code)); }
+    void reset()
+    {
+        for (int i = 0; i < n; ++i) code[used[i]] = -1;
+        n = 0;
+    }
+    // returns the code, or -1 when a 257th distinct key arrives
+    int get(uint64_t k)
+    {
+        uint64_t h = k * 0x9E3779B97F4A7C15ull;
+        int slot = (int)(h >> 55);  // 9 bits
+        while (code[slot] >= 0) {
+            if (key[slot] == k) return code[slot];
+            slot = (slot + 1) & 511;
+        }
+        if (n == kDictMax) return -1;
+        key[slot] = k;
+        code[slot] = (int16_t)n;
+        used[n] = slot;
+        return n++;
+    }
+};
+
+}  // namespace
+
+int build_spmv_dict(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, const double *val,
+                    const std::vector<schwz_idx> &tiles)
+{
+    const char *env = std::getenv("SCHWZ_SPMV_DICT");
+    if (env && env[0] == '0') return SCHWZ_OK;
+    const int ntiles = (int)tiles.size() - 1;
+    const int64_t nnz = rp[tiles.back()];
+    if (ntiles == 0 || nnz == 0) return SCHWZ_OK;
+    std::vector<uint16_t> code((size_t)nnz, 0);
+    std::vector<schwz_idx> vptr((size_t)ntiles + 1, 0), dptr((size_t)ntiles + 1, 0);
+    std::vector<double> vdata;
+    std::vector<schwz_idx> ddata;
+    std::vector<double> tv;
+    std::vector<schwz_idx> td;
+    TinyMap vm, dm;
+    int64_t coded = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        const schwz_idx r0 = tiles[(size_t)t], r1 = tiles[(size_t)t + 1];
+        const int64_t s = rp[r0], e = rp[r1];
+        // the kernel stages the codes of the 8-byte aligned window [s & ~3, e) : 2048 at most
+        bool ok = e > s && (s & 3) + (e - s) <= kTileNnz;
+        vm.reset();
+        dm.reset();
+        tv.clear();
+        td.clear();
+        if (ok) {
+            for (schwz_idx r = r0; r < r1 && ok; ++r) {
+                for (int64_t j = rp[r]; j < rp[r + 1]; ++j) {
+                    uint64_t bits;
+                    std::memcpy(&bits, &val[j], 8);
+                    const int before_v = vm.n, before_d = dm.n;
+                    const int cv = vm.get(bits);
+                    const int cdv = dm.get((uint64_t)(int64_t)(col[j] - r));
+                    if (cv < 0 || cdv < 0) {
+                        ok = false;
+                        break;
+                    }
+                    if (vm.n > before_v) tv.push_back(val[j]);
+                    if (dm.n > before_d) td.push_back(col[j] - r);
+                    code[(size_t)j] = (uint16_t)(cv | (cdv << 8));
+                }
+            }
+        }
+        if (!ok) {
+            vptr[(size_t)t + 1] = vptr[(size_t)t];
+            dptr[(size_t)t + 1] = dptr[(size_t)t];
+            continue;
+        }
+        coded += e - s;
+        vdata.insert(vdata.end(), tv.begin(), tv.end());
+        ddata.insert(ddata.end(), td.begin(), td.end());
+        vptr[(size_t)t + 1] = (schwz_idx)vdata.size();
+        dptr[(size_t)t + 1] = (schwz_idx)ddata.size();
+    }
+    A->dict_fraction = (double)coded / (double)nnz;
+    // worth it only when (nearly) the whole matrix is coded; SCHWZ_SPMV_DICT=2 forces it (tests)
+    if (A->dict_fraction < 0.9 && !(env && env[0] == '2')) return SCHWZ_OK;
+    int rc;
+    if ((rc = up(code, &A->d_code, 8)) || (rc = up(vptr, &A->d_vptr)) || (rc = up(dptr, &A->d_dptr)) ||
+        (rc = up(vdata, &A->d_vdict)) || (rc = up(ddata, &A->d_ddict))) {
+        free_spmv_dict(A);
+        return rc;
+    }
+    A->v.code = (const uint16_t *)A->d_code;
+    A->v.vdict_ptr = (const schwz_idx *)A->d_vptr;
+    A->v.ddict_ptr = (const schwz_idx *)A->d_dptr;
+    A->v.vdict = (const double *)A->d_vdict;
+    A->v.ddict = (const schwz_idx *)A->d_ddict;
+    return SCHWZ_OK;
+}
+
+void free_spmv_dict(schwz_csr *A)
+{
+    void *ptrs[] = {A->d_code, A->d_vptr, A->d_dptr, A->d_vdict, A->d_ddict};
+    for (void *p : ptrs) (void)hipFree(p);
+    A->d_code = A->d_vptr = A->d_dptr = A->d_vdict = A->d_ddict = nullptr;
+    A->v.code = nullptr;
+}
+
+}  // namespace schwz

@@ -57,7 +57,7 @@ def _ragged_matrix(rng, n, max_len, long_row=None):
     return rp, col, val
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("case", ["lap2d", "lap3d", "ragged", "longrow", "tiny"])
 def test_spmv_matches_oracle(schwz, oracle, torch_cuda, case, variant):
     torch = torch_cuda
@@ -209,3 +209,52 @@ def test_spmv_with_forced_tile_order(schwz, oracle, torch_cuda, case, monkeypatc
     assert np.array_equal(ys[0], ys[1])
     exp = oracle.spmv(rp, col, val, x.cpu().numpy())
     assert np.abs(ys[1] - exp).max() <= 1e-12 * max(np.abs(exp).max(), 1.0)
+
+
+def _mixed_matrix(oracle, rng):
+    """Laplacian rows (few distinct values/offsets -> dictionary tiles), then rows with random
+    values (raw tiles), one row longer than a tile, empty rows."""
+    rp1, col1, val1 = oracle.laplacian3d(20, 15, 12)
+    n1 = len(rp1) - 1
+    rp2, col2, val2 = _ragged_matrix(rng, 3000, 20, long_row=2500)
+    n = n1 + 3000
+    rp = np.concatenate([rp1, rp1[-1] + rp2[1:]]).astype(np.int32)
+    col = np.concatenate([col1, col2 + rng.integers(0, n1)]).astype(np.int32) % n
+    # keep columns sorted within the random rows
+    for i in range(n1, n):
+        col[rp[i]:rp[i + 1]] = np.sort(col[rp[i]:rp[i + 1]])
+    val = np.concatenate([val1, val2])
+    return rp, col, val
+
+
+def test_dictionary_tiles_are_bit_identical_to_plain_csr(schwz, oracle, torch_cuda, monkeypatch):
+    """Variant 0 (dictionary-coded tiles where possible, raw tiles elsewhere) vs variant 6 (plain
+    CSR): the same products summed in the same order => identical bits, for every epilogue the
+    PCG uses (checked through a short solve) and for the plain product."""
+    torch = torch_cuda
+    rng = np.random.default_rng(21)
+    monkeypatch.setenv("SCHWZ_SPMV_DICT", "2")  # code whatever can be coded, whatever the share
+    rp, col, val = _mixed_matrix(oracle, rng)
+    n = len(rp) - 1
+    A = schwz.Csr(rp, col, val)
+    x = _dev(torch, rng.standard_normal(n))
+    y0, y6 = torch.zeros(n, dtype=torch.float64, device="cuda"), torch.zeros(n, dtype=torch.float64, device="cuda")
+    A.spmv(x.data_ptr(), y0.data_ptr(), 1.0, 0.0, 0)
+    A.spmv(x.data_ptr(), y6.data_ptr(), 1.0, 0.0, 6)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y6)
+    exp = oracle.spmv(rp, col, val, x.cpu().numpy())
+    assert np.abs(y0.cpu().numpy() - exp).max() <= 1e-12 * max(np.abs(exp).max(), 1.0)
+    # a matrix that is entirely dictionary coded: CG trajectories must coincide bit for bit
+    rp, col, val = oracle.laplacian3d(33, 21, 17)
+    n = len(rp) - 1
+    b = rng.standard_normal(n)
+    sols = []
+    for dict_env in ("1", "0"):
+        monkeypatch.setenv("SCHWZ_SPMV_DICT", dict_env)
+        A = schwz.Csr(rp, col, val)
+        cg = schwz.Pcg(A, 1)
+        d_b, d_x = _dev(torch, b), torch.zeros(n, dtype=torch.float64, device="cuda")
+        it, rn = cg.solve(d_b.data_ptr(), d_x.data_ptr(), 0.0, 25)
+        sols.append((d_x.cpu().numpy(), rn))
+    assert np.array_equal(sols[0][0], sols[1][0]) and sols[0][1] == sols[1][1]

@@ -31,7 +31,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--reps", type=int, default=20)
-    ap.add_argument("--variants", default="0,4")
+    ap.add_argument("--variants", default="0,6")
     ap.add_argument("--only-spmv", action="store_true")
     a = ap.parse_args()
     import torch
@@ -67,7 +67,7 @@ def main():
                           "alg_GB/s": A.algorithmic_bytes() / ms / 1e6,
                           "frac_of_8TBs": A.algorithmic_bytes() / ms / 1e6 / 8000}))
     # one CG iteration cost by kernel class
-    for v in [int(t) for t in a.variants.split(",") if t not in ("1", "2")]:
+    for v in [int(t) for t in a.variants.split(",") if t not in ("1", "2", "3", "5")]:
         sd2 = S.Subdomain(prob, 1, 0, 2, S.partition_regular(prob.N, 1))
         import numpy as np
         sd2.to_device(np.ones(N), precond=S.capi.PRECOND_JACOBI, local_tol=0.0, local_max_iters=20,
