@@ -289,6 +289,8 @@ int schwz_ras_restrict(schwz_subdomain *sd, schwz_stream stream);
  * which: 0 = x~ (local_size_x+halo), 1 = b~ / local_solution (local_size_x),
  *        2 = y / init_guess (local_size_x), 3 = local_rhs (local_size_x) */
 int schwz_ras_vector(schwz_subdomain *sd, int which, double **d_ptr, int64_t *len);
+/* the HBM-resident local_matrix of the subdomain (borrowed handle, owned by sd) */
+int schwz_ras_local_csr(schwz_subdomain *sd, schwz_csr **out);
 /* copy x~[0:local_size] to the host (synchronous) -- the rank's piece of the
  * solution assembled in Solve::compute_residual_norm (solve.cpp:1025-1085) */
 int schwz_ras_get_interior(schwz_subdomain *sd, double *h_out, schwz_stream stream);

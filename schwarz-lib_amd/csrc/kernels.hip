@@ -27,6 +27,9 @@ namespace schwz {
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void spmv_tiled_kernel(CsrView A, SpmvArgs a)
 {
+    // every SpMV variant rounds each product before it is added (no FMA contraction), so
+    // that all variants -- and the sequential CPU oracle -- produce the same bits
+#pragma clang fp contract(off)
     __shared__ double prod[kTileNnz];
     __shared__ double red[4];
     if (MODE == kSpmvDot || MODE == kSpmvResidInit) {
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(kBlock) void spmv_tiled_kernel(CsrView A, SpmvArgs 
         } else {
             // a single row longer than a tile: the whole workgroup reduces it
             double part = 0.0;
-            for (int i = tid; i < cnt; i += kBlock) part += A.val[s + i] * a.x[A.col[s + i]];
+            for (int i = tid; i < cnt; i += kBlock) part += __dmul_rn(A.val[s + i], a.x[A.col[s + i]]);
             part = block_sum(part, red);
             row = r0;
             if (tid == 0) {
@@ -117,6 +120,9 @@ constexpr int kPairsPerLane = kTileNnz / (2 * kBlock);  // 4
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void spmv_tiled2_kernel(CsrView A, SpmvArgs a)
 {
+    // every SpMV variant rounds each product before it is added (no FMA contraction), so
+    // that all variants -- and the sequential CPU oracle -- produce the same bits
+#pragma clang fp contract(off)
     __shared__ double prod[kTileNnz + 2];
     __shared__ double red[4];
     if (MODE == kSpmvDot || MODE == kSpmvResidInit) {
@@ -217,8 +223,8 @@ __global__ __launch_bounds__(kBlock) void spmv_tiled2_kernel(CsrView A, SpmvArgs
             // a single long row: the whole workgroup reduces it
             double part = 0.0, part2 = 0.0;
             for (int i = tid; i < cnt; i += kBlock) {
-                part += A.val[s + i] * a.x[A.col[s + i]];
-                if (dual) part2 += A.val[s + i] * a.x2[A.col[s + i]];
+                part += __dmul_rn(A.val[s + i], a.x[A.col[s + i]]);
+                if (dual) part2 += __dmul_rn(A.val[s + i], a.x2[A.col[s + i]]);
             }
             part = block_sum(part, red);
             if (dual) part2 = block_sum(part2, red);
@@ -306,6 +312,9 @@ __device__ __forceinline__ TileDesc tile_desc(const CsrView &A, int xcd, int chu
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void spmv_pipe_kernel(CsrView A, SpmvArgs a)
 {
+    // every SpMV variant rounds each product before it is added (no FMA contraction), so
+    // that all variants -- and the sequential CPU oracle -- produce the same bits
+#pragma clang fp contract(off)
     __shared__ double prod[kTileNnz + 2];
     __shared__ double red[4];
     if (MODE == kSpmvDot || MODE == kSpmvResidInit) {
@@ -410,8 +419,8 @@ __global__ __launch_bounds__(kBlock) void spmv_pipe_kernel(CsrView A, SpmvArgs a
                 // a single long row: the whole workgroup reduces it
                 double part = 0.0, part2 = 0.0;
                 for (int i = tid; i < cnt; i += kBlock) {
-                    part += A.val[s + i] * a.x[A.col[s + i]];
-                    if (dual) part2 += A.val[s + i] * a.x2[A.col[s + i]];
+                    part += __dmul_rn(A.val[s + i], a.x[A.col[s + i]]);
+                    if (dual) part2 += __dmul_rn(A.val[s + i], a.x2[A.col[s + i]]);
                 }
                 part = block_sum(part, red);
                 if (dual) part2 = block_sum(part2, red);
@@ -605,6 +614,9 @@ constexpr int kWavePairs = kWaveTileNnz / 128;  // 16-byte pairs per lane per ti
 template <int MODE, bool NT>
 __global__ __launch_bounds__(kBlock) void spmv_wave_kernel(CsrView A, SpmvArgs a)
 {
+    // every SpMV variant rounds each product before it is added (no FMA contraction), so
+    // that all variants -- and the sequential CPU oracle -- produce the same bits
+#pragma clang fp contract(off)
     __shared__ double prod_all[kBlock / 64][kWaveTileNnz + 2];
     __shared__ double red[4];
     if (MODE == kSpmvDot || MODE == kSpmvResidInit) {
@@ -664,7 +676,7 @@ __global__ __launch_bounds__(kBlock) void spmv_wave_kernel(CsrView A, SpmvArgs a
         } else {
             // a single row longer than a wave tile: the wave reduces it
             double part = 0.0;
-            for (int i = lane; i < cnt; i += 64) part += A.val[s + i] * a.x[A.col[s + i]];
+            for (int i = lane; i < cnt; i += 64) part += __dmul_rn(A.val[s + i], a.x[A.col[s + i]]);
             part = wave_sum(part);
             row = r0;
             if (lane == 0) {
@@ -707,6 +719,9 @@ __global__ __launch_bounds__(kBlock) void spmv_wave_kernel(CsrView A, SpmvArgs a
 // row-parallel CPU loop would do).  Only the plain mode.
 __global__ __launch_bounds__(kBlock) void spmv_rowlane_kernel(CsrView A, SpmvArgs a)
 {
+    // every SpMV variant rounds each product before it is added (no FMA contraction), so
+    // that all variants -- and the sequential CPU oracle -- produce the same bits
+#pragma clang fp contract(off)
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < A.nrows; row += stride) {
         double sum = 0.0;

@@ -32,7 +32,10 @@ constexpr int kChunk = 8;  // gathers issued back to back per lane
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void spmv_dict_kernel(CsrView A, SpmvArgs a)
 {
-    __shared__ uint16_t codes[kTileNnz + 8];
+    // every SpMV variant rounds each product before it is added (no FMA contraction), so
+    // that all variants -- and the sequential CPU oracle -- produce the same bits
+#pragma clang fp contract(off)
+    __shared__ __attribute__((aligned(16))) uint16_t codes[kTileNnz + 8];
     __shared__ double vdict[kDictMax];
     __shared__ int ddict[kDictMax];
     __shared__ double red[4];
@@ -94,9 +97,11 @@ __global__ __launch_bounds__(kBlock) void spmv_dict_kernel(CsrView A, SpmvArgs a
                     }
 #pragma unroll
                     for (int k = 0; k < kChunk; ++k) {
+                        // product rounded on its own (no FMA contraction): the plain CSR
+                        // kernels round it when they stage it in LDS, and the two must agree
                         if (j + k < b1) {
-                            sum += v[k] * xg[k];
-                            if (dual) sum2 += v[k] * xg2[k];
+                            sum += __dmul_rn(v[k], xg[k]);
+                            if (dual) sum2 += __dmul_rn(v[k], xg2[k]);
                         }
                     }
                 }
@@ -108,16 +113,16 @@ __global__ __launch_bounds__(kBlock) void spmv_dict_kernel(CsrView A, SpmvArgs a
                 for (int j = A.rp[row]; j < A.rp[row + 1]; ++j) {
                     const double vv = A.val[j];
                     const int cc = A.col[j];
-                    sum += vv * a.x[cc];
-                    if (dual) sum2 += vv * a.x2[cc];
+                    sum += __dmul_rn(vv, a.x[cc]);
+                    if (dual) sum2 += __dmul_rn(vv, a.x2[cc]);
                 }
             }
         } else {
             // ---- a single long row: the whole workgroup reduces it ------------------------------
             double part = 0.0, part2 = 0.0;
             for (int i = s + tid; i < e; i += kBlock) {
-                part += A.val[i] * a.x[A.col[i]];
-                if (dual) part2 += A.val[i] * a.x2[A.col[i]];
+                part += __dmul_rn(A.val[i], a.x[A.col[i]]);
+                if (dual) part2 += __dmul_rn(A.val[i], a.x2[A.col[i]]);
             }
             sum = block_sum(part, red);
             if (dual) sum2 = block_sum(part2, red);

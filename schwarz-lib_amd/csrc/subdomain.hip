@@ -282,6 +282,14 @@ int schwz_ras_vector(schwz_subdomain *sd, int which, double **d_ptr, int64_t *le
     return SCHWZ_OK;
 }
 
+int schwz_ras_local_csr(schwz_subdomain *sd, schwz_csr **out)
+{
+    REQUIRE_DEVICE(sd, "schwz_ras_local_csr");
+    SCHWZ_REQUIRE(out, "schwz_ras_local_csr: null output");
+    *out = sd->A;
+    return SCHWZ_OK;
+}
+
 int schwz_ras_get_interior(schwz_subdomain *sd, double *h_out, schwz_stream stream)
 {
     REQUIRE_DEVICE(sd, "schwz_ras_get_interior");

@@ -44,7 +44,7 @@ SYMBOLS = [
     "schwz_subdomain_to_device", "schwz_ras_pack", "schwz_ras_unpack",
     "schwz_ras_update_boundary", "schwz_ras_local_residual", "schwz_ras_local_residual_launch",
     "schwz_ras_local_residual_wait", "schwz_ras_local_solve", "schwz_ras_check_and_solve_launch",
-    "schwz_ras_restrict", "schwz_ras_vector", "schwz_ras_get_interior",
+    "schwz_ras_restrict", "schwz_ras_vector", "schwz_ras_local_csr", "schwz_ras_get_interior",
     "schwz_ras_true_residual_sq", "schwz_ras_algorithmic_bytes",
 ]
 
@@ -144,6 +144,7 @@ _sig("schwz_ras_check_and_solve_launch", i32, [vp, vp])
 _sig("schwz_ras_local_solve", i32, [vp, C.POINTER(C.c_int), vp])
 _sig("schwz_ras_restrict", i32, [vp, vp])
 _sig("schwz_ras_vector", i32, [vp, i32, pvp, C.POINTER(i64)])
+_sig("schwz_ras_local_csr", i32, [vp, pvp])
 _sig("schwz_ras_get_interior", i32, [vp, vp, vp])
 _sig("schwz_ras_true_residual_sq", i32, [vp, C.POINTER(dbl), vp])
 _sig("schwz_ras_algorithmic_bytes", i64, [vp, i32])

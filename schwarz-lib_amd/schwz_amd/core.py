@@ -54,7 +54,7 @@ class Csr:
         return 12 * self.nnz + 4 * (self.nrows + 1) + 16 * self.nrows
 
     def close(self):
-        if self.h:
+        if self.h and lib is not None:
             lib.schwz_csr_destroy(self.h)
             self.h = None
 
@@ -80,7 +80,7 @@ class Pcg:
         return it.value, rn.value
 
     def close(self):
-        if self.h:
+        if self.h and lib is not None:
             lib.schwz_pcg_destroy(self.h)
             self.h = None
 
@@ -104,7 +104,7 @@ class Trs:
         check(lib.schwz_trs_solve(self.h, ptr(d_b), ptr(d_y), _stream_arg(stream)))
 
     def close(self):
-        if self.h:
+        if self.h and lib is not None:
             lib.schwz_trs_destroy(self.h)
             self.h = None
 
@@ -215,7 +215,7 @@ class Problem:
         return part
 
     def close(self):
-        if self.h:
+        if self.h and lib is not None:
             lib.schwz_problem_destroy(self.h)
             self.h = None
 
@@ -385,7 +385,7 @@ class Subdomain:
         return int(lib.schwz_ras_algorithmic_bytes(self.h, which))
 
     def close(self):
-        if self.h:
+        if self.h and lib is not None:
             lib.schwz_subdomain_destroy(self.h)
             self.h = None
 

@@ -21,7 +21,7 @@ import shutil
 import sys
 from collections import defaultdict
 
-DOMINANT = "spmv_tiled2_kernel<1>"
+DOMINANT = ("spmv_dict_kernel<1>", "spmv_tiled2_kernel<1>")  # first one present wins
 
 
 def read_counter(dirname, counter):
@@ -57,12 +57,17 @@ def main():
             entry["hbm_GBs"] = entry["hbm_bytes_per_launch"] / entry["avg_ns"]
         summary[name] = entry
     json.dump(summary, open(os.path.join(out, tag + "_summary.json"), "w"), indent=1, sort_keys=True)
-    dom = [v for k, v in summary.items() if DOMINANT in k]
+    dom, dom_name = [], None
+    for name in DOMINANT:
+        dom = [v for k, v in summary.items() if name in k]
+        if dom:
+            dom_name = name
+            break
     if dom and "hbm_bytes_per_launch" in dom[0]:
         tpath = os.path.join(out, "traffic.json")
         tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
         key = sys.argv[3] if len(sys.argv) > 3 else "256x256x256"
-        tj[key] = dict(kernel=DOMINANT, hbm_bytes_per_launch=dom[0]["hbm_bytes_per_launch"],
+        tj[key] = dict(kernel=dom_name, hbm_bytes_per_launch=dom[0]["hbm_bytes_per_launch"],
                        avg_ns=dom[0]["avg_ns"], source=tag + "_summary.json",
                        note="(2*FETCH_SIZE + WRITE_SIZE) KiB per launch, separate --pmc passes")
         json.dump(tj, open(tpath, "w"), indent=1, sort_keys=True)
