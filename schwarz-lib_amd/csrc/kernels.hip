@@ -742,7 +742,7 @@ int spmv_grid(const CsrView &A, int variant)
 int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipStream_t s)
 {
     if (A.nrows == 0) return SCHWZ_OK;
-    if (mode == kSpmvResidDual && variant != 0 && variant != 4 && variant != 6) {
+    if (mode == kSpmvResidDual && variant != 0 && variant != 4 && variant != 6 && variant != 7) {
         set_error("launch_spmv: the fused dual-residual mode exists for variants 0, 4 and 6 only");
         return SCHWZ_ERR_INVALID;
     }
@@ -762,7 +762,8 @@ int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipS
         hipLaunchKernelGGL((spmv_wave_kernel<kSpmvResidNorm, NTV>), dim3(wgrid), dim3(kBlock), 0, s, A, a); \
         break;                                                                                         \
     }
-    if (variant == 0 && A.code) return launch_spmv_dict(A, mode, a, grid, s);
+    if (variant == 0 && A.pat_id) return launch_spmv_pattern(A, mode, a, grid, s);
+    if ((variant == 0 || variant == 7) && A.code) return launch_spmv_dict(A, mode, a, grid, s);
     if (variant >= 10 && variant < 74 && mode == kSpmvPlain) {
         switch (variant - 10) {
 #define SCHWZ_ABL(W) \

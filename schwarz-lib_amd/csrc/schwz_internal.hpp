@@ -60,6 +60,14 @@ struct CsrView {
     const schwz_idx *ddict_ptr = nullptr;   // ntiles+1
     const double *vdict = nullptr;
     const schwz_idx *ddict = nullptr;
+    // row-pattern coding (spmv_dict.hip): one byte per row selects a (values, col - row offsets)
+    // pattern from a small table shared by many tiles
+    const uint8_t *pat_id = nullptr;        // nrows
+    const schwz_idx *tile_table = nullptr;  // ntiles: table id, -1 = tile not pattern coded
+    const schwz_idx *tbl_desc = nullptr;    // per table: {entry offset, len offset, npat, lmax}
+    const uint8_t *tbl_len = nullptr;       // pattern lengths, concatenated
+    const double *tbl_val = nullptr;        // [npat][lmax] per table, concatenated
+    const schwz_idx *tbl_delta = nullptr;
 };
 
 // epilogues of the tiled SpMV kernel
@@ -91,6 +99,7 @@ struct SpmvArgs {
 int spmv_grid(const CsrView &A, int variant);
 int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipStream_t s);
 int launch_spmv_dict(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s);
+int launch_spmv_pattern(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s);
 
 // device-side CG scalar state
 struct CgState {
@@ -124,7 +133,10 @@ struct schwz_csr {
     schwz::CsrView v;
     void *d_rp = nullptr, *d_col = nullptr, *d_val = nullptr, *d_tile = nullptr, *d_wtile = nullptr, *d_order = nullptr;
     void *d_code = nullptr, *d_vptr = nullptr, *d_dptr = nullptr, *d_vdict = nullptr, *d_ddict = nullptr;
+    void *d_pat_id = nullptr, *d_tile_table = nullptr, *d_tbl_desc = nullptr, *d_tbl_len = nullptr, *d_tbl_val = nullptr,
+         *d_tbl_delta = nullptr;
     double dict_fraction = 0.0;  // share of the nonzeros that are dictionary coded
+    double pattern_fraction = 0.0;  // share of the nonzeros in row-pattern coded tiles
 };
 
 struct schwz_pcg {

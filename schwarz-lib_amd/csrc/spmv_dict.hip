@@ -238,11 +238,329 @@ struct TinyMap {
 
 }  // namespace
 
+// =============================================================================================
+// Row-pattern coding: the second level of the same idea.  In a stencil-like matrix almost every
+// row of a tile is one of a few (values, col - row offsets) sequences; coding the SEQUENCE costs
+// one byte per ROW.  A tile's table of <= 64 patterns (<= 1024 entries) is staged in LDS, and
+// because most tiles share one table (tables are de-duplicated at build time) a workgroup
+// reloads it only when the table id changes -- the row loop then runs without any barrier:
+// per row 1 byte of matrix, the coalesced x gathers, 8 bytes of y.  Summation order is the
+// row's entry order, products rounded individually: bit-identical to the CSR kernels again.
+// =============================================================================================
+
+constexpr int kPatMax = 64;       // patterns per table
+constexpr int kPatEntries = 1024;  // entries per table (npat * lmax)
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void spmv_pattern_kernel(CsrView A, SpmvArgs a)
+{
+#pragma clang fp contract(off)
+    __shared__ double pval[kPatEntries];
+    __shared__ int pdelta[kPatEntries];
+    __shared__ int plen[kPatMax];
+    __shared__ double red[4];
+    if (MODE == kSpmvDot || MODE == kSpmvResidInit) {
+        if (a.stop_iter && a.it >= *a.stop_iter) return;
+    }
+    const int tid = threadIdx.x;
+    const int xcd = blockIdx.x % kXcds;
+    const int slot = blockIdx.x / kXcds;
+    const int per_xcd = gridDim.x / kXcds;
+    const int chunk = xcd_slots(A);
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+    const bool dual = (MODE == kSpmvResidDual) && a.x2 != nullptr;
+    int cached = -1, lmax = 0;
+
+    for (int t = slot; t < chunk; t += per_xcd) {
+        const int tile = xcd_tile(A, xcd, t);
+        if (tile < 0) continue;
+        const int r0 = A.tile_row[tile], r1 = A.tile_row[tile + 1];
+        const int tb = A.tile_table[tile];
+        const int row = r0 + tid;
+        const bool have_row = (r1 - r0 > 1) ? row < r1 : tid == 0;
+        double sum = 0.0, sum2 = 0.0;
+        if (tb >= 0) {
+            if (tb != cached) {  // workgroup-uniform
+                const int eoff = A.tbl_desc[4 * tb], loff = A.tbl_desc[4 * tb + 1];
+                const int npat = A.tbl_desc[4 * tb + 2];
+                lmax = A.tbl_desc[4 * tb + 3];
+                lds_barrier();  // everyone is done with the previous table
+                for (int i = tid; i < npat * lmax; i += kBlock) {
+                    pval[i] = A.tbl_val[eoff + i];
+                    pdelta[i] = A.tbl_delta[eoff + i];
+                }
+                if (tid < npat) plen[tid] = A.tbl_len[loff + tid];
+                lds_barrier();
+                cached = tb;
+            }
+            if (row < r1) {
+                const int pid = A.pat_id[row];
+                const int len = plen[pid];
+                const int base = pid * lmax;
+                for (int j = 0; j < len; j += kChunk) {
+                    double v[kChunk], xg[kChunk], xg2[kChunk];
+                    int c[kChunk];
+                    const int jl = base + len - 1;
+#pragma unroll
+                    for (int k = 0; k < kChunk; ++k) {
+                        const int q = min(base + j + k, jl);
+                        v[k] = pval[q];
+                        c[k] = row + pdelta[q];
+                    }
+#pragma unroll
+                    for (int k = 0; k < kChunk; ++k) xg[k] = a.x[c[k]];
+                    if (dual) {
+#pragma unroll
+                        for (int k = 0; k < kChunk; ++k) xg2[k] = a.x2[c[k]];
+                    }
+#pragma unroll
+                    for (int k = 0; k < kChunk; ++k) {
+                        if (j + k < len) {
+                            sum += v[k] * xg[k];
+                            if (dual) sum2 += v[k] * xg2[k];
+                        }
+                    }
+                }
+            }
+        } else if (r1 - r0 > 1) {
+            // tile without a pattern table: one lane per row straight from val/col
+            if (row < r1) {
+                for (int j = A.rp[row]; j < A.rp[row + 1]; ++j) {
+                    const double vv = A.val[j];
+                    const int cc = A.col[j];
+                    sum += vv * a.x[cc];
+                    if (dual) sum2 += vv * a.x2[cc];
+                }
+            }
+        } else {
+            // a single long row: the whole workgroup reduces it
+            const int s = A.rp[r0], e = A.rp[r1];
+            double part = 0.0, part2 = 0.0;
+            for (int i = s + tid; i < e; i += kBlock) {
+                part += A.val[i] * a.x[A.col[i]];
+                if (dual) part2 += A.val[i] * a.x2[A.col[i]];
+            }
+            sum = block_sum(part, red);
+            if (dual) sum2 = block_sum(part2, red);
+        }
+        if (have_row) {
+            const int rw = (r1 - r0 > 1) ? row : r0;
+            if (MODE == kSpmvPlain) {
+                a.y[rw] = (a.beta == 0.0) ? a.alpha * sum : a.alpha * sum + a.beta * a.y[rw];
+            } else if (MODE == kSpmvDot) {
+                a.y[rw] = sum;
+                acc0 += a.x[rw] * sum;
+            } else if (MODE == kSpmvResidInit || MODE == kSpmvResidDual) {
+                const double bb = a.b[rw];
+                const double r = bb - sum;
+                const double z = a.dinv ? a.dinv[rw] * r : r;
+                a.y[rw] = r;
+                a.p[rw] = z;
+                acc0 += r * z;
+                acc1 += r * r;
+                if (MODE == kSpmvResidDual && rw < a.row_limit) {
+                    const double r2 = dual ? bb - sum2 : r;
+                    acc2 += r2 * r2;
+                }
+            } else {  // kSpmvResidNorm
+                if (rw < a.row_limit) {
+                    const double r = a.b[rw] - sum;
+                    acc1 += r * r;
+                }
+            }
+        }
+    }
+    if (MODE != kSpmvPlain) {
+        const double s0 = block_sum(acc0, red);
+        const double s1 = block_sum(acc1, red);
+        if (tid == 0) {
+            a.partials[blockIdx.x] = s0;
+            a.partials[gridDim.x + blockIdx.x] = s1;
+        }
+        if (MODE == kSpmvResidDual) {
+            const double s2v = block_sum(acc2, red);
+            if (tid == 0) a.partials[2 * gridDim.x + blockIdx.x] = s2v;
+        }
+    }
+}
+
+int launch_spmv_pattern(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s)
+{
+    switch (mode) {
+    case kSpmvPlain:
+        hipLaunchKernelGGL(spmv_pattern_kernel<kSpmvPlain>, dim3(grid), dim3(kBlock), 0, s, A, a);
+        break;
+    case kSpmvDot:
+        hipLaunchKernelGGL(spmv_pattern_kernel<kSpmvDot>, dim3(grid), dim3(kBlock), 0, s, A, a);
+        break;
+    case kSpmvResidInit:
+        hipLaunchKernelGGL(spmv_pattern_kernel<kSpmvResidInit>, dim3(grid), dim3(kBlock), 0, s, A, a);
+        break;
+    case kSpmvResidDual:
+        hipLaunchKernelGGL(spmv_pattern_kernel<kSpmvResidDual>, dim3(grid), dim3(kBlock), 0, s, A, a);
+        break;
+    default:
+        hipLaunchKernelGGL(spmv_pattern_kernel<kSpmvResidNorm>, dim3(grid), dim3(kBlock), 0, s, A, a);
+        break;
+    }
+    SCHWZ_HIP_TRY(hipGetLastError());
+    return SCHWZ_OK;
+}
+
+namespace {
+
+struct RowPat {
+    std::vector<uint64_t> bits;
+    std::vector<schwz_idx> delta;
+    bool operator==(const RowPat &o) const { return bits == o.bits && delta == o.delta; }
+};
+
+struct Table {
+    int npat = 0, lmax = 0;
+    std::vector<uint8_t> len;
+    std::vector<double> val;       // [npat][lmax]
+    std::vector<schwz_idx> delta;  // [npat][lmax]
+    uint64_t hash = 0;
+    bool same(const Table &o) const
+    {
+        return npat == o.npat && lmax == o.lmax && len == o.len && delta == o.delta &&
+               std::memcmp(val.data(), o.val.data(), val.size() * sizeof(double)) == 0;
+    }
+};
+
+}  // namespace
+
+// Returns SCHWZ_OK; leaves A->v.pat_id null when the coding does not cover >= 90 % of the
+// nonzeros (SCHWZ_SPMV_PATTERN=0 disables, =2 forces whatever the coverage).
+static int build_spmv_pattern(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, const double *val,
+                              const std::vector<schwz_idx> &tiles)
+{
+    const char *env = std::getenv("SCHWZ_SPMV_PATTERN");
+    if (env && env[0] == '0') return SCHWZ_OK;
+    const int ntiles = (int)tiles.size() - 1;
+    const int64_t nrows = tiles.back(), nnz = rp[nrows];
+    if (ntiles == 0 || nnz == 0) return SCHWZ_OK;
+    std::vector<uint8_t> pat_id((size_t)nrows, 0);
+    std::vector<schwz_idx> tile_table((size_t)ntiles, -1);
+    std::vector<Table> tables;
+    std::unordered_multimap<uint64_t, int> by_hash;
+    std::vector<RowPat> pats;
+    int64_t coded = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        const schwz_idx r0 = tiles[(size_t)t], r1 = tiles[(size_t)t + 1];
+        if (rp[r1] == rp[r0] || (r1 - r0 == 1 && rp[r1] - rp[r0] > kTileNnz - 2)) continue;
+        pats.clear();
+        int lmax = 0;
+        bool ok = true;
+        for (schwz_idx r = r0; r < r1 && ok; ++r) {
+            RowPat p;
+            const int len = rp[r + 1] - rp[r];
+            if (len > 255) {
+                ok = false;
+                break;
+            }
+            p.bits.resize((size_t)len);
+            p.delta.resize((size_t)len);
+            for (int k = 0; k < len; ++k) {
+                std::memcpy(&p.bits[(size_t)k], &val[rp[r] + k], 8);
+                p.delta[(size_t)k] = col[rp[r] + k] - r;
+            }
+            int id = -1;
+            for (size_t q = 0; q < pats.size(); ++q)
+                if (pats[q] == p) {
+                    id = (int)q;
+                    break;
+                }
+            if (id < 0) {
+                if ((int)pats.size() == kPatMax) {
+                    ok = false;
+                    break;
+                }
+                id = (int)pats.size();
+                lmax = std::max(lmax, len);
+                pats.push_back(std::move(p));
+            }
+            pat_id[(size_t)r] = (uint8_t)id;
+        }
+        if (!ok || (int64_t)pats.size() * std::max(lmax, 1) > kPatEntries) continue;
+        Table tb;
+        tb.npat = (int)pats.size();
+        tb.lmax = std::max(lmax, 1);
+        tb.len.resize((size_t)tb.npat);
+        tb.val.assign((size_t)tb.npat * tb.lmax, 0.0);
+        tb.delta.assign((size_t)tb.npat * tb.lmax, 0);
+        uint64_t h = 1469598103934665603ull;
+        for (int q = 0; q < tb.npat; ++q) {
+            tb.len[(size_t)q] = (uint8_t)pats[(size_t)q].bits.size();
+            for (size_t k = 0; k < pats[(size_t)q].bits.size(); ++k) {
+                std::memcpy(&tb.val[(size_t)q * tb.lmax + k], &pats[(size_t)q].bits[k], 8);
+                tb.delta[(size_t)q * tb.lmax + k] = pats[(size_t)q].delta[k];
+                h = (h ^ pats[(size_t)q].bits[k]) * 1099511628211ull;
+                h = (h ^ (uint64_t)(int64_t)pats[(size_t)q].delta[k]) * 1099511628211ull;
+            }
+            h = (h ^ 0xffull ^ (uint64_t)tb.len[(size_t)q]) * 1099511628211ull;
+        }
+        tb.hash = h;
+        int id = -1;
+        auto range = by_hash.equal_range(h);
+        for (auto it = range.first; it != range.second; ++it)
+            if (tables[(size_t)it->second].same(tb)) {
+                id = it->second;
+                break;
+            }
+        if (id < 0) {
+            id = (int)tables.size();
+            by_hash.emplace(h, id);
+            tables.push_back(std::move(tb));
+        }
+        tile_table[(size_t)t] = id;
+        coded += rp[r1] - rp[r0];
+    }
+    A->pattern_fraction = (double)coded / (double)nnz;
+    if (A->pattern_fraction < 0.9 && !(env && env[0] == '2')) return SCHWZ_OK;
+    // a table pays off only when it is shared: with one table per tile the "coding" is just the
+    // raw data in another layout
+    if (tables.size() * 4 > (size_t)ntiles && !(env && env[0] == '2')) return SCHWZ_OK;
+    std::vector<schwz_idx> desc;
+    std::vector<uint8_t> lens;
+    std::vector<double> vals;
+    std::vector<schwz_idx> deltas;
+    for (const Table &tb : tables) {
+        desc.push_back((schwz_idx)vals.size());
+        desc.push_back((schwz_idx)lens.size());
+        desc.push_back(tb.npat);
+        desc.push_back(tb.lmax);
+        lens.insert(lens.end(), tb.len.begin(), tb.len.end());
+        vals.insert(vals.end(), tb.val.begin(), tb.val.end());
+        deltas.insert(deltas.end(), tb.delta.begin(), tb.delta.end());
+    }
+    int rc;
+    if ((rc = up(pat_id, &A->d_pat_id)) || (rc = up(tile_table, &A->d_tile_table)) || (rc = up(desc, &A->d_tbl_desc)) ||
+        (rc = up(lens, &A->d_tbl_len)) || (rc = up(vals, &A->d_tbl_val)) || (rc = up(deltas, &A->d_tbl_delta)))
+        return rc;
+    A->v.pat_id = (const uint8_t *)A->d_pat_id;
+    A->v.tile_table = (const schwz_idx *)A->d_tile_table;
+    A->v.tbl_desc = (const schwz_idx *)A->d_tbl_desc;
+    A->v.tbl_len = (const uint8_t *)A->d_tbl_len;
+    A->v.tbl_val = (const double *)A->d_tbl_val;
+    A->v.tbl_delta = (const schwz_idx *)A->d_tbl_delta;
+    return SCHWZ_OK;
+}
+
 int build_spmv_dict(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, const double *val,
                     const std::vector<schwz_idx> &tiles)
 {
+    {
+        int rc = build_spmv_pattern(A, rp, col, val, tiles);
+        if (rc) {
+            free_spmv_dict(A);
+            return rc;
+        }
+    }
     const char *env = std::getenv("SCHWZ_SPMV_DICT");
     if (env && env[0] == '0') return SCHWZ_OK;
+    // the row-pattern coding supersedes the per-entry one unless that is forced too
+    if (A->v.pat_id && !(env && env[0] == '2')) return SCHWZ_OK;
     const int ntiles = (int)tiles.size() - 1;
     const int64_t nnz = rp[tiles.back()];
     if (ntiles == 0 || nnz == 0) return SCHWZ_OK;
@@ -311,10 +629,13 @@ int build_spmv_dict(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, con
 
 void free_spmv_dict(schwz_csr *A)
 {
-    void *ptrs[] = {A->d_code, A->d_vptr, A->d_dptr, A->d_vdict, A->d_ddict};
+    void *ptrs[] = {A->d_code, A->d_vptr, A->d_dptr, A->d_vdict, A->d_ddict, A->d_pat_id, A->d_tile_table,
+                    A->d_tbl_desc, A->d_tbl_len, A->d_tbl_val, A->d_tbl_delta};
     for (void *p : ptrs) (void)hipFree(p);
     A->d_code = A->d_vptr = A->d_dptr = A->d_vdict = A->d_ddict = nullptr;
+    A->d_pat_id = A->d_tile_table = A->d_tbl_desc = A->d_tbl_len = A->d_tbl_val = A->d_tbl_delta = nullptr;
     A->v.code = nullptr;
+    A->v.pat_id = nullptr;
 }
 
 }  // namespace schwz

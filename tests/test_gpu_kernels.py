@@ -227,34 +227,39 @@ def _mixed_matrix(oracle, rng):
     return rp, col, val
 
 
-def test_dictionary_tiles_are_bit_identical_to_plain_csr(schwz, oracle, torch_cuda, monkeypatch):
-    """Variant 0 (dictionary-coded tiles where possible, raw tiles elsewhere) vs variant 6 (plain
-    CSR): the same products summed in the same order => identical bits, for every epilogue the
-    PCG uses (checked through a short solve) and for the plain product."""
+def test_coded_tiles_are_bit_identical_to_plain_csr(schwz, oracle, torch_cuda, monkeypatch):
+    """Variant 0 (row-pattern coded tiles), variant 7 (per-entry dictionary tiles) and variant 6
+    (plain CSR) sum the same individually rounded products in the same order => identical bits,
+    on a matrix that mixes codable tiles, raw tiles, a long row and empty rows, and for every
+    epilogue the PCG uses (checked through a short solve)."""
     torch = torch_cuda
     rng = np.random.default_rng(21)
-    monkeypatch.setenv("SCHWZ_SPMV_DICT", "2")  # code whatever can be coded, whatever the share
+    monkeypatch.setenv("SCHWZ_SPMV_DICT", "2")     # code whatever can be coded, whatever the share
+    monkeypatch.setenv("SCHWZ_SPMV_PATTERN", "2")
     rp, col, val = _mixed_matrix(oracle, rng)
     n = len(rp) - 1
     A = schwz.Csr(rp, col, val)
     x = _dev(torch, rng.standard_normal(n))
-    y0, y6 = torch.zeros(n, dtype=torch.float64, device="cuda"), torch.zeros(n, dtype=torch.float64, device="cuda")
-    A.spmv(x.data_ptr(), y0.data_ptr(), 1.0, 0.0, 0)
-    A.spmv(x.data_ptr(), y6.data_ptr(), 1.0, 0.0, 6)
+    ys = {}
+    for v in (0, 7, 6):
+        ys[v] = torch.zeros(n, dtype=torch.float64, device="cuda")
+        A.spmv(x.data_ptr(), ys[v].data_ptr(), 1.0, 0.0, v)
     torch.cuda.synchronize()
-    assert torch.equal(y0, y6)
+    assert torch.equal(ys[0], ys[6]) and torch.equal(ys[7], ys[6])
     exp = oracle.spmv(rp, col, val, x.cpu().numpy())
-    assert np.abs(y0.cpu().numpy() - exp).max() <= 1e-12 * max(np.abs(exp).max(), 1.0)
-    # a matrix that is entirely dictionary coded: CG trajectories must coincide bit for bit
+    assert np.abs(ys[0].cpu().numpy() - exp).max() <= 1e-12 * max(np.abs(exp).max(), 1.0)
+    # matrices that are entirely coded: CG trajectories must coincide bit for bit
     rp, col, val = oracle.laplacian3d(33, 21, 17)
     n = len(rp) - 1
     b = rng.standard_normal(n)
     sols = []
-    for dict_env in ("1", "0"):
+    for pat_env, dict_env in (("1", "1"), ("0", "1"), ("0", "0")):
+        monkeypatch.setenv("SCHWZ_SPMV_PATTERN", pat_env)
         monkeypatch.setenv("SCHWZ_SPMV_DICT", dict_env)
         A = schwz.Csr(rp, col, val)
         cg = schwz.Pcg(A, 1)
         d_b, d_x = _dev(torch, b), torch.zeros(n, dtype=torch.float64, device="cuda")
         it, rn = cg.solve(d_b.data_ptr(), d_x.data_ptr(), 0.0, 25)
         sols.append((d_x.cpu().numpy(), rn))
-    assert np.array_equal(sols[0][0], sols[1][0]) and sols[0][1] == sols[1][1]
+    for k in (1, 2):
+        assert np.array_equal(sols[0][0], sols[k][0]) and sols[0][1] == sols[k][1]

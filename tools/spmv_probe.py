@@ -31,7 +31,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--reps", type=int, default=20)
-    ap.add_argument("--variants", default="0,6")
+    ap.add_argument("--variants", default="0,7,6")
     ap.add_argument("--only-spmv", action="store_true")
     a = ap.parse_args()
     import torch
