@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <climits>
 #include <cstdlib>
+#include <cstring>
 
 #include "schwz_internal.hpp"
 #include "device_utils.hpp"
@@ -878,6 +879,30 @@ __device__ __forceinline__ void store2(double *base, int64_t i, vd2 v)
         reinterpret_cast<vd2 *>(base)[i] = v;
 }
 
+// 1/diag of rows 2i and 2i+1 in whichever representation the solver holds
+__device__ __forceinline__ vd2 diag_pair(const DiagView &dg, const vd2 *full2, const uint16_t *code2,
+                                         const double *ddict, int64_t i)
+{
+    vd2 d;
+    if (dg.mode == 1) {
+        d = full2[i];
+    } else if (dg.mode == 2) {
+        const unsigned c = code2[i];
+        d.x = ddict[c & 255u];
+        d.y = ddict[c >> 8];
+    } else {
+        d.x = d.y = dg.uniform;
+    }
+    return d;
+}
+
+__device__ __forceinline__ double diag_one(const DiagView &dg, const double *ddict, int64_t i)
+{
+    if (dg.mode == 1) return dg.full[i];
+    if (dg.mode == 2) return ddict[dg.code[i]];
+    return dg.uniform;
+}
+
 // x += alpha p ; r -= alpha q ; z = dinv r ; partials: r.z and r.r
 // U: 16-byte elements per lane in flight per trip; NT: non-temporal stores
 template <int U, bool NT>
@@ -885,13 +910,20 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, double *__
                                                            double *__restrict__ r,
                                                            const double *__restrict__ p,
                                                            const double *__restrict__ q,
-                                                           const double *__restrict__ dinv,
+                                                           const DiagView dg,
                                                            const double *pq_partials, int nparts_in,
                                                            const CgState *st, int it,
                                                            double *partials_out)
 {
     __shared__ double red[4];
+    __shared__ double ddict[256];
     if (it >= st->stop_iter) return;
+    if (dg.mode == 2) {
+        if (threadIdx.x < dg.ndict) ddict[threadIdx.x] = dg.dict[threadIdx.x];
+        __syncthreads();
+    }
+    const double *__restrict__ dinv = dg.mode == 1 ? dg.full : nullptr;
+    const uint16_t *dc2 = reinterpret_cast<const uint16_t *>(dg.code);
     const double pq = fold_partials(pq_partials, nparts_in, red);
     const double alpha = st->rho[it & 1] / pq;
     double a0 = 0.0, a1 = 0.0;
@@ -912,7 +944,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, double *__
                 rv[u] = r2[i];
                 pv[u] = p2[i];
                 qv[u] = q2[i];
-                if (dinv) dv[u] = d2[i];
+                dv[u] = diag_pair(dg, d2, dc2, ddict, i);
             }
         }
 #pragma unroll
@@ -924,7 +956,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, double *__
                 store2<NT>(x, i, xv[u]);
                 store2<NT>(r, i, rv[u]);
                 vd2 z = rv[u];
-                if (dinv) z *= dv[u];
+                if (dg.mode) z *= dv[u];
                 a0 += rv[u].x * z.x;
                 a0 += rv[u].y * z.y;
                 a1 += rv[u].x * rv[u].x;
@@ -937,7 +969,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, double *__
         x[i] += alpha * p[i];
         const double rv = r[i] - alpha * q[i];
         r[i] = rv;
-        const double z = dinv ? dinv[i] * rv : rv;
+        const double z = dg.mode ? diag_one(dg, ddict, i) * rv : rv;
         a0 += rv * z;
         a1 += rv * rv;
     }
@@ -953,12 +985,19 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, double *__
 template <int U, bool NT>
 __global__ __launch_bounds__(kBlock) void cg_direction_kernel(int64_t n, double *__restrict__ p,
                                                               const double *__restrict__ r,
-                                                              const double *__restrict__ dinv,
+                                                              const DiagView dg,
                                                               const double *partials_in, int nparts,
                                                               CgState *st, int it, double rtol)
 {
     __shared__ double red[4];
+    __shared__ double ddict[256];
     if (it >= st->stop_iter) return;
+    if (dg.mode == 2) {
+        if (threadIdx.x < dg.ndict) ddict[threadIdx.x] = dg.dict[threadIdx.x];
+        __syncthreads();
+    }
+    const double *__restrict__ dinv = dg.mode == 1 ? dg.full : nullptr;
+    const uint16_t *dc2 = reinterpret_cast<const uint16_t *>(dg.code);
     const double rho_new = fold_partials(partials_in, nparts, red);
     const double rr = fold_partials(partials_in + nparts, nparts, red);
     const double beta = rho_new / st->rho[it & 1];
@@ -975,21 +1014,21 @@ __global__ __launch_bounds__(kBlock) void cg_direction_kernel(int64_t n, double 
             if (i < n2) {
                 pv[u] = p2[i];
                 zv[u] = r2[i];
-                if (dinv) dv[u] = d2[i];
+                dv[u] = diag_pair(dg, d2, dc2, ddict, i);
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t i = i0 + u * stride;
             if (i < n2) {
-                if (dinv) zv[u] *= dv[u];
+                if (dg.mode) zv[u] *= dv[u];
                 store2<NT>(p, i, zv[u] + beta * pv[u]);
             }
         }
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const int64_t i = n - 1;
-        const double z = dinv ? dinv[i] * r[i] : r[i];
+        const double z = dg.mode ? diag_one(dg, ddict, i) * r[i] : r[i];
         p[i] = z + beta * p[i];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1496,6 +1535,47 @@ int schwz_pcg_create(const schwz_csr *A, int precond, schwz_pcg **out)
             SCHWZ_HIP_TRY(hipGetLastError());
             SCHWZ_HIP_TRY(hipDeviceSynchronize());
         }
+        // compact representation for the per-iteration vector kernels (DiagView)
+        s->diag.mode = 1;
+        s->diag.full = s->dinv;
+        const char *env = std::getenv("SCHWZ_DIAG_DICT");
+        if (s->n && !(env && env[0] == '0')) {
+            std::vector<double> h((size_t)s->n);
+            SCHWZ_HIP_TRY(hipMemcpy(h.data(), s->dinv, (size_t)s->n * sizeof(double), hipMemcpyDeviceToHost));
+            std::vector<double> dict;
+            std::vector<uint8_t> code((size_t)s->n + 2, 0);
+            bool ok = true;
+            for (int64_t i = 0; i < s->n && ok; ++i) {
+                int c = -1;
+                for (size_t k = 0; k < dict.size(); ++k)
+                    if (std::memcmp(&dict[k], &h[(size_t)i], 8) == 0) {
+                        c = (int)k;
+                        break;
+                    }
+                if (c < 0) {
+                    if (dict.size() == 256) {
+                        ok = false;
+                        break;
+                    }
+                    c = (int)dict.size();
+                    dict.push_back(h[(size_t)i]);
+                }
+                code[(size_t)i] = (uint8_t)c;
+            }
+            if (ok && dict.size() == 1) {
+                s->diag.mode = 3;
+                s->diag.uniform = dict[0];
+            } else if (ok && dict.size() <= 16) {  // linear search above stays cheap
+                int rc;
+                if ((rc = upload(code.data(), code.size(), &s->d_dcode)) ||
+                    (rc = upload(dict.data(), dict.size(), &s->d_ddict)))
+                    return rc;
+                s->diag.mode = 2;
+                s->diag.code = (const uint8_t *)s->d_dcode;
+                s->diag.dict = (const double *)s->d_ddict;
+                s->diag.ndict = (int)dict.size();
+            }
+        }
     }
     *out = s;
     return SCHWZ_OK;
@@ -1508,6 +1588,8 @@ void schwz_pcg_destroy(schwz_pcg *s)
     (void)hipFree(s->p);
     (void)hipFree(s->q);
     (void)hipFree(s->dinv);
+    (void)hipFree(s->d_dcode);
+    (void)hipFree(s->d_ddict);
     (void)hipFree(s->partials);
     (void)hipFree(s->d_norm_sq);
     (void)hipFree(s->state);
@@ -1582,9 +1664,9 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
             }
 #define SCHWZ_LAUNCH_UPDATE(U, NT)                                                                        \
     hipLaunchKernelGGL((cg_update_kernel<U, NT>), dim3(gv), dim3(kBlock), 0, st, n, d_x, s->r, s->p, s->q, \
-                       s->dinv, part_spmv, gs, s->state, it, part_vec)
+                       s->diag, part_spmv, gs, s->state, it, part_vec)
 #define SCHWZ_LAUNCH_DIRECTION(U, NT)                                                                        \
-    hipLaunchKernelGGL((cg_direction_kernel<U, NT>), dim3(gv), dim3(kBlock), 0, st, n, s->p, s->r, s->dinv, \
+    hipLaunchKernelGGL((cg_direction_kernel<U, NT>), dim3(gv), dim3(kBlock), 0, st, n, s->p, s->r, s->diag, \
                        part_vec, gv, s->state, it, rtol)
             SCHWZ_LAUNCH_UPDATE(1, false);
             SCHWZ_LAUNCH_DIRECTION(1, false);

@@ -101,6 +101,18 @@ int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipS
 int launch_spmv_dict(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s);
 int launch_spmv_pattern(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s);
 
+// Jacobi scaling as the CG vector kernels see it.  The full 1/diag vector costs 8 B per row and
+// per kernel; matrices with few distinct diagonal values (every stencil) get a 1-byte code per
+// row into a <= 256-entry dictionary, or a single scalar.  Same values, same bits.
+struct DiagView {
+    int mode = 0;  // 0 none, 1 full vector, 2 dictionary codes, 3 uniform scalar
+    const double *full = nullptr;
+    const uint8_t *code = nullptr;
+    const double *dict = nullptr;
+    int ndict = 0;
+    double uniform = 1.0;
+};
+
 // device-side CG scalar state
 struct CgState {
     double rho[2];
@@ -144,6 +156,8 @@ struct schwz_pcg {
     int precond = 0;
     int64_t n = 0;
     double *r = nullptr, *p = nullptr, *q = nullptr, *dinv = nullptr;
+    schwz::DiagView diag;
+    void *d_dcode = nullptr, *d_ddict = nullptr;
     double *partials = nullptr;  // 3 * kMaxGrid (SpMV banks) + 2 * kMaxGrid (vector banks)
     double *d_norm_sq = nullptr; // kSpmvResidDual result
     schwz::CgState *state = nullptr;

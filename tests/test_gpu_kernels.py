@@ -263,3 +263,31 @@ def test_coded_tiles_are_bit_identical_to_plain_csr(schwz, oracle, torch_cuda, m
         sols.append((d_x.cpu().numpy(), rn))
     for k in (1, 2):
         assert np.array_equal(sols[0][0], sols[k][0]) and sols[0][1] == sols[k][1]
+
+
+@pytest.mark.parametrize("nshift", [1, 3, 40])
+def test_pcg_diagonal_representations_agree(schwz, oracle, torch_cuda, monkeypatch, nshift):
+    """Jacobi 1/diag as a scalar (1 distinct value), as 1-byte codes into a dictionary (3), or as
+    the full vector (40 distinct -> no coding): identical bits to the forced full-vector run, and
+    the oracle's iterates within tolerance.  n is odd to exercise the tail element."""
+    torch = torch_cuda
+    rp, col, val = oracle.laplacian2d(21)  # 441 rows
+    n = len(rp) - 1
+    val = val.copy()
+    shifts = np.linspace(0.0, 1.0, nshift) if nshift > 1 else np.zeros(1)
+    for i in range(n):
+        for j in range(rp[i], rp[i + 1]):
+            if col[j] == i:
+                val[j] += shifts[i % nshift]
+    b = np.random.default_rng(9).standard_normal(n)
+    res = []
+    for env in ("1", "0"):
+        monkeypatch.setenv("SCHWZ_DIAG_DICT", env)
+        A = schwz.Csr(rp, col, val)
+        cg = schwz.Pcg(A, 1)
+        d_b, d_x = _dev(torch, b), torch.zeros(n, dtype=torch.float64, device="cuda")
+        it, rn = cg.solve(d_b.data_ptr(), d_x.data_ptr(), 0.0, 15)
+        res.append((d_x.cpu().numpy(), rn))
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
+    exp, _, rn_o = oracle.pcg(rp, col, val, b, None, 1, 0.0, 15)
+    assert np.abs(res[0][0] - exp).max() <= RTOL_CG * np.abs(exp).max()
