@@ -1033,7 +1033,79 @@ int schwz_or_ras_run(int64_t N, const or_idx *rp, const or_idx *col,
     double gres = 0.0, gres0 = -1.0;
     int num_converged = 0, iter = 0, rc = 0;
     const double tol = s->tol;
+    /* overlapped one-sided model: per subdomain a bit mask of the subdomains known to be
+     * locally converged and an agreed stop iteration, both travelling one hop per iteration
+     * with the halo messages (the flooding of conv_tools.hpp:213-275 on matched messages) */
+    const int overlapped = s->enable_onesided && s->enable_overlap;
+    uint64_t *mask = (uint64_t *)xcalloc((size_t)P, sizeof(uint64_t));
+    uint64_t *mask_sent = (uint64_t *)xcalloc((size_t)P, sizeof(uint64_t));
+    int64_t *stop_at = (int64_t *)xmalloc(sizeof(int64_t) * (size_t)P);
+    int64_t *stop_sent = (int64_t *)xmalloc(sizeof(int64_t) * (size_t)P);
+    const int64_t never = INT64_MAX;
+    const uint64_t full = P >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << P) - 1);
+    for (int p = 0; p < P; ++p) stop_at[p] = stop_sent[p] = never;
+    int have_msg = 0;
     double t0 = now_s();
+    if (overlapped) {
+        for (; iter < s->max_iters; ++iter) {
+            /* (a) consume what the neighbours posted one iteration ago */
+            if (have_msg) {
+                for (int p = 0; p < P; ++p) {
+                    for (int k = 0; k < sd[p]->n_in; ++k) {
+                        const int q = sd[p]->nbr_in[k];
+                        schwz_or_unpack(st[p], k, msg[(size_t)q * P + p]);
+                        mask[p] |= mask_sent[q];
+                        if (stop_sent[q] < stop_at[p]) stop_at[p] = stop_sent[q];
+                    }
+                }
+            }
+            /* (b) post this iteration's messages: x after the previous restriction */
+            int last = (iter == s->max_iters - 1);
+            for (int p = 0; p < P; ++p)
+                if (stop_at[p] == iter) last = 1;
+            /* (c) boundary update, local test, local solve, restriction */
+            int nan_seen = 0;
+            for (int p = 0; p < P; ++p) schwz_or_update_boundary(st[p]);
+            for (int p = 0; p < P; ++p) {
+                lres[p] = -1.0;
+                if (tol >= 0.0) {
+                    lres[p] = schwz_or_local_residual(st[p]);
+                    if (lres0[p] < 0.0) lres0[p] = lres[p];
+                }
+                if (isnan(lres[p])) nan_seen = 1;
+                if (hist_local) hist_local[(size_t)iter * P + p] = lres[p];
+                if (tol > 0.0 && lres[p] / lres0[p] <= tol) mask[p] |= (uint64_t)1 << p;
+                if (mask[p] == full && stop_at[p] == never) stop_at[p] = (int64_t)iter + P;
+            }
+            if (hist_global) hist_global[iter] = 0.0;
+            if (nan_seen) {
+                rc = -1;
+                break;
+            }
+            /* messages carry the state after the local test of this iteration */
+            if (!last) {
+                for (int p = 0; p < P; ++p) {
+                    for (int k = 0; k < sd[p]->n_out; ++k)
+                        schwz_or_pack(st[p], k, msg[(size_t)p * P + sd[p]->nbr_out[k]]);
+                    mask_sent[p] = mask[p];
+                    stop_sent[p] = stop_at[p];
+                }
+                have_msg = 1;
+            }
+            int stop_now = 0;
+            for (int p = 0; p < P; ++p)
+                if (stop_at[p] == iter) stop_now = 1;
+            if (stop_now) {
+                num_converged = P;
+                break;
+            }
+            for (int p = 0; p < P; ++p) {
+                int it = schwz_or_local_solve(st[p]);
+                if (hist_inner) hist_inner[(size_t)iter * P + p] = it;
+                schwz_or_restrict(st[p]);
+            }
+        }
+    } else
     for (; iter < s->max_iters; ++iter) {
         /* 0 exchange (one-sided mode skips iteration 0, restricted_schwarz.cpp:725) */
         if (!(s->enable_onesided && iter == 0)) {
@@ -1096,6 +1168,10 @@ int schwz_or_ras_run(int64_t N, const or_idx *rp, const or_idx *col,
             schwz_or_restrict(st[p]);
         }
     }
+    free(mask);
+    free(mask_sent);
+    free(stop_at);
+    free(stop_sent);
     res->elapsed_s = now_s() - t0;
     res->iter_count = iter;
     res->converged = (num_converged == P);

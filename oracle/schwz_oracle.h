@@ -111,6 +111,10 @@ typedef struct {
     int32_t global_check_iter_offset;/* enable_global_check_iter_offset */
     int32_t natural_factor_ordering; /* settings.naturally_ordered_factor */
     int32_t num_threads;             /* OpenMP threads for the kernels (0=default) */
+    /* comm_settings.enable_overlap together with enable_onesided: the deterministic
+     * asynchronous model of this build -- halos are consumed one iteration late and the
+     * stop decision is flooded over neighbour messages (see schwz_or_ras_run) */
+    int32_t enable_overlap;
 } or_settings;
 
 /* ---- per-subdomain state and the five loop steps (A.3) -------------------- */

@@ -38,12 +38,20 @@ class InProcessComm:
         for key, dst_buf in recvs.items():
             dst_buf.copy_(sends[key])
 
-    def start_exchange(self, sends, recvs):
+    def start_exchange(self, sends, recvs, overlap=False):
         self.exchange(sends, recvs)
         return None
 
     def finish_exchange(self, handle):
         pass
+
+    def start_flags(self, values, neighbours):
+        """values: {me: (mask, stop_at)}; neighbours: {me: (out_ranks, in_ranks)}.
+        Delivered by finish_flags as {me: [(mask, stop_at) of every in-neighbour]}."""
+        return {me: [values[q] for q in neighbours[me][1]] for me in values}
+
+    def finish_flags(self, handle):
+        return handle
 
     def allgather_scalars(self, values):
         """values: {me: float} for the local subdomains -> list of P floats."""
@@ -85,6 +93,7 @@ class TorchDistComm:
         self.host_group = group if self.backend == "gloo" else dist.new_group(backend="gloo")
         self.stage_through_host = self.backend == "gloo" and self.device.type != "cpu"
         self._stage = {}
+        self._side = None
 
     def handshake(self, get_lists):
         """Counts and ids travel as int64 host tensors (tags 1 and 2 of the reference become
@@ -120,8 +129,34 @@ class TorchDistComm:
             self._stage[key] = t
         return t
 
-    def start_exchange(self, sends, recvs):
-        """Grouped send/recv of the packed halo buffers ({(src, dst): 1-D tensor})."""
+    def start_flags(self, values, neighbours):
+        """Two int64 per neighbour over the host group: (mask of subdomains known to have
+        converged locally, agreed stop iteration).  The decentralised flooding of
+        conv_tools.hpp:213-275 on matched point-to-point messages."""
+        torch, dist = self._torch, self._dist
+        mask, stop = values[self.rank]
+        outs, ins = neighbours[self.rank]
+        ops, bufs = [], []
+        payload = torch.tensor([int(mask), int(stop)], dtype=torch.int64)
+        for q in outs:
+            ops.append(dist.P2POp(dist.isend, payload, q, group=self.host_group))
+        for q in ins:
+            b = torch.zeros(2, dtype=torch.int64)
+            bufs.append(b)
+            ops.append(dist.P2POp(dist.irecv, b, q, group=self.host_group))
+        works = dist.batch_isend_irecv(ops) if ops else []
+        return works, bufs, payload
+
+    def finish_flags(self, handle):
+        works, bufs, _ = handle
+        for w in works:
+            w.wait()
+        return {self.rank: [(int(b[0]), int(b[1])) for b in bufs]}
+
+    def start_exchange(self, sends, recvs, overlap=False):
+        """Grouped send/recv of the packed halo buffers ({(src, dst): 1-D tensor}).  With
+        `overlap` (nccl) the transfers are issued on a side stream that first waits for the
+        pack kernel; the compute stream only meets them again in finish_exchange."""
         dist = self._dist
         ops, post = [], []
         if self.stage_through_host:
@@ -138,7 +173,15 @@ class TorchDistComm:
                 ops.append(dist.P2POp(dist.isend, buf, dst, group=self.group))
             for (src, dst), buf in sorted(recvs.items()):
                 ops.append(dist.P2POp(dist.irecv, buf, src, group=self.group))
-        works = dist.batch_isend_irecv(ops) if ops else []
+        if overlap and ops and not self.stage_through_host and self.device.type != "cpu":
+            torch = self._torch
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                works = dist.batch_isend_irecv(ops)
+        else:
+            works = dist.batch_isend_irecv(ops) if ops else []
         return works, post
 
     def finish_exchange(self, handle):

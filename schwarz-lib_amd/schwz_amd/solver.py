@@ -28,6 +28,8 @@ SOLVER_DIRECT_GINKGO = "direct-ginkgo"
 SOLVER_ITERATIVE_GINKGO = "iterative-ginkgo"
 
 # MEASURE_ELAPSED_FUNC_TIME ids and names (schwarz_base.cpp:393-450)
+NEVER = (1 << 62)  # "no stop iteration agreed yet" in the flooded convergence state
+
 TIMING_NAMES = ["boundary_exchange", "boundary_update", "convergence_check", "local_solve",
                 "expand_local_vec"]
 
@@ -346,17 +348,107 @@ class SolverRAS:
         self._gres, self._gres0 = 0.0, -1.0
         self._num_converged = 0
         self._timings = [[] for _ in range(5)]
+        # overlapped one-sided mode: flooded convergence state and the messages in flight
+        self._mask = {me: 0 for me in self.subdomains}
+        self._stop = {me: NEVER for me in self.subdomains}
+        self._pending = None
         ppd = m.post_process_data
         for k in ppd:
             ppd[k] = []
         ppd["global_residual_vector_out"] = [[] for _ in range(P)]
         m.iter_count = 0
 
+    def _step_overlapped(self):
+        """`enable_onesided` + `enable_overlap`: the asynchronous flavour of the iteration as
+        this build defines it (BASELINE config 5).  The halo exchange of iteration k is posted
+        before the local solve of iteration k -- on a side stream under RCCL -- and consumed at
+        the start of iteration k+1, so it is hidden behind the solve and halos are one iteration
+        older than in the synchronous loop.  There is no global collective: every subdomain
+        tests itself (solve.cpp:913-915) and floods (mask of converged subdomains, agreed stop
+        iteration) to its neighbours with each message, the decentralised protocol of
+        conv_tools.hpp:213-275 on matched messages; the first subdomain that sees the full mask
+        at iteration k proposes stop = k + P, the minimum wins, and everybody stops together."""
+        s, m, be, comm = self.settings, self.metadata, self.backend, self.comm
+        P = m.num_subdomains
+        locals_ = list(self.subdomains.items())
+        ppd = m.post_process_data
+        tol = m.tolerance
+        it = m.iter_count
+        stream = be.stream()
+        full = (1 << P) - 1
+        t0 = time.perf_counter()
+        # (a) consume what was posted one iteration ago
+        if self._pending is not None:
+            comm.finish_exchange(self._pending["halo"])
+            for me, sd in locals_:
+                sd.unpack(self.recv_buf[me].data_ptr(), stream)
+            for me, msgs in comm.finish_flags(self._pending["flags"]).items():
+                for mk, st in msgs:
+                    self._mask[me] |= mk
+                    self._stop[me] = min(self._stop[me], st)
+            self._pending = None
+        last = it == m.max_iters - 1 or any(self._stop[me] == it for me, _ in locals_)
+        # (b) post this iteration's halos: x~ after the previous restriction
+        halo = None
+        if not last:
+            for me, sd in locals_:
+                sd.pack(self.send_buf[me].data_ptr(), stream)
+            halo = comm.start_exchange(self._sends, self._recvs, overlap=True)
+        t1 = time.perf_counter()
+        # (c) boundary update, local test + local solve (enqueued together), restriction
+        for _, sd in locals_:
+            sd.update_boundary(stream)
+        t2 = time.perf_counter()
+        fused = hasattr(locals_[0][1], "check_and_solve_launch") and tol >= 0.0
+        if fused:
+            for _, sd in locals_:
+                sd.check_and_solve_launch(stream)
+        for me, sd in locals_:
+            lres = -1.0
+            if tol >= 0.0:
+                lres = sd.local_residual_wait() if fused else sd.local_residual(stream)
+                if self._lres0[me] < 0.0:
+                    self._lres0[me] = lres
+            if np.isnan(lres):
+                raise capi.SchwzError(capi.ERR_DIVERGED, "local residual is NaN")
+            ppd["local_residual_vector_out"].append(lres)
+            m.current_residual_norm = lres
+            if tol > 0.0 and lres / self._lres0[me] <= tol:
+                self._mask[me] |= 1 << me
+            if self._mask[me] == full and self._stop[me] == NEVER:
+                self._stop[me] = it + P
+        if not last:
+            neighbours = {me: ([q for q, _ in sd.put_lists()], [p for p, _ in sd.get_lists()])
+                          for me, sd in locals_}
+            flags = comm.start_flags({me: (self._mask[me], self._stop[me]) for me, _ in locals_},
+                                     neighbours)
+            self._pending = dict(halo=halo, flags=flags)
+        t3 = time.perf_counter()
+        tm = self._timings
+        tm[0].append(t1 - t0)
+        tm[1].append(t2 - t1)
+        tm[2].append(t3 - t2)
+        if any(self._stop[me] == it for me, _ in locals_):
+            self._num_converged = P
+            return True
+        if not fused:
+            for _, sd in locals_:
+                sd.local_solve(stream)
+        t4 = time.perf_counter()
+        for _, sd in locals_:
+            sd.restrict(stream)
+        tm[3].append(t4 - t3)
+        tm[4].append(time.perf_counter() - t4)
+        m.iter_count += 1
+        return False
+
     def step(self):
         """One pass of the loop body of SchwarzBase::run (schwarz_base.cpp:387-452).
         Returns True when the convergence test fired (no local solve is done then)."""
         s, m, be, comm = self.settings, self.metadata, self.backend, self.comm
         cs, cv = s.comm_settings, s.convergence_settings
+        if cs.enable_onesided and cs.enable_overlap:
+            return self._step_overlapped()
         P = m.num_subdomains
         locals_ = list(self.subdomains.items())
         ppd = m.post_process_data

@@ -39,6 +39,10 @@ def _worker(rank, world, port, case, out_path):
         if case.get("onesided"):
             s.comm_settings.enable_onesided = True
             s.convergence_settings.enable_global_simple_tree = True
+        if case.get("overlap"):
+            s.comm_settings.enable_overlap = True
+            s.convergence_settings.enable_global_simple_tree = False
+            s.convergence_settings.enable_decentralized_leader_election = True
         m = S.Metadata(**case["metadata"])
         solver = S.SolverRAS(s, m, comm=S.TorchDistComm(), backend=OracleBackend(), quiet=True)
         assert m.num_subdomains == world and m.my_rank == rank
@@ -86,6 +90,14 @@ CASES = {
     "lap2d_onesided": dict(
         world=2, settings=dict(), onesided=True,
         metadata=dict(oned_laplacian_size=16, tolerance=1e-6, max_iters=300)),
+    # asynchronous flavour: halos one iteration late, decentralised stop agreement
+    "lap2d_overlapped_decentralized": dict(
+        world=3, settings=dict(), onesided=True, overlap=True,
+        metadata=dict(oned_laplacian_size=18, tolerance=1e-6, max_iters=400)),
+    "lap3d_overlapped_truncated_cg": dict(
+        world=4, settings=dict(laplacian_dim=3, laplacian_shape=(5, 4, 12)), onesided=True, overlap=True,
+        metadata=dict(tolerance=1e-5, max_iters=400, local_precond="block-jacobi",
+                      precond_max_block_size=1, local_solver_tolerance=0.0, local_max_iters=4)),
 }
 
 
@@ -105,7 +117,7 @@ def test_distributed_run_reproduces_lockstep_oracle(oracle, name, tmp_path):
         local_solver=oracle.SOLVER_DIRECT if st.get("local_solver", "").startswith("direct") else 0,
         precond=1 if md.get("local_precond") == "block-jacobi" else 0,
         local_tol=md.get("local_solver_tolerance", 1e-12), local_max_iters=md.get("local_max_iters", -1),
-        enable_onesided=int(bool(case.get("onesided"))))
+        enable_onesided=int(bool(case.get("onesided"))), enable_overlap=int(bool(case.get("overlap"))))
     fr = oracle.first_rows_regular(N, world)
     assert np.array_equal(got["first_row"], fr)
     ref = oracle.ras_run(rp, col, val, np.ones(N), world, fr, s)

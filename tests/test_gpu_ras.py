@@ -31,6 +31,7 @@ def _oracle_settings(oracle, m, s, **kw):
         local_tol=m.local_solver_tolerance, local_max_iters=m.local_max_iters,
         enable_global_check=int(s.convergence_settings.enable_global_check),
         enable_onesided=int(s.comm_settings.enable_onesided),
+        enable_overlap=int(s.comm_settings.enable_overlap),
         natural_factor_ordering=int(s.naturally_ordered_factor), **kw)
 
 
@@ -324,3 +325,33 @@ def test_fused_check_and_solve_equals_separate_steps(schwz, torch_cuda, P):
         sols.append(out["solution"])
     assert hist[0].shape == hist[1].shape and np.array_equal(hist[0], hist[1])
     assert np.array_equal(sols[0], sols[1])
+
+
+@pytest.mark.parametrize("P", [2, 5])
+def test_ras_overlapped_decentralized_matches_oracle(schwz, oracle, torch_cuda, P):
+    """BASELINE config 5 semantics at small size: one-sided + overlap = halos consumed one
+    iteration late, convergence agreed by flooding flags over neighbour messages only.  The
+    model is deterministic, so the oracle reproduces it in lockstep: same iteration count, same
+    solution."""
+    n = 20
+    s = schwz.Settings()
+    s.comm_settings.enable_onesided = True
+    s.comm_settings.enable_overlap = True
+    s.convergence_settings.enable_decentralized_leader_election = True
+    m = schwz.Metadata(num_subdomains=P, oned_laplacian_size=n, tolerance=1e-6, max_iters=600)
+    solver = schwz.SolverRAS(s, m, comm=schwz.InProcessComm(P), quiet=True)
+    solver.initialize()
+    out = solver.run()
+    rp, col, val = oracle.laplacian2d(n)
+    r = oracle.ras_run(rp, col, val, np.ones(n * n), P, np.asarray(m.first_row, dtype=np.int32),
+                       _oracle_settings(oracle, m, s))
+    assert out["converged"] and r["converged"]
+    assert out["iter_count"] == r["iter_count"]
+    assert np.abs(out["solution"] - r["solution"]).max() <= 1e-8 * np.abs(r["solution"]).max()
+    assert out["residual_norm"] / out["rhs_norm"] < 1e-4
+    # staleness costs iterations: more than the synchronous loop needs
+    s2 = schwz.Settings()
+    m2 = schwz.Metadata(num_subdomains=P, oned_laplacian_size=n, tolerance=1e-6, max_iters=600)
+    sync = schwz.SolverRAS(s2, m2, comm=schwz.InProcessComm(P), quiet=True)
+    sync.initialize()
+    assert sync.run()["iter_count"] < out["iter_count"]
