@@ -167,19 +167,24 @@ def main():
     alg_spmv = sd.algorithmic_bytes(0)
     avg_ms = tot_ms.value / max(launches.value, 1)
     achieved = alg_spmv / (avg_ms * 1e-3) / 1e9 if launches.value else 0.0
+    hist = m.post_process_data["global_residual_vector_out"]
+    fmt = int(schwz.capi.lib.schwz_csr_format(sd_csr(sd, schwz))) if a.spmv_variant == 0 else 0
+    dict_coded = fmt != 0
+    kernel_name = {2: "spmv_pattern_kernel<kSpmvDot> (q = A p, fused p.q; row-pattern coded CSR tiles)",
+                   1: "spmv_dict_kernel<kSpmvDot> (q = A p, fused p.q; dictionary-coded CSR tiles)",
+                   0: "spmv_tiled2_kernel<kSpmvDot> (q = A p, fused p.q; plain CSR)"}[fmt]
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             key = "%dx%dx%d" % shape
-            traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            ent = tj.get(key, {})
+            # only quote the PMC figure if it was taken for the kernel this run is using
+            if ent.get("kernel", "").split("<")[0] == kernel_name.split("<")[0]:
+                traffic = ent.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    hist = m.post_process_data["global_residual_vector_out"]
-    dict_coded = a.spmv_variant == 0 and os.environ.get("SCHWZ_SPMV_DICT", "1") != "0"
-    kernel_name = ("spmv_dict_kernel<kSpmvDot> (q = A p, fused p.q; dictionary-coded CSR tiles)"
-                   if dict_coded else "spmv_tiled2_kernel<kSpmvDot> (q = A p, fused p.q; plain CSR)")
     # the plain-CSR kernel on the same matrix (variant 6), timed on its own: the figure the
     # north_star's ">= 60 % of the HBM roofline on the local CSR SpMV" refers to
     csr_plain = None

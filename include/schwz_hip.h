@@ -85,6 +85,10 @@ int schwz_csr_create(int64_t nrows, int64_t ncols, const schwz_idx *h_row_ptr,
                      const schwz_idx *h_col, const double *h_val, schwz_csr **out);
 void schwz_csr_destroy(schwz_csr *A);
 int64_t schwz_csr_nnz(const schwz_csr *A);
+/* encoding the default SpMV (variant 0) uses for this matrix: 0 = plain CSR, 1 = per-entry
+ * dictionary tiles, 2 = row-pattern tiles (both lossless re-encodings built at upload,
+ * csrc/spmv_dict.hip) */
+int schwz_csr_format(const schwz_csr *A);
 
 /* y = alpha*A*x + beta*y : gko Csr::apply(alpha,x,beta,y), call sites
  * source/restricted_schwarz.cpp:1014-1015, source/solve.cpp:834-835,1079-1080.

@@ -1435,6 +1435,8 @@ void schwz_csr_destroy(schwz_csr *A)
 
 int64_t schwz_csr_nnz(const schwz_csr *A) { return A ? A->v.nnz : 0; }
 
+int schwz_csr_format(const schwz_csr *A) { return !A ? 0 : (A->v.pat_id ? 2 : (A->v.code ? 1 : 0)); }
+
 int schwz_csr_spmv(const schwz_csr *A, double alpha, const double *d_x, double beta, double *d_y,
                    int variant, schwz_stream stream)
 {
