@@ -144,6 +144,7 @@ __global__ __launch_bounds__(kBlock) void spmv_tiled2_kernel(CsrView A, SpmvArgs
         const int r0 = A.tile_row[tl], r1 = A.tile_row[tl + 1];
         const int s = A.rp[r0], e = A.rp[r1];
         const int cnt = e - s;
+        const bool dual_t = dual && (!A.tile_dual || A.tile_dual[tl]);
         double sum = 0.0, sum2 = 0.0;
         int row = r0 + tid;
         bool have_row = false;
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(kBlock) void spmv_tiled2_kernel(CsrView A, SpmvArgs
                 for (int j = b0; j < b1; ++j) sum += prod[j];
             }
             lds_barrier();
-            if (dual) {
+            if (dual_t) {
                 // second vector, same matrix entries (still in registers)
 #pragma unroll
                 for (int k = 0; k < kPairsPerLane; ++k) {
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(kBlock) void spmv_tiled2_kernel(CsrView A, SpmvArgs
                 for (int j = b0; j < b1; ++j) sum += prod[j];
             }
             lds_barrier();
-            if (dual) {
+            if (dual_t) {
                 for (int i = tid; i < cnt; i += kBlock) prod[i] = A.val[s + i] * a.x2[A.col[s + i]];
                 lds_barrier();
                 for (int j = b0; j < b1; ++j) sum2 += prod[j];
@@ -225,10 +226,10 @@ __global__ __launch_bounds__(kBlock) void spmv_tiled2_kernel(CsrView A, SpmvArgs
             double part = 0.0, part2 = 0.0;
             for (int i = tid; i < cnt; i += kBlock) {
                 part += __dmul_rn(A.val[s + i], a.x[A.col[s + i]]);
-                if (dual) part2 += __dmul_rn(A.val[s + i], a.x2[A.col[s + i]]);
+                if (dual_t) part2 += __dmul_rn(A.val[s + i], a.x2[A.col[s + i]]);
             }
             part = block_sum(part, red);
-            if (dual) part2 = block_sum(part2, red);
+            if (dual_t) part2 = block_sum(part2, red);
             row = r0;
             if (tid == 0) {
                 have_row = true;
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(kBlock) void spmv_tiled2_kernel(CsrView A, SpmvArgs
                 acc0 += r * z;
                 acc1 += r * r;
                 if (MODE == kSpmvResidDual && row < a.row_limit) {
-                    const double r2 = dual ? bb - sum2 : r;
+                    const double r2 = dual_t ? bb - sum2 : r;
                     acc2 += r2 * r2;
                 }
             } else {  // kSpmvResidNorm
@@ -1386,6 +1387,7 @@ int schwz_csr_create(int64_t nrows, int64_t ncols, const schwz_idx *h_rp, const 
     A->v.col = (const schwz_idx *)A->d_col;
     A->v.val = (const double *)A->d_val;
     A->v.ntiles = (int)tiles.size() - 1;
+    A->h_tiles = tiles;
     A->v.tile_row = (const schwz_idx *)A->d_tile;
     A->v.tile_order = order.empty() ? nullptr : (const schwz_idx *)A->d_order;
     {
@@ -1429,6 +1431,7 @@ void schwz_csr_destroy(schwz_csr *A)
     (void)hipFree(A->d_tile);
     (void)hipFree(A->d_wtile);
     (void)hipFree(A->d_order);
+    (void)hipFree(A->d_tile_dual);
     free_spmv_dict(A);
     delete A;
 }
@@ -1845,6 +1848,25 @@ int launch_copy(int64_t n, const double *src, double *dst, hipStream_t s)
     if (n == 0) return SCHWZ_OK;
     hipLaunchKernelGGL(copy_kernel, dim3(grid_for((n + 1) / 2)), dim3(kBlock), 0, s, n, src, dst);
     SCHWZ_HIP_TRY(hipGetLastError());
+    return SCHWZ_OK;
+}
+
+int csr_set_dual_split(schwz_csr *A, const schwz_idx *h_rp, const schwz_idx *h_col, int64_t split)
+{
+    const int ntiles = (int)A->h_tiles.size() - 1;
+    if (ntiles <= 0) return SCHWZ_OK;
+    std::vector<uint8_t> flag((size_t)ntiles, 0);
+    for (int t = 0; t < ntiles; ++t) {
+        const schwz_idx r0 = A->h_tiles[(size_t)t], r1 = A->h_tiles[(size_t)t + 1];
+        bool f = r1 > split;
+        for (int64_t j = h_rp[r0]; j < h_rp[r1] && !f; ++j) f = h_col[j] >= split;
+        flag[(size_t)t] = f ? 1 : 0;
+    }
+    (void)hipFree(A->d_tile_dual);
+    A->d_tile_dual = nullptr;
+    SCHWZ_HIP_TRY(hipMalloc(&A->d_tile_dual, flag.size()));
+    SCHWZ_HIP_TRY(hipMemcpy(A->d_tile_dual, flag.data(), flag.size(), hipMemcpyHostToDevice));
+    A->v.tile_dual = (const uint8_t *)A->d_tile_dual;
     return SCHWZ_OK;
 }
 

@@ -51,6 +51,9 @@ struct CsrView {
     const schwz_idx *tile_row = nullptr;  // ntiles+1 row boundaries
     const schwz_idx *tile_order = nullptr;  // optional BFS visiting order (SCHWZ_TILE_ORDER=1)
     int xcd_block = 0;  // tiles are dealt to the 8 XCDs block-cyclically in runs of this many
+    // kSpmvResidDual: 1 where the tile's rows or columns reach past `dual_split` (where x2 may
+    // differ from x); elsewhere the second product is skipped (nullptr: every tile)
+    const uint8_t *tile_dual = nullptr;
     int nwtiles = 0;                        // wave tiles: <= 64 rows, <= kWaveTileNnz-2 nnz
     const schwz_idx *wtile_row = nullptr;
     // dictionary-coded copy of (val, col) for the tiles that allow it (spmv_dict.hip):
@@ -130,6 +133,8 @@ namespace schwz {
 int build_spmv_dict(schwz_csr *A, const schwz_idx *h_rp, const schwz_idx *h_col, const double *h_val,
                     const std::vector<schwz_idx> &tiles);
 void free_spmv_dict(schwz_csr *A);
+// marks the tiles whose rows or columns reach index >= split (see CsrView::tile_dual)
+int csr_set_dual_split(schwz_csr *A, const schwz_idx *h_rp, const schwz_idx *h_col, int64_t split);
 }  // namespace schwz
 
 struct schwz_pcg;
@@ -147,6 +152,8 @@ struct schwz_csr {
     void *d_code = nullptr, *d_vptr = nullptr, *d_dptr = nullptr, *d_vdict = nullptr, *d_ddict = nullptr;
     void *d_pat_id = nullptr, *d_tile_table = nullptr, *d_tbl_desc = nullptr, *d_tbl_len = nullptr, *d_tbl_val = nullptr,
          *d_tbl_delta = nullptr;
+    void *d_tile_dual = nullptr;
+    std::vector<schwz_idx> h_tiles;  // host copy of the tile boundaries
     double dict_fraction = 0.0;  // share of the nonzeros that are dictionary coded
     double pattern_fraction = 0.0;  // share of the nonzeros in row-pattern coded tiles
 };

@@ -59,6 +59,7 @@ __global__ __launch_bounds__(kBlock) void spmv_dict_kernel(CsrView A, SpmvArgs a
         const int d0 = A.ddict_ptr[tile], nd = A.ddict_ptr[tile + 1] - d0;
         const int row = r0 + tid;
         const bool have_row = (r1 - r0 > 1) ? row < r1 : tid == 0;
+        const bool dual_t = dual && (!A.tile_dual || A.tile_dual[tile]);
         double sum = 0.0, sum2 = 0.0;
         if (nd > 0) {
             // ---- coded tile ------------------------------------------------------------------
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(kBlock) void spmv_dict_kernel(CsrView A, SpmvArgs a
                     }
 #pragma unroll
                     for (int k = 0; k < kChunk; ++k) xg[k] = a.x[c[k]];
-                    if (dual) {
+                    if (dual_t) {
 #pragma unroll
                         for (int k = 0; k < kChunk; ++k) xg2[k] = a.x2[c[k]];
                     }
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(kBlock) void spmv_dict_kernel(CsrView A, SpmvArgs a
                         // kernels round it when they stage it in LDS, and the two must agree
                         if (j + k < b1) {
                             sum += __dmul_rn(v[k], xg[k]);
-                            if (dual) sum2 += __dmul_rn(v[k], xg2[k]);
+                            if (dual_t) sum2 += __dmul_rn(v[k], xg2[k]);
                         }
                     }
                 }
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(kBlock) void spmv_dict_kernel(CsrView A, SpmvArgs a
                     const double vv = A.val[j];
                     const int cc = A.col[j];
                     sum += __dmul_rn(vv, a.x[cc]);
-                    if (dual) sum2 += __dmul_rn(vv, a.x2[cc]);
+                    if (dual_t) sum2 += __dmul_rn(vv, a.x2[cc]);
                 }
             }
         } else {
@@ -122,10 +123,10 @@ __global__ __launch_bounds__(kBlock) void spmv_dict_kernel(CsrView A, SpmvArgs a
             double part = 0.0, part2 = 0.0;
             for (int i = s + tid; i < e; i += kBlock) {
                 part += __dmul_rn(A.val[i], a.x[A.col[i]]);
-                if (dual) part2 += __dmul_rn(A.val[i], a.x2[A.col[i]]);
+                if (dual_t) part2 += __dmul_rn(A.val[i], a.x2[A.col[i]]);
             }
             sum = block_sum(part, red);
-            if (dual) sum2 = block_sum(part2, red);
+            if (dual_t) sum2 = block_sum(part2, red);
         }
         if (have_row) {
             const int rw = (r1 - r0 > 1) ? row : r0;
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(kBlock) void spmv_dict_kernel(CsrView A, SpmvArgs a
                 acc0 += r * z;
                 acc1 += r * r;
                 if (MODE == kSpmvResidDual && rw < a.row_limit) {
-                    const double r2 = dual ? bb - sum2 : r;
+                    const double r2 = dual_t ? bb - sum2 : r;
                     acc2 += r2 * r2;
                 }
             } else {  // kSpmvResidNorm
@@ -278,6 +279,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pattern_kernel(CsrView A, SpmvArg
         const int tb = A.tile_table[tile];
         const int row = r0 + tid;
         const bool have_row = (r1 - r0 > 1) ? row < r1 : tid == 0;
+        const bool dual_t = dual && (!A.tile_dual || A.tile_dual[tile]);
         double sum = 0.0, sum2 = 0.0;
         if (tb >= 0) {
             if (tb != cached) {  // workgroup-uniform
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pattern_kernel(CsrView A, SpmvArg
                     }
 #pragma unroll
                     for (int k = 0; k < kChunk; ++k) xg[k] = a.x[c[k]];
-                    if (dual) {
+                    if (dual_t) {
 #pragma unroll
                         for (int k = 0; k < kChunk; ++k) xg2[k] = a.x2[c[k]];
                     }
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pattern_kernel(CsrView A, SpmvArg
                     for (int k = 0; k < kChunk; ++k) {
                         if (j + k < len) {
                             sum += v[k] * xg[k];
-                            if (dual) sum2 += v[k] * xg2[k];
+                            if (dual_t) sum2 += v[k] * xg2[k];
                         }
                     }
                 }
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pattern_kernel(CsrView A, SpmvArg
                     const double vv = A.val[j];
                     const int cc = A.col[j];
                     sum += vv * a.x[cc];
-                    if (dual) sum2 += vv * a.x2[cc];
+                    if (dual_t) sum2 += vv * a.x2[cc];
                 }
             }
         } else {
@@ -338,10 +340,10 @@ __global__ __launch_bounds__(kBlock) void spmv_pattern_kernel(CsrView A, SpmvArg
             double part = 0.0, part2 = 0.0;
             for (int i = s + tid; i < e; i += kBlock) {
                 part += A.val[i] * a.x[A.col[i]];
-                if (dual) part2 += A.val[i] * a.x2[A.col[i]];
+                if (dual_t) part2 += A.val[i] * a.x2[A.col[i]];
             }
             sum = block_sum(part, red);
-            if (dual) sum2 = block_sum(part2, red);
+            if (dual_t) sum2 = block_sum(part2, red);
         }
         if (have_row) {
             const int rw = (r1 - r0 > 1) ? row : r0;
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pattern_kernel(CsrView A, SpmvArg
                 acc0 += r * z;
                 acc1 += r * r;
                 if (MODE == kSpmvResidDual && rw < a.row_limit) {
-                    const double r2 = dual ? bb - sum2 : r;
+                    const double r2 = dual_t ? bb - sum2 : r;
                     acc2 += r2 * r2;
                 }
             } else {  // kSpmvResidNorm

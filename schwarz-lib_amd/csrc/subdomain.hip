@@ -96,6 +96,9 @@ int schwz_subdomain_to_device(schwz_subdomain *sd, const double *h_local_rhs, co
     sd->nnz_interface = (int64_t)i_col.size();
     if ((rc = schwz_csr_create(n, n, sd->l_rp.data(), sd->l_col.data(), sd->l_val.data(), &sd->A))) return rc;
     sd->on_device = true;  // from here on destroy() releases device memory
+    // x~ and the CG iterate coincide on the interior: only tiles reaching the overlap need the
+    // second product of the fused check+start residual kernel
+    if (sd->overlap_size > 0 && (rc = csr_set_dual_split(sd->A, sd->l_rp.data(), sd->l_col.data(), sd->local_size))) return rc;
     if ((rc = dev_upload(i_rp, &sd->d_i_rp)) || (rc = dev_upload(i_col, &sd->d_i_col)) ||
         (rc = dev_upload(sd->i_val, &sd->d_i_val)) || (rc = dev_upload(put_idx, &sd->d_put_idx)) ||
         (rc = dev_upload(get_idx, &sd->d_get_idx)))
