@@ -177,6 +177,12 @@ int schwz_problem_permute(const schwz_problem *p, int P, const uint32_t *h_part,
                           int64_t *h_perm, int64_t *h_first_row,
                           schwz_problem **out);
 
+/* Initialize::generate_rhs (source/initialization.cpp:88-96): entry g of the sequence
+ * std::uniform_real_distribution<double>(0,1) draws from a default-seeded
+ * std::default_random_engine (libstdc++: minstd_rand0, two draws per value).  Random access by
+ * global row id (LCG jump-ahead), so no rank generates or broadcasts the whole vector
+ * (source/schwarz_base.cpp:169-182 does). */
+int schwz_rhs_random(int64_t count, const int64_t *h_global_ids, double *h_out);
 /* contiguous row blocks (source/restricted_schwarz.cpp:84,97-102) */
 int schwz_partition_regular(int64_t N, int P, int64_t *h_first_row);
 /* PartitionTools::PartitionRegular2D (include/partition_tools.hpp:70-106) */

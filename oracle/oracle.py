@@ -85,6 +85,7 @@ def lib():
     L.schwz_or_laplacian2d.argtypes = [C.c_int, vp, vp, vp]
     L.schwz_or_laplacian3d.restype = i64
     L.schwz_or_laplacian3d.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp]
+    L.schwz_or_rhs_random.argtypes = [i64, vp]
     L.schwz_or_first_rows_regular.argtypes = [i64, C.c_int, vp]
     L.schwz_or_partition_regular2d.argtypes = [C.c_int, C.c_int, vp]
     L.schwz_or_partition_regular2d.restype = C.c_int
@@ -177,6 +178,12 @@ def laplacian3d(nx, ny=None, nz=None):
     val = np.zeros(nnz, dtype=np.float64)
     L.schwz_or_laplacian3d(nx, ny, nz, _p(rp), _p(col), _p(val))
     return rp, col, val
+
+
+def rhs_random(N):
+    out = np.zeros(N, dtype=np.float64)
+    lib().schwz_or_rhs_random(N, _p(out))
+    return out
 
 
 def first_rows_regular(N, P):

@@ -122,6 +122,26 @@ void schwz_or_rhs_ones(int64_t n, double *rhs)
     for (int64_t i = 0; i < n; ++i) rhs[i] = 1.0;
 }
 
+/* source/initialization.cpp:88-96.  std::default_random_engine is minstd_rand0 in libstdc++
+ * (x <- 16807 x mod 2^31-1, seed 1); uniform_real_distribution<double>(0,1) draws through
+ * generate_canonical<double,53>, which consumes two values per result. */
+void schwz_or_rhs_random(int64_t n, double *rhs)
+{
+    uint64_t x = 1;
+    const long double range = 2147483646.0L;
+    for (int64_t i = 0; i < n; ++i) {
+        double sum = 0.0, tmp = 1.0;
+        for (int k = 0; k < 2; ++k) {
+            x = x * 16807ull % 2147483647ull;
+            sum += (double)(x - 1) * tmp;
+            tmp = (double)(tmp * range);
+        }
+        double ret = sum / tmp;
+        if (ret >= 1.0) ret = nextafter(1.0, 0.0);
+        rhs[i] = ret;
+    }
+}
+
 /* ======================================================================== */
 /* partitioning                                                              */
 /* ======================================================================== */

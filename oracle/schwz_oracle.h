@@ -45,6 +45,10 @@ int64_t schwz_or_laplacian3d(int nx, int ny, int nz, or_idx *row_ptr,
 
 /* rhs: all ones (source/schwarz_base.cpp:169). */
 void schwz_or_rhs_ones(int64_t n, double *rhs);
+/* Initialize::generate_rhs (source/initialization.cpp:88-96): the libstdc++ sequence of
+ * uniform_real_distribution<double>(0,1) over a default-seeded default_random_engine */
+void schwz_or_rhs_random(int64_t n, double *rhs);
+
 
 /* ---- partitioning -------------------------------------------------------- */
 

@@ -279,6 +279,38 @@ int schwz_problem_permute(const schwz_problem *p, int P, const uint32_t *part, i
     return schwz_problem_from_csr(N, rp.data(), col.data(), val.data(), out);
 }
 
+// minstd_rand0 (x <- 16807 x mod 2^31-1, seed 1) and libstdc++'s generate_canonical<double,53>
+// with two draws, evaluated in the same floating-point order
+int schwz_rhs_random(int64_t count, const int64_t *ids, double *out)
+{
+    SCHWZ_REQUIRE(count >= 0 && (count == 0 || (ids && out)), "schwz_rhs_random: bad arguments");
+    const uint64_t m = 2147483647ull, a = 16807ull;
+    const long double range = 2147483646.0L;  // max() - min() + 1
+    auto powmod = [&](uint64_t e) {
+        uint64_t r = 1, b = a;
+        while (e) {
+            if (e & 1) r = r * b % m;
+            b = b * b % m;
+            e >>= 1;
+        }
+        return r;
+    };
+    for (int64_t i = 0; i < count; ++i) {
+        SCHWZ_REQUIRE(ids[i] >= 0, "schwz_rhs_random: negative row id");
+        const uint64_t x1 = powmod(2 * (uint64_t)ids[i] + 1);  // state after 2g+1 steps from seed 1
+        const uint64_t x2 = x1 * a % m;
+        double sum = 0.0, tmp = 1.0;
+        sum += (double)(x1 - 1) * tmp;
+        tmp = (double)(tmp * range);
+        sum += (double)(x2 - 1) * tmp;
+        tmp = (double)(tmp * range);
+        double ret = sum / tmp;
+        if (ret >= 1.0) ret = std::nextafter(1.0, 0.0);
+        out[i] = ret;  // (b - a) * ret + a with a = 0, b = 1
+    }
+    return SCHWZ_OK;
+}
+
 // source/restricted_schwarz.cpp:84,97-102
 int schwz_partition_regular(int64_t N, int P, int64_t *first_row)
 {

@@ -73,6 +73,7 @@ struct SchwarzBase<ValueType, IndexType, MixedValueType>::Impl {
     double *h_send = nullptr, *h_recv = nullptr;  // pinned staging
     hipStream_t stream = nullptr;
     int device = 0;
+    double rhs_sq_interior = 0.0;
 
     ~Impl()
     {
@@ -134,7 +135,6 @@ void SchwarzBase<V, I, M>::initialize()
 
     // ---- options the GPU path does not provide ------------------------------------------
     if (s.non_symmetric_matrix) throw ::NotImplemented(__FILE__, __LINE__, "GMRES (non_symmetric_matrix)");
-    if (s.enable_random_rhs) throw ::NotImplemented(__FILE__, __LINE__, "enable_random_rhs");
     schwz_solver_options opt{};
     switch (s.local_solver) {
     case Settings::local_solver_settings::iterative_solver_ginkgo:
@@ -279,6 +279,14 @@ void SchwarzBase<V, I, M>::initialize()
     local_rhs = gko::share(gko::matrix::Dense<V>::create(s.executor->get_master(), gko::dim<2>(m.local_size_x, 1)));
     local_solution = gko::share(gko::matrix::Dense<V>::create(s.executor->get_master(), gko::dim<2>(m.local_size_x, 1)));
     std::vector<double> rhs((size_t)m.local_size_x, 1.0);
+    if (s.enable_random_rhs && s.explicit_laplacian && s.matrix_filename == "null") {
+        // Initialize::generate_rhs (initialization.cpp:88-96), by global row id
+        std::vector<int64_t> l2g((size_t)(im.sizes[1] + im.sizes[3]));
+        SCHWZ_CALL(schwz_subdomain_local_to_global(im.sd, l2g.data()));
+        SCHWZ_CALL(schwz_rhs_random((int64_t)rhs.size(), l2g.data(), rhs.data()));
+    }
+    im.rhs_sq_interior = 0.0;
+    for (gko::size_type i = 0; i < m.local_size; ++i) im.rhs_sq_interior += rhs[i] * rhs[i];
     for (size_t i = 0; i < rhs.size(); ++i) local_rhs->at(i) = (V)rhs[i];
     SCHWZ_CALL(schwz_subdomain_to_device(im.sd, rhs.data(), &opt));
 
@@ -441,7 +449,7 @@ void SchwarzBase<V, I, M>::run(std::shared_ptr<gko::matrix::Dense<V>> &solution)
         std::cout << " Rank " << me << " converged in " << m.iter_count << " iterations " << std::endl;
     }
     exchange();
-    double part = 0.0, res_sq = 0.0, rhs_sq_loc = (double)m.local_size, rhs_sq = 0.0;
+    double part = 0.0, res_sq = 0.0, rhs_sq_loc = im.rhs_sq_interior, rhs_sq = 0.0;
     SCHWZ_CALL(schwz_ras_true_residual_sq(im.sd, &part, im.stream));
     MPI_Allreduce(&part, &res_sq, 1, MPI_DOUBLE, MPI_SUM, MPI_COMM_WORLD);
     MPI_Allreduce(&rhs_sq_loc, &rhs_sq, 1, MPI_DOUBLE, MPI_SUM, MPI_COMM_WORLD);

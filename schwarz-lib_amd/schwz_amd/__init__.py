@@ -8,7 +8,7 @@ from . import _capi as capi  # noqa: F401  (loads libschwz_hip.so)
 from ._capi import SchwzError, NotImplementedSchwz  # noqa: F401
 from .comm import InProcessComm, TorchDistComm  # noqa: F401
 from .core import (Csr, Pcg, Problem, Subdomain, Trs, cholesky, gather, scatter,  # noqa: F401
-                   partition_regular, partition_regular2d)
+                   partition_regular, partition_regular2d, rhs_random)
 from .solver import (HipBackend, Metadata, Settings, SolverRAS,  # noqa: F401
                      PARTITION_CUSTOM, PARTITION_METIS, PARTITION_REGULAR, PARTITION_REGULAR2D,
                      SOLVER_DIRECT_CHOLMOD, SOLVER_DIRECT_GINKGO, SOLVER_DIRECT_UMFPACK,

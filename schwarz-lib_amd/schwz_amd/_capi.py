@@ -34,7 +34,7 @@ SYMBOLS = [
     "schwz_problem_laplacian", "schwz_problem_from_csr", "schwz_problem_from_matrix_market",
     "schwz_problem_destroy", "schwz_problem_size", "schwz_problem_nnz", "schwz_problem_row",
     "schwz_problem_permute",
-    "schwz_partition_regular", "schwz_partition_regular2d", "schwz_partition_graph",
+    "schwz_rhs_random", "schwz_partition_regular", "schwz_partition_regular2d", "schwz_partition_graph",
     "schwz_subdomain_setup", "schwz_subdomain_destroy", "schwz_subdomain_sizes",
     "schwz_subdomain_local_to_global", "schwz_subdomain_local_matrix",
     "schwz_subdomain_interface_matrix", "schwz_subdomain_get_list",
@@ -118,6 +118,7 @@ _sig("schwz_problem_size", i64, [vp])
 _sig("schwz_problem_nnz", i64, [vp])
 _sig("schwz_problem_row", i32, [vp, i64, C.POINTER(C.c_int), vp, vp, i32])
 _sig("schwz_problem_permute", i32, [vp, i32, vp, vp, vp, pvp])
+_sig("schwz_rhs_random", i32, [i64, vp, vp])
 _sig("schwz_partition_regular", i32, [i64, i32, vp])
 _sig("schwz_partition_regular2d", i32, [i64, i32, vp])
 _sig("schwz_partition_graph", i32, [vp, i32, vp])

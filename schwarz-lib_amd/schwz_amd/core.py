@@ -223,6 +223,14 @@ class Problem:
         self.close()
 
 
+def rhs_random(global_ids):
+    """Initialize::generate_rhs (initialization.cpp:88-96) by global row id."""
+    ids = np.ascontiguousarray(global_ids, dtype=np.int64)
+    out = np.zeros(max(len(ids), 1), dtype=np.float64)
+    check(lib.schwz_rhs_random(len(ids), ptr(ids), ptr(out)))
+    return out[:len(ids)]
+
+
 def partition_regular(N, P):
     fr = np.zeros(P + 1, dtype=np.int64)
     check(lib.schwz_partition_regular(N, P, ptr(fr)))

@@ -270,11 +270,12 @@ class SolverRAS:
         return prob
 
     def _rhs(self, ids):
-        """rhs = 1.0 (schwarz_base.cpp:169).  The random rhs of
-        initialization.cpp:88-96 is not reproduced."""
-        if self.settings.enable_random_rhs:
-            raise capi.NotImplementedSchwz(capi.ERR_NOT_IMPLEMENTED,
-                                           "enable_random_rhs is not implemented")
+        """rhs = 1.0, or the default-seeded uniform(0,1) sequence when enable_random_rhs is set
+        together with explicit_laplacian (schwarz_base.cpp:169-173, initialization.cpp:88-96).
+        As in the reference the rhs is indexed by the (possibly permuted) row id."""
+        if self.settings.enable_random_rhs and self.settings.explicit_laplacian \
+                and self.settings.matrix_filename == "null":
+            return core.rhs_random(ids)
         return np.ones(len(ids), dtype=np.float64)
 
     def initialize(self):

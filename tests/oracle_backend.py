@@ -75,13 +75,16 @@ class OracleSubdomain:
 
     def to_device(self, local_rhs, local_solver=0, precond=0, local_tol=1e-12, local_max_iters=-1,
                   natural_factor_ordering=False, spmv_variant=0):
-        # the oracle state extracts the local rhs from a global vector; rhs is all ones
-        assert np.all(np.asarray(local_rhs) == 1.0)
+        # the oracle state extracts the local rhs from a global vector: rebuild the entries it
+        # will read
+        rhs = np.zeros(self.sd.N)
+        rhs[self.sd.local_to_global[:self.local_size_x]] = np.asarray(local_rhs)
+        self._rhs_global = rhs
         s = O.make_settings(overlap=self.overlap, local_solver=local_solver, precond=precond,
                             local_tol=local_tol, local_max_iters=local_max_iters,
                             natural_factor_ordering=int(natural_factor_ordering))
         self._settings = s
-        self.state = O.State(self.sd, np.ones(self.sd.N), s)
+        self.state = O.State(self.sd, rhs, s)
 
     def pack(self, d_send, stream=0):
         buf = _view(d_send, self.num_send)
@@ -116,7 +119,7 @@ class OracleSubdomain:
         rp, col, val = self.sd.local_matrix()
         x = self.state.global_solution()[self.sd.local_to_global[:self.local_size_x]]
         ax = O.spmv(rp, col, val, x)
-        r = 1.0 - ax[:self.local_size]
+        r = self._rhs_global[self.sd.local_to_global[:self.local_size]] - ax[:self.local_size]
         return float(np.dot(r, r))
 
     def algorithmic_bytes(self, which=0):

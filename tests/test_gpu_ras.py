@@ -47,7 +47,8 @@ def _check_against_oracle(oracle, csr, P, solver, m, out, x_ref=None, exact_iter
     rp, col, val = csr
     N = len(rp) - 1
     fr = np.asarray(m.first_row, dtype=np.int32)
-    r = oracle.ras_run(rp, col, val, np.ones(N), P, fr, _oracle_settings(oracle, m, solver.settings))
+    rhs = oracle.rhs_random(N) if solver.settings.enable_random_rhs else np.ones(N)
+    r = oracle.ras_run(rp, col, val, rhs, P, fr, _oracle_settings(oracle, m, solver.settings))
     if truncated_cg:
         assert abs(out["iter_count"] - r["iter_count"]) <= 2
     elif exact_iters:
@@ -355,3 +356,15 @@ def test_ras_overlapped_decentralized_matches_oracle(schwz, oracle, torch_cuda, 
     sync = schwz.SolverRAS(s2, m2, comm=schwz.InProcessComm(P), quiet=True)
     sync.initialize()
     assert sync.run()["iter_count"] < out["iter_count"]
+
+
+def test_ras_random_rhs(schwz, oracle, torch_cuda):
+    """--enable_random_rhs: the rhs is the reference's default-seeded uniform(0,1) sequence
+    (pinned to libstdc++ in tests/test_oracle_golden.py); each subdomain generates its own
+    entries by global row id."""
+    n, P = 24, 3
+    solver, m, out = _run_gpu(schwz, P, dict(enable_random_rhs=True),
+                              dict(oned_laplacian_size=n, tolerance=1e-8, max_iters=400))
+    _check_against_oracle(oracle, oracle.laplacian2d(n), P, solver, m, out)
+    assert out["converged"]
+    assert abs(out["rhs_norm"] - np.linalg.norm(oracle.rhs_random(n * n))) < 1e-12 * out["rhs_norm"]

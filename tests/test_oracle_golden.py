@@ -203,3 +203,22 @@ def test_truncated_cg_trajectory_is_rounding_sensitive(oracle):
     assert dev["converged"] < 1e-12
     assert dev["truncated"] > 1e3 * dev["converged"]
     assert dev["truncated"] < 2e-6
+
+
+# first values, entry 1000 and entry 123456 of
+#   std::uniform_real_distribution<double> unif(0.0, 1.0); std::default_random_engine engine;
+# printed with %.17g by g++ 11.4 / libstdc++ in this container (Initialize::generate_rhs,
+# source/initialization.cpp:88-96)
+RANDOM_RHS_HEAD = [0.13153778773876065, 0.4586501320232198, 0.21895918621247895, 0.67886471674068549,
+                   0.93469289622673879, 0.51941637202274749, 0.034572110464847441, 0.52970019314105721]
+RANDOM_RHS_1000 = 0.065227306861153342
+RANDOM_RHS_123456 = 0.47647455830667862
+
+
+def test_random_rhs_is_the_libstdcxx_sequence(oracle, schwz):
+    r = oracle.rhs_random(123457)
+    assert r[:8].tolist() == RANDOM_RHS_HEAD and r[1000] == RANDOM_RHS_1000 and r[123456] == RANDOM_RHS_123456
+    # the product generates any entry by global row id (no N-long vector, no broadcast)
+    ids = np.array([123456, 0, 7, 1000, 5, 99999], dtype=np.int64)
+    assert np.array_equal(schwz.rhs_random(ids), r[ids])
+    assert np.array_equal(schwz.rhs_random(np.arange(4096)), r[:4096])
