@@ -268,6 +268,12 @@ int schwz_ras_pack(schwz_subdomain *sd, double *d_send, schwz_stream stream);
  * (restricted_schwarz.cpp:950-962; CommHelpers::unpack_buffer,
  * include/comm_helpers.hpp:154-177).  d_recv has num_recv entries. */
 int schwz_ras_unpack(schwz_subdomain *sd, const double *d_recv, schwz_stream stream);
+/* Mixed-precision variants of step 0 (settings.use_mixed_precision with MixedValueType =
+ * float): the packed halo travels as fp32 -- the reference converts the fp64 send buffer with
+ * Dense::convert_to before MPI_Isend and back after the receive
+ * (restricted_schwarz.cpp:898-903, 929-933, 952-954).  Half the xGMI bytes. */
+int schwz_ras_pack_f32(schwz_subdomain *sd, float *d_send, schwz_stream stream);
+int schwz_ras_unpack_f32(schwz_subdomain *sd, const float *d_recv, schwz_stream stream);
 /* step 1: b~ = b_loc - A_Gamma x~ (SolverRAS::update_boundary,
  * restricted_schwarz.cpp:992-1017) */
 int schwz_ras_update_boundary(schwz_subdomain *sd, schwz_stream stream);

@@ -36,18 +36,20 @@ class Settings(C.Structure):
         ("natural_factor_ordering", C.c_int32),
         ("num_threads", C.c_int32),
         ("enable_overlap", C.c_int32),
+        ("use_mixed_precision", C.c_int32),
     ]
 
 
 def make_settings(max_iters=100, tol=1e-6, overlap=2, local_solver=SOLVER_ITERATIVE,
                   precond=PRECOND_NONE, local_tol=1e-12, local_max_iters=-1,
                   enable_global_check=1, enable_onesided=0, global_check_iter_offset=0,
-                  natural_factor_ordering=0, num_threads=0, enable_overlap=0):
+                  natural_factor_ordering=0, num_threads=0, enable_overlap=0, use_mixed_precision=0):
     """Defaults follow benchmarking/bench_base.hpp:50-144 except
     enable_global_check (needed to ever stop)."""
     return Settings(max_iters, tol, overlap, local_solver, precond, local_tol,
                     local_max_iters, enable_global_check, enable_onesided,
-                    global_check_iter_offset, natural_factor_ordering, num_threads, enable_overlap)
+                    global_check_iter_offset, natural_factor_ordering, num_threads, enable_overlap,
+                    use_mixed_precision)
 
 
 class Result(C.Structure):

@@ -933,6 +933,8 @@ void schwz_or_pack(or_state *st, int k, double *send)
 {
     const or_idx *lst = st->sd->put[k];
     schwz_or_gather(lst[0], lst + 1, st->global_solution, send, 1);
+    if (st->s.use_mixed_precision) /* send_buffer->convert_to(mixedt_send_buffer), :898-903 */
+        for (or_idx i = 0; i < lst[0]; ++i) send[i] = (double)(float)send[i];
 }
 
 /* restricted_schwarz.cpp:950-962: global_solution[global_get[k][1+i]] = recv[i] */

@@ -119,6 +119,9 @@ typedef struct {
      * asynchronous model of this build -- halos are consumed one iteration late and the
      * stop decision is flooded over neighbour messages (see schwz_or_ras_run) */
     int32_t enable_overlap;
+    /* settings.use_mixed_precision with MixedValueType=float: halo values are rounded to fp32
+     * on the wire (restricted_schwarz.cpp:898-903,952-954) */
+    int32_t use_mixed_precision;
 } or_settings;
 
 /* ---- per-subdomain state and the five loop steps (A.3) -------------------- */

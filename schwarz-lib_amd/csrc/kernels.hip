@@ -1080,6 +1080,23 @@ __global__ void scatter_kernel(int64_t n, const schwz_idx *__restrict__ idx,
     }
 }
 
+// halo pack / unpack with the fp64 <-> fp32 conversion of the mixed-precision exchange
+__global__ void gather_f32_kernel(int64_t n, const schwz_idx *__restrict__ idx, const double *__restrict__ from,
+                                  float *__restrict__ into)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        into[i] = (float)from[idx[i]];
+}
+
+__global__ void scatter_f32_kernel(int64_t n, const schwz_idx *__restrict__ idx, const float *__restrict__ from,
+                                   double *__restrict__ into)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        into[idx[i]] = (double)from[i];
+}
+
 static int grid_for(int64_t n)
 {
     int64_t g = (n + kBlock - 1) / kBlock;
@@ -1867,6 +1884,22 @@ int csr_set_dual_split(schwz_csr *A, const schwz_idx *h_rp, const schwz_idx *h_c
     SCHWZ_HIP_TRY(hipMalloc(&A->d_tile_dual, flag.size()));
     SCHWZ_HIP_TRY(hipMemcpy(A->d_tile_dual, flag.data(), flag.size(), hipMemcpyHostToDevice));
     A->v.tile_dual = (const uint8_t *)A->d_tile_dual;
+    return SCHWZ_OK;
+}
+
+int launch_gather_f32(int64_t n, const schwz_idx *idx, const double *from, float *into, hipStream_t s)
+{
+    if (n == 0) return SCHWZ_OK;
+    hipLaunchKernelGGL(gather_f32_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, n, idx, from, into);
+    SCHWZ_HIP_TRY(hipGetLastError());
+    return SCHWZ_OK;
+}
+
+int launch_scatter_f32(int64_t n, const schwz_idx *idx, const float *from, double *into, hipStream_t s)
+{
+    if (n == 0) return SCHWZ_OK;
+    hipLaunchKernelGGL(scatter_f32_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, n, idx, from, into);
+    SCHWZ_HIP_TRY(hipGetLastError());
     return SCHWZ_OK;
 }
 

@@ -19,6 +19,8 @@ int launch_interface_update(int64_t nrows, int64_t row0, const schwz_idx *rp, co
                             const double *val, const double *x, const double *b, double *bt, hipStream_t s);
 int launch_final_norm(const double *partials, int nparts, double *out, hipStream_t s);
 int launch_copy(int64_t n, const double *src, double *dst, hipStream_t s);
+int launch_gather_f32(int64_t n, const schwz_idx *idx, const double *from, float *into, hipStream_t s);
+int launch_scatter_f32(int64_t n, const schwz_idx *idx, const float *from, double *into, hipStream_t s);
 }  // namespace schwz
 
 using namespace schwz;
@@ -152,6 +154,22 @@ int schwz_ras_unpack(schwz_subdomain *sd, const double *d_recv, schwz_stream str
     if (sd->num_recv == 0) return SCHWZ_OK;
     SCHWZ_REQUIRE(d_recv, "schwz_ras_unpack: null recv buffer");
     return schwz_scatter(sd->num_recv, sd->d_get_idx, d_recv, sd->d_x, SCHWZ_OP_COPY, stream);
+}
+
+int schwz_ras_pack_f32(schwz_subdomain *sd, float *d_send, schwz_stream stream)
+{
+    REQUIRE_DEVICE(sd, "schwz_ras_pack_f32");
+    if (sd->num_send == 0) return SCHWZ_OK;
+    SCHWZ_REQUIRE(d_send, "schwz_ras_pack_f32: null send buffer");
+    return launch_gather_f32(sd->num_send, sd->d_put_idx, sd->d_x, d_send, (hipStream_t)stream);
+}
+
+int schwz_ras_unpack_f32(schwz_subdomain *sd, const float *d_recv, schwz_stream stream)
+{
+    REQUIRE_DEVICE(sd, "schwz_ras_unpack_f32");
+    if (sd->num_recv == 0) return SCHWZ_OK;
+    SCHWZ_REQUIRE(d_recv, "schwz_ras_unpack_f32: null recv buffer");
+    return launch_scatter_f32(sd->num_recv, sd->d_get_idx, d_recv, sd->d_x, (hipStream_t)stream);
 }
 
 int schwz_ras_update_boundary(schwz_subdomain *sd, schwz_stream stream)

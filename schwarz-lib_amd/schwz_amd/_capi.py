@@ -41,7 +41,8 @@ SYMBOLS = [
     "schwz_subdomain_add_put_list", "schwz_subdomain_put_list",
     "schwz_subdomain_send_offset", "schwz_subdomain_recv_offset",
     "schwz_cholesky", "schwz_free",
-    "schwz_subdomain_to_device", "schwz_ras_pack", "schwz_ras_unpack",
+    "schwz_subdomain_to_device", "schwz_ras_pack", "schwz_ras_unpack", "schwz_ras_pack_f32",
+    "schwz_ras_unpack_f32",
     "schwz_ras_update_boundary", "schwz_ras_local_residual", "schwz_ras_local_residual_launch",
     "schwz_ras_local_residual_wait", "schwz_ras_local_solve", "schwz_ras_check_and_solve_launch",
     "schwz_ras_restrict", "schwz_ras_vector", "schwz_ras_local_csr", "schwz_ras_get_interior",
@@ -138,6 +139,8 @@ _sig("schwz_free", None, [vp])
 _sig("schwz_subdomain_to_device", i32, [vp, vp, C.POINTER(SolverOptions)])
 _sig("schwz_ras_pack", i32, [vp, vp, vp])
 _sig("schwz_ras_unpack", i32, [vp, vp, vp])
+_sig("schwz_ras_pack_f32", i32, [vp, vp, vp])
+_sig("schwz_ras_unpack_f32", i32, [vp, vp, vp])
 _sig("schwz_ras_update_boundary", i32, [vp, vp])
 _sig("schwz_ras_local_residual", i32, [vp, C.POINTER(dbl), vp])
 _sig("schwz_ras_local_residual_launch", i32, [vp, vp])

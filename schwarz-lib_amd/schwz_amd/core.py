@@ -345,6 +345,12 @@ class Subdomain:
     def unpack(self, d_recv, stream=0):
         check(lib.schwz_ras_unpack(self.h, ptr(d_recv), _stream_arg(stream)))
 
+    def pack_f32(self, d_send, stream=0):
+        check(lib.schwz_ras_pack_f32(self.h, ptr(d_send), _stream_arg(stream)))
+
+    def unpack_f32(self, d_recv, stream=0):
+        check(lib.schwz_ras_unpack_f32(self.h, ptr(d_recv), _stream_arg(stream)))
+
     def update_boundary(self, stream=0):
         check(lib.schwz_ras_update_boundary(self.h, _stream_arg(stream)))
 

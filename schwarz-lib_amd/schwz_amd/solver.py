@@ -146,8 +146,9 @@ class HipBackend:
     def stream(self):
         return self._torch.cuda.current_stream().cuda_stream
 
-    def empty(self, n):
-        return self._torch.empty(max(int(n), 1), dtype=self._torch.float64, device=self.device)
+    def empty(self, n, single=False):
+        return self._torch.empty(max(int(n), 1), device=self.device,
+                                 dtype=self._torch.float32 if single else self._torch.float64)
 
     def synchronize(self):
         self._torch.cuda.synchronize()
@@ -302,8 +303,9 @@ class SolverRAS:
                          local_tol=m.local_solver_tolerance, local_max_iters=m.local_max_iters,
                          natural_factor_ordering=s.naturally_ordered_factor,
                          spmv_variant=s.spmv_variant)
-            self.send_buf[me] = be.empty(sd.num_send)
-            self.recv_buf[me] = be.empty(sd.num_recv)
+            # use_mixed_precision (MixedValueType = float): halos travel as fp32
+            self.send_buf[me] = be.empty(sd.num_send, s.use_mixed_precision)
+            self.recv_buf[me] = be.empty(sd.num_recv, s.use_mixed_precision)
         first = self.subdomains[comm.local_ranks[0]]
         m.local_size, m.local_size_x = first.local_size, first.local_size_x
         m.overlap_size, m.local_size_o = first.overlap_size, m.global_size
@@ -329,13 +331,25 @@ class SolverRAS:
             self._print(" Local direct solve with HIP TRS")
 
     # -------------------------------------------------------------------- run
+    def _pack(self, me, sd, stream):
+        if self.settings.use_mixed_precision:
+            sd.pack_f32(self.send_buf[me].data_ptr(), stream)
+        else:
+            sd.pack(self.send_buf[me].data_ptr(), stream)
+
+    def _unpack(self, me, sd, stream):
+        if self.settings.use_mixed_precision:
+            sd.unpack_f32(self.recv_buf[me].data_ptr(), stream)
+        else:
+            sd.unpack(self.recv_buf[me].data_ptr(), stream)
+
     def _exchange(self):
         stream = self.backend.stream()
         for me, sd in self.subdomains.items():
-            sd.pack(self.send_buf[me].data_ptr(), stream)
+            self._pack(me, sd, stream)
         self.comm.exchange(self._sends, self._recvs)
         for me, sd in self.subdomains.items():
-            sd.unpack(self.recv_buf[me].data_ptr(), stream)
+            self._unpack(me, sd, stream)
 
     def begin_run(self):
         """State of SchwarzBase::run before its loop (schwarz_base.cpp:340-386)."""
@@ -382,7 +396,7 @@ class SolverRAS:
         if self._pending is not None:
             comm.finish_exchange(self._pending["halo"])
             for me, sd in locals_:
-                sd.unpack(self.recv_buf[me].data_ptr(), stream)
+                self._unpack(me, sd, stream)
             for me, msgs in comm.finish_flags(self._pending["flags"]).items():
                 for mk, st in msgs:
                     self._mask[me] |= mk
@@ -393,7 +407,7 @@ class SolverRAS:
         halo = None
         if not last:
             for me, sd in locals_:
-                sd.pack(self.send_buf[me].data_ptr(), stream)
+                self._pack(me, sd, stream)
             halo = comm.start_exchange(self._sends, self._recvs, overlap=True)
         t1 = time.perf_counter()
         # (c) boundary update, local test + local solve (enqueued together), restriction

@@ -133,7 +133,8 @@ class OracleBackend:
     def stream(self):
         return 0
 
-    def empty(self, n):
+    def empty(self, n, single=False):
+        assert not single, "the test backend exchanges fp64 halos only"
         return torch.zeros(max(int(n), 1), dtype=torch.float64)
 
     def synchronize(self):

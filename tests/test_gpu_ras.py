@@ -32,6 +32,7 @@ def _oracle_settings(oracle, m, s, **kw):
         enable_global_check=int(s.convergence_settings.enable_global_check),
         enable_onesided=int(s.comm_settings.enable_onesided),
         enable_overlap=int(s.comm_settings.enable_overlap),
+        use_mixed_precision=int(s.use_mixed_precision),
         natural_factor_ordering=int(s.naturally_ordered_factor), **kw)
 
 
@@ -368,3 +369,16 @@ def test_ras_random_rhs(schwz, oracle, torch_cuda):
     _check_against_oracle(oracle, oracle.laplacian2d(n), P, solver, m, out)
     assert out["converged"]
     assert abs(out["rhs_norm"] - np.linalg.norm(oracle.rhs_random(n * n))) < 1e-12 * out["rhs_norm"]
+
+
+def test_ras_mixed_precision_halo(schwz, oracle, torch_cuda):
+    """use_mixed_precision: halos cross the wire as fp32.  The oracle rounds the packed values
+    the same way, so histories agree to fp64 tolerance; the attainable accuracy is limited by
+    the fp32 halos (final residual ~1e-7 relative, not 1e-12)."""
+    n, P = 24, 4
+    solver, m, out = _run_gpu(schwz, P, dict(use_mixed_precision=True),
+                              dict(oned_laplacian_size=n, tolerance=1e-6, max_iters=400))
+    _check_against_oracle(oracle, oracle.laplacian2d(n), P, solver, m, out)
+    assert out["converged"]
+    full, m2, out2 = _run_gpu(schwz, P, dict(), dict(oned_laplacian_size=n, tolerance=1e-6, max_iters=400))
+    assert 0 < np.abs(out["solution"] - out2["solution"]).max() < 1e-4 * np.abs(out2["solution"]).max()
