@@ -51,9 +51,15 @@ enum schwz_op { SCHWZ_OP_ADD = 0, SCHWZ_OP_COPY = 1, SCHWZ_OP_DIFF = 2, SCHWZ_OP
 /* Settings::local_solver_settings (include/settings.hpp) as used by
  * Solve::local_solve (source/solve.cpp:667-792) */
 enum schwz_local_solver { SCHWZ_SOLVER_ITERATIVE = 0, SCHWZ_SOLVER_DIRECT = 1 };
-/* metadata.local_precond (source/solve.cpp:486-652): "null" and
- * "block-jacobi" with precond_max_block_size = 1 */
-enum schwz_precond { SCHWZ_PRECOND_NONE = 0, SCHWZ_PRECOND_JACOBI = 1 };
+/* metadata.local_precond (source/solve.cpp:486-652): "null", "block-jacobi"
+ * (gko::preconditioner::Jacobi, :490-505,575-589) and "ilu" (ParIlu + LowerTrs/UpperTrs,
+ * :506-532,590-615); "isai" is not provided */
+enum schwz_precond {
+    SCHWZ_PRECOND_NONE = 0,
+    SCHWZ_PRECOND_JACOBI = 1,       /* block-jacobi, precond_max_block_size = 1 */
+    SCHWZ_PRECOND_BLOCK_JACOBI = 2, /* block-jacobi, consecutive blocks of precond_max_block_size rows */
+    SCHWZ_PRECOND_ILU = 3           /* ilu: ILU(0) + lower/upper triangular sweeps per iteration */
+};
 
 const char *schwz_last_error(void);
 const char *schwz_version(void);
@@ -110,6 +116,9 @@ int schwz_csr_spmv(const schwz_csr *A, double alpha, const double *d_x,
  * sync only when requested. */
 typedef struct schwz_pcg schwz_pcg;
 int schwz_pcg_create(const schwz_csr *A, int precond, schwz_pcg **out);
+/* the same with the block size of SCHWZ_PRECOND_BLOCK_JACOBI (metadata.precond_max_block_size,
+ * 1..32) */
+int schwz_pcg_create_ex(const schwz_csr *A, int precond, int block_size, schwz_pcg **out);
 void schwz_pcg_destroy(schwz_pcg *s);
 int schwz_pcg_solve(schwz_pcg *s, const double *d_b, double *d_x, double rtol,
                     int max_iters, int *h_iters, double *h_resnorm,
@@ -134,7 +143,9 @@ int schwz_profile_end(double *h_total_ms, int64_t *h_launches);
  * Solve::local_solve (source/solve.cpp:709-720) and
  * SolverTools::solve_direct_ginkgo (include/solver_tools.hpp:69-87); also the
  * intent of the dead CusparseWrappers (include/cusparse_helpers.hpp:200-212).
- * L: CSR lower, diagonal last in each row; U = L^T: CSR upper, diagonal first. */
+ * L: CSR lower, diagonal last in each row; U: CSR upper, diagonal first (U = L^T for the
+ * Cholesky path; any L, U pair for ILU).  h_perm may be NULL (identity).  Factors whose level
+ * structure does not fit one workgroup are solved level by level with multi-workgroup launches. */
 typedef struct schwz_trs schwz_trs;
 int schwz_trs_create(int64_t n, const schwz_idx *h_l_rp, const schwz_idx *h_l_col,
                      const double *h_l_val, const schwz_idx *h_u_rp,
@@ -235,6 +246,13 @@ int schwz_cholesky(int64_t n, const schwz_idx *h_rp, const schwz_idx *h_col,
                    const double *h_val, int natural_ordering, schwz_idx **l_rp,
                    schwz_idx **l_col, double **l_val, schwz_idx **u_rp,
                    schwz_idx **u_col, double **u_val, schwz_idx **perm);
+/* Host ILU(0) on the pattern of A (columns sorted): L unit lower with the 1 stored LAST in each
+ * row, U upper with its diagonal FIRST -- the layout schwz_trs_create expects.  Stands in for
+ * gko::factorization::ParIlu (source/solve.cpp:506-532), whose sweeps converge to these
+ * factors.  Outputs are malloc'd; free with schwz_free. */
+int schwz_ilu0(int64_t n, const schwz_idx *h_rp, const schwz_idx *h_col, const double *h_val,
+               schwz_idx **l_rp, schwz_idx **l_col, double **l_val, schwz_idx **u_rp,
+               schwz_idx **u_col, double **u_val);
 void schwz_free(void *p);
 
 /* ------------------------------------------------------------------------ */
@@ -248,7 +266,7 @@ typedef struct {
     int32_t local_max_iters; /* -1 => local_size_x (solve.cpp:458-463) */
     int32_t natural_factor_ordering; /* settings.naturally_ordered_factor */
     int32_t spmv_variant;    /* 0 default */
-    int32_t reserved;
+    int32_t precond_block_size; /* metadata.precond_max_block_size (block-jacobi) */
 } schwz_solver_options;
 
 /* Upload matrices / index lists, allocate x~=[interior|overlap|halo] (zero,

@@ -18,7 +18,7 @@ c_dbl_p = C.POINTER(C.c_double)
 
 OP_ADD, OP_COPY, OP_DIFF, OP_AVG = 0, 1, 2, 3
 SOLVER_ITERATIVE, SOLVER_DIRECT = 0, 1
-PRECOND_NONE, PRECOND_JACOBI = 0, 1
+PRECOND_NONE, PRECOND_JACOBI, PRECOND_BLOCK_JACOBI, PRECOND_ILU = 0, 1, 2, 3
 
 
 class Settings(C.Structure):
@@ -37,19 +37,21 @@ class Settings(C.Structure):
         ("num_threads", C.c_int32),
         ("enable_overlap", C.c_int32),
         ("use_mixed_precision", C.c_int32),
+        ("precond_block_size", C.c_int32),
     ]
 
 
 def make_settings(max_iters=100, tol=1e-6, overlap=2, local_solver=SOLVER_ITERATIVE,
                   precond=PRECOND_NONE, local_tol=1e-12, local_max_iters=-1,
                   enable_global_check=1, enable_onesided=0, global_check_iter_offset=0,
-                  natural_factor_ordering=0, num_threads=0, enable_overlap=0, use_mixed_precision=0):
+                  natural_factor_ordering=0, num_threads=0, enable_overlap=0, use_mixed_precision=0,
+                  precond_block_size=1):
     """Defaults follow benchmarking/bench_base.hpp:50-144 except
     enable_global_check (needed to ever stop)."""
     return Settings(max_iters, tol, overlap, local_solver, precond, local_tol,
                     local_max_iters, enable_global_check, enable_onesided,
                     global_check_iter_offset, natural_factor_ordering, num_threads, enable_overlap,
-                    use_mixed_precision)
+                    use_mixed_precision, precond_block_size)
 
 
 class Result(C.Structure):
@@ -136,6 +138,9 @@ def lib():
     L.schwz_or_scatter.argtypes = [i64, vp, vp, vp, C.c_int]
     L.schwz_or_pcg.restype = C.c_int
     L.schwz_or_pcg.argtypes = [i64, vp, vp, vp, vp, vp, C.c_int, C.c_double, C.c_int, vp]
+    L.schwz_or_pcg_ex.restype = C.c_int
+    L.schwz_or_pcg_ex.argtypes = [i64, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_double, C.c_int, vp]
+    L.schwz_or_ilu0.argtypes = [i64, vp, vp, vp] + [C.POINTER(vp)] * 6
     L.schwz_or_cholesky.restype = C.c_int
     L.schwz_or_cholesky.argtypes = [i64, vp, vp, vp, C.c_int] + [C.POINTER(vp)] * 7
     L.schwz_or_direct_solve.argtypes = [i64] + [vp] * 10
@@ -415,16 +420,42 @@ def scatter(idx, src, into, op=OP_COPY):
     return into
 
 
-def pcg(rp, col, val, b, x0=None, precond=PRECOND_NONE, rtol=1e-12, max_iters=-1):
+def precond_code(local_precond, block_size=1):
+    """(OR_PRECOND_*, block size) of a --local_precond / --precond_max_block_size pair
+    (solve.cpp:488-571)."""
+    if local_precond == "block-jacobi":
+        return (1, 1) if int(block_size) == 1 else (2, int(block_size))
+    if local_precond == "ilu":
+        return 3, 1
+    return 0, 1
+
+
+def pcg(rp, col, val, b, x0=None, precond=PRECOND_NONE, rtol=1e-12, max_iters=-1, block_size=1):
     n = len(rp) - 1
     x = np.zeros(n, dtype=np.float64) if x0 is None else np.array(x0, dtype=np.float64)
     b = np.ascontiguousarray(b, dtype=np.float64)
     rn = C.c_double(0.0)
     if max_iters < 0:
         max_iters = n
-    it = lib().schwz_or_pcg(n, _p(rp), _p(col), _p(val), _p(b), _p(x), precond, rtol,
-                            max_iters, C.byref(rn))
+    it = lib().schwz_or_pcg_ex(n, _p(rp), _p(col), _p(val), _p(b), _p(x), precond, block_size, rtol,
+                               max_iters, C.byref(rn))
     return x, it, rn.value
+
+
+def ilu0(rp, col, val):
+    L = lib()
+    n = len(rp) - 1
+    ptrs = [C.c_void_p() for _ in range(6)]
+    L.schwz_or_ilu0(n, _p(rp), _p(col), _p(val), *[C.byref(p) for p in ptrs])
+    l_rp = _np_from(C.cast(ptrs[0], c_idx_p), n + 1, IDX)
+    u_rp = _np_from(C.cast(ptrs[3], c_idx_p), n + 1, IDX)
+    out = dict(l_rp=l_rp, l_col=_np_from(C.cast(ptrs[1], c_idx_p), int(l_rp[-1]), IDX),
+               l_val=_np_from(C.cast(ptrs[2], c_dbl_p), int(l_rp[-1]), np.float64),
+               u_rp=u_rp, u_col=_np_from(C.cast(ptrs[4], c_idx_p), int(u_rp[-1]), IDX),
+               u_val=_np_from(C.cast(ptrs[5], c_dbl_p), int(u_rp[-1]), np.float64))
+    for p in ptrs:
+        L.schwz_or_free(p)
+    return out
 
 
 def cholesky(rp, col, val, natural=False):

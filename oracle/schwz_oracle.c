@@ -554,50 +554,245 @@ static double dot(int64_t n, const double *a, const double *b)
  *   updates (stop::Combined of Iteration and ResidualNormReduction).
  * precond: OR_PRECOND_NONE or OR_PRECOND_JACOBI (= block-Jacobi with
  * max_block_size 1, solve.cpp:575-589). */
-int schwz_or_pcg(int64_t n, const or_idx *rp, const or_idx *col,
-                 const double *val, const double *b, double *x, int precond,
-                 double rtol, int max_iters, double *final_resnorm)
+/* ---- preconditioners beyond scalar Jacobi ---------------------------------- */
+
+typedef struct {
+    int kind;         /* OR_PRECOND_* */
+    int64_t n;
+    double *dinv;     /* Jacobi */
+    int bs;           /* block-Jacobi: consecutive blocks of bs rows (the last may be shorter) */
+    double *binv;     /* [nblocks][bs][bs], identity padded */
+    or_idx *l_rp, *l_col, *u_rp, *u_col; /* ILU(0): L unit lower with the 1 stored LAST in each */
+    double *l_val, *u_val;               /* row, U upper with its diagonal FIRST */
+    double *tmp;
+} or_precond;
+
+/* inverse of a dense bs x bs block (row major) by Gauss-Jordan with partial pivoting */
+static void invert_block(int bs, double *a, double *inv)
+{
+    for (int i = 0; i < bs; ++i)
+        for (int j = 0; j < bs; ++j) inv[i * bs + j] = (i == j) ? 1.0 : 0.0;
+    for (int c = 0; c < bs; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < bs; ++r)
+            if (fabs(a[r * bs + c]) > fabs(a[piv * bs + c])) piv = r;
+        if (piv != c)
+            for (int j = 0; j < bs; ++j) {
+                double t = a[c * bs + j];
+                a[c * bs + j] = a[piv * bs + j];
+                a[piv * bs + j] = t;
+                t = inv[c * bs + j];
+                inv[c * bs + j] = inv[piv * bs + j];
+                inv[piv * bs + j] = t;
+            }
+        const double d = a[c * bs + c];
+        for (int j = 0; j < bs; ++j) {
+            a[c * bs + j] /= d;
+            inv[c * bs + j] /= d;
+        }
+        for (int r = 0; r < bs; ++r) {
+            if (r == c) continue;
+            const double f = a[r * bs + c];
+            if (f == 0.0) continue;
+            for (int j = 0; j < bs; ++j) {
+                a[r * bs + j] -= f * a[c * bs + j];
+                inv[r * bs + j] -= f * inv[c * bs + j];
+            }
+        }
+    }
+}
+
+/* Block-Jacobi (gko::preconditioner::Jacobi with max_block_size bs, solve.cpp:490-505,
+ * 575-589).  Ginkgo finds blocks by supervariable agglomeration; for matrices whose rows all
+ * have distinct column patterns (every stencil) that is consecutive rows, which is what is
+ * restated here for every matrix -- block detection "parity unpinned". */
+static void build_block_jacobi(or_precond *M, const or_idx *rp, const or_idx *col, const double *val)
+{
+    const int bs = M->bs;
+    const int64_t n = M->n, nb = (n + bs - 1) / bs;
+    M->binv = (double *)xcalloc((size_t)nb * bs * bs, sizeof(double));
+    double *blk = (double *)xmalloc(sizeof(double) * (size_t)bs * bs);
+    for (int64_t b = 0; b < nb; ++b) {
+        const int64_t r0 = b * bs;
+        for (int i = 0; i < bs * bs; ++i) blk[i] = 0.0;
+        for (int i = 0; i < bs; ++i) {
+            if (r0 + i >= n) {
+                blk[i * bs + i] = 1.0;
+                continue;
+            }
+            for (or_idx j = rp[r0 + i]; j < rp[r0 + i + 1]; ++j)
+                if (col[j] >= r0 && col[j] < r0 + bs) blk[i * bs + (col[j] - r0)] = val[j];
+        }
+        invert_block(bs, blk, M->binv + (size_t)b * bs * bs);
+    }
+    free(blk);
+}
+
+/* ILU(0) on the pattern of A (columns sorted), IKJ order.  gko::factorization::ParIlu
+ * (solve.cpp:506-532,590-615) iterates towards the same factors; the exact ones are restated. */
+static void build_ilu0(or_precond *M, const or_idx *rp, const or_idx *col, const double *val)
+{
+    const int64_t n = M->n;
+    const int64_t nnz = rp[n];
+    double *a = (double *)xmalloc(sizeof(double) * (size_t)nnz);
+    memcpy(a, val, sizeof(double) * (size_t)nnz);
+    or_idx *diag = (or_idx *)xmalloc(sizeof(or_idx) * (size_t)n);
+    or_idx *pos = (or_idx *)xmalloc(sizeof(or_idx) * (size_t)n);
+    for (int64_t i = 0; i < n; ++i) pos[i] = -1;
+    for (int64_t i = 0; i < n; ++i) {
+        diag[i] = -1;
+        for (or_idx j = rp[i]; j < rp[i + 1]; ++j) {
+            pos[col[j]] = j;
+            if (col[j] == i) diag[i] = j;
+        }
+        for (or_idx kk = rp[i]; kk < rp[i + 1] && col[kk] < i; ++kk) {
+            const or_idx k = col[kk];
+            a[kk] /= a[diag[k]];
+            const double lik = a[kk];
+            for (or_idx j = diag[k] + 1; j < rp[k + 1]; ++j) {
+                const or_idx q = pos[col[j]];
+                if (q >= 0) a[q] -= lik * a[j];
+            }
+        }
+        for (or_idx j = rp[i]; j < rp[i + 1]; ++j) pos[col[j]] = -1;
+    }
+    M->l_rp = (or_idx *)xcalloc((size_t)n + 1, sizeof(or_idx));
+    M->u_rp = (or_idx *)xcalloc((size_t)n + 1, sizeof(or_idx));
+    for (int64_t i = 0; i < n; ++i) {
+        or_idx nl = 0, nu = 0;
+        for (or_idx j = rp[i]; j < rp[i + 1]; ++j) {
+            if (col[j] < i) ++nl;
+            else ++nu;
+        }
+        M->l_rp[i + 1] = M->l_rp[i] + nl + 1;
+        M->u_rp[i + 1] = M->u_rp[i] + nu;
+    }
+    M->l_col = (or_idx *)xmalloc(sizeof(or_idx) * (size_t)M->l_rp[n]);
+    M->l_val = (double *)xmalloc(sizeof(double) * (size_t)M->l_rp[n]);
+    M->u_col = (or_idx *)xmalloc(sizeof(or_idx) * (size_t)M->u_rp[n]);
+    M->u_val = (double *)xmalloc(sizeof(double) * (size_t)M->u_rp[n]);
+    for (int64_t i = 0; i < n; ++i) {
+        or_idx pl = M->l_rp[i], pu = M->u_rp[i];
+        for (or_idx j = rp[i]; j < rp[i + 1]; ++j) {
+            if (col[j] < i) {
+                M->l_col[pl] = col[j];
+                M->l_val[pl++] = a[j];
+            } else {
+                M->u_col[pu] = col[j];
+                M->u_val[pu++] = a[j];
+            }
+        }
+        M->l_col[pl] = (or_idx)i;
+        M->l_val[pl] = 1.0;
+    }
+    free(a);
+    free(diag);
+    free(pos);
+}
+
+static or_precond *precond_create(int kind, int bs, int64_t n, const or_idx *rp, const or_idx *col,
+                                  const double *val)
+{
+    or_precond *M = (or_precond *)xcalloc(1, sizeof(*M));
+    M->kind = kind;
+    M->n = n;
+    M->bs = bs < 1 ? 1 : bs;
+    if (kind == OR_PRECOND_BLOCK_JACOBI && M->bs == 1) M->kind = kind = OR_PRECOND_JACOBI;
+    if (kind == OR_PRECOND_JACOBI) {
+        M->dinv = (double *)xmalloc(sizeof(double) * (size_t)(n ? n : 1));
+        for (int64_t i = 0; i < n; ++i) {
+            double d = 1.0;
+            for (or_idx j = rp[i]; j < rp[i + 1]; ++j)
+                if (col[j] == i) d = val[j];
+            M->dinv[i] = 1.0 / d;
+        }
+    } else if (kind == OR_PRECOND_BLOCK_JACOBI) {
+        build_block_jacobi(M, rp, col, val);
+    } else if (kind == OR_PRECOND_ILU) {
+        build_ilu0(M, rp, col, val);
+        M->tmp = (double *)xmalloc(sizeof(double) * (size_t)(n ? n : 1));
+    }
+    return M;
+}
+
+static void precond_free(or_precond *M)
+{
+    if (!M) return;
+    free(M->dinv);
+    free(M->binv);
+    free(M->l_rp);
+    free(M->l_col);
+    free(M->l_val);
+    free(M->u_rp);
+    free(M->u_col);
+    free(M->u_val);
+    free(M->tmp);
+    free(M);
+}
+
+/* z = M^-1 r */
+static void precond_apply(const or_precond *M, const double *r, double *z)
+{
+    const int64_t n = M->n;
+    if (M->kind == OR_PRECOND_JACOBI) {
+        for (int64_t i = 0; i < n; ++i) z[i] = M->dinv[i] * r[i];
+    } else if (M->kind == OR_PRECOND_BLOCK_JACOBI) {
+        const int bs = M->bs;
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t b = i / bs, r0 = b * bs;
+            const double *row = M->binv + ((size_t)b * bs + (size_t)(i - r0)) * bs;
+            double s = 0.0;
+            for (int j = 0; j < bs && r0 + j < n; ++j) s += row[j] * r[r0 + j];
+            z[i] = s;
+        }
+    } else if (M->kind == OR_PRECOND_ILU) {
+        double *t = M->tmp;
+        for (int64_t i = 0; i < n; ++i) { /* L t = r, unit diagonal stored last */
+            double s = r[i];
+            const or_idx e = M->l_rp[i + 1] - 1;
+            for (or_idx j = M->l_rp[i]; j < e; ++j) s -= M->l_val[j] * t[M->l_col[j]];
+            t[i] = s / M->l_val[e];
+        }
+        for (int64_t i = n - 1; i >= 0; --i) { /* U z = t, diagonal first */
+            double s = t[i];
+            for (or_idx j = M->u_rp[i] + 1; j < M->u_rp[i + 1]; ++j) s -= M->u_val[j] * z[M->u_col[j]];
+            z[i] = s / M->u_val[M->u_rp[i]];
+        }
+    } else {
+        memcpy(z, r, sizeof(double) * (size_t)n);
+    }
+}
+
+int schwz_or_pcg_ex(int64_t n, const or_idx *rp, const or_idx *col, const double *val, const double *b,
+                    double *x, int precond, int block_size, double rtol, int max_iters,
+                    double *final_resnorm)
 {
     double *r = (double *)xmalloc(sizeof(double) * (size_t)n);
     double *z = (double *)xmalloc(sizeof(double) * (size_t)n);
     double *p = (double *)xmalloc(sizeof(double) * (size_t)n);
     double *q = (double *)xmalloc(sizeof(double) * (size_t)n);
-    double *dinv = NULL;
-    if (precond == OR_PRECOND_JACOBI) {
-        dinv = (double *)xmalloc(sizeof(double) * (size_t)n);
-        for (int64_t i = 0; i < n; ++i) {
-            double d = 1.0;
-            for (or_idx j = rp[i]; j < rp[i + 1]; ++j)
-                if (col[j] == i) d = val[j];
-            dinv[i] = 1.0 / d;
-        }
-    }
+    or_precond *M = precond_create(precond, block_size, n, rp, col, val);
     memcpy(r, b, sizeof(double) * (size_t)n);
     schwz_or_spmv(n, rp, col, val, -1.0, x, 1.0, r);
     double rr = dot(n, r, r);
     const double r0 = sqrt(rr);
-    double rho = 0.0;
-#pragma omp parallel for schedule(static) reduction(+ : rho) if (n > OMP_MIN_N)
-    for (int64_t i = 0; i < n; ++i) {
-        z[i] = dinv ? dinv[i] * r[i] : r[i];
-        p[i] = z[i];
-        rho += r[i] * z[i];
-    }
+    precond_apply(M, r, z);
+    memcpy(p, z, sizeof(double) * (size_t)n);
+    double rho = dot(n, r, z);
     int it = 0;
     for (; it < max_iters; ++it) {
         if (sqrt(rr) <= rtol * r0) break;
         schwz_or_spmv(n, rp, col, val, 1.0, p, 0.0, q);
         double pq = dot(n, p, q);
         double alpha = rho / pq;
-        double rho_new = 0.0, rr_new = 0.0;
-#pragma omp parallel for schedule(static) reduction(+ : rho_new, rr_new) if (n > OMP_MIN_N)
+#pragma omp parallel for schedule(static) if (n > OMP_MIN_N)
         for (int64_t i = 0; i < n; ++i) {
             x[i] += alpha * p[i];
             r[i] -= alpha * q[i];
-            z[i] = dinv ? dinv[i] * r[i] : r[i];
-            rho_new += r[i] * z[i];
-            rr_new += r[i] * r[i];
         }
+        precond_apply(M, r, z);
+        double rho_new = dot(n, r, z);
+        double rr_new = dot(n, r, r);
         double beta = rho_new / rho;
 #pragma omp parallel for schedule(static) if (n > OMP_MIN_N)
         for (int64_t i = 0; i < n; ++i) p[i] = z[i] + beta * p[i];
@@ -609,8 +804,30 @@ int schwz_or_pcg(int64_t n, const or_idx *rp, const or_idx *col,
     free(z);
     free(p);
     free(q);
-    free(dinv);
+    precond_free(M);
     return it;
+}
+
+int schwz_or_pcg(int64_t n, const or_idx *rp, const or_idx *col, const double *val, const double *b,
+                 double *x, int precond, double rtol, int max_iters, double *final_resnorm)
+{
+    return schwz_or_pcg_ex(n, rp, col, val, b, x, precond, 1, rtol, max_iters, final_resnorm);
+}
+
+/* ILU(0) factors for inspection by the tests (malloc'd; free with schwz_or_free) */
+void schwz_or_ilu0(int64_t n, const or_idx *rp, const or_idx *col, const double *val, or_idx **l_rp,
+                   or_idx **l_col, double **l_val, or_idx **u_rp, or_idx **u_col, double **u_val)
+{
+    or_precond M;
+    memset(&M, 0, sizeof(M));
+    M.n = n;
+    build_ilu0(&M, rp, col, val);
+    *l_rp = M.l_rp;
+    *l_col = M.l_col;
+    *l_val = M.l_val;
+    *u_rp = M.u_rp;
+    *u_col = M.u_col;
+    *u_val = M.u_val;
 }
 
 /* ---- sparse LL^T (stands in for CHOLMOD simplicial LL^T, solve.cpp:92-143) -- */
@@ -990,8 +1207,8 @@ int schwz_or_local_solve(or_state *st)
     /* :721-781 : solver->apply(rhs=local_solution, x=init_guess) with the
      * warm start kept across outer iterations; local_solution <- init_guess */
     int maxit = st->s.local_max_iters == -1 ? (int)n : st->s.local_max_iters;
-    int it = schwz_or_pcg(n, sd->l_rp, sd->l_col, sd->l_val, st->local_solution,
-                          st->init_guess, st->s.precond, st->s.local_tol, maxit, NULL);
+    int it = schwz_or_pcg_ex(n, sd->l_rp, sd->l_col, sd->l_val, st->local_solution, st->init_guess,
+                             st->s.precond, st->s.precond_block_size, st->s.local_tol, maxit, NULL);
     memcpy(st->local_solution, st->init_guess, sizeof(double) * (size_t)n);
     st->last_inner = it;
     return it;

@@ -100,7 +100,7 @@ void schwz_or_sd_add_put_list(or_subdomain *sd, int p, or_idx count,
 /* ---- solver settings ------------------------------------------------------ */
 
 enum { OR_SOLVER_ITERATIVE = 0, OR_SOLVER_DIRECT = 1 };
-enum { OR_PRECOND_NONE = 0, OR_PRECOND_JACOBI = 1 };
+enum { OR_PRECOND_NONE = 0, OR_PRECOND_JACOBI = 1, OR_PRECOND_BLOCK_JACOBI = 2, OR_PRECOND_ILU = 3 };
 
 typedef struct {
     int32_t max_iters;        /* metadata.max_iters (--num_iters) */
@@ -122,6 +122,7 @@ typedef struct {
     /* settings.use_mixed_precision with MixedValueType=float: halo values are rounded to fp32
      * on the wire (restricted_schwarz.cpp:898-903,952-954) */
     int32_t use_mixed_precision;
+    int32_t precond_block_size; /* metadata.precond_max_block_size for OR_PRECOND_BLOCK_JACOBI */
 } or_settings;
 
 /* ---- per-subdomain state and the five loop steps (A.3) -------------------- */
@@ -189,6 +190,11 @@ void schwz_or_scatter(int64_t n, const or_idx *idx, const double *from,
 int schwz_or_pcg(int64_t n, const or_idx *rp, const or_idx *col,
                  const double *val, const double *b, double *x, int precond,
                  double rtol, int max_iters, double *final_resnorm);
+int schwz_or_pcg_ex(int64_t n, const or_idx *rp, const or_idx *col, const double *val, const double *b,
+                    double *x, int precond, int block_size, double rtol, int max_iters,
+                    double *final_resnorm);
+void schwz_or_ilu0(int64_t n, const or_idx *rp, const or_idx *col, const double *val, or_idx **l_rp,
+                   or_idx **l_col, double **l_val, or_idx **u_rp, or_idx **u_col, double **u_val);
 /* sparse LL^T of A(perm,perm); outputs malloc'd CSR L and U=L^T; perm is
  * old index per new row.  natural=1 => identity ordering, else RCM. */
 int schwz_or_cholesky(int64_t n, const or_idx *rp, const or_idx *col,

@@ -839,4 +839,66 @@ int schwz_cholesky(int64_t n, const schwz_idx *rp, const schwz_idx *col, const d
     return SCHWZ_OK;
 }
 
+// ILU(0), row by row (IKJ): for every k < i in row i: l_ik = a_ik / u_kk, then row i loses
+// l_ik * (row k of U) on the positions it stores.
+int schwz_ilu0(int64_t n, const schwz_idx *rp, const schwz_idx *col, const double *val, schwz_idx **l_rp_o,
+               schwz_idx **l_col_o, double **l_val_o, schwz_idx **u_rp_o, schwz_idx **u_col_o, double **u_val_o)
+{
+    SCHWZ_REQUIRE(rp && l_rp_o && l_col_o && l_val_o && u_rp_o && u_col_o && u_val_o && n >= 0,
+                  "schwz_ilu0: bad arguments");
+    const int64_t nnz = rp[n];
+    std::vector<double> a(val, val + nnz);
+    std::vector<schwz_idx> diag((size_t)n, -1), where((size_t)n, -1);
+    for (int64_t i = 0; i < n; ++i) {
+        for (schwz_idx j = rp[i]; j < rp[i + 1]; ++j) {
+            SCHWZ_REQUIRE(j == rp[i] || col[j - 1] < col[j], "schwz_ilu0: columns must be sorted and unique");
+            where[(size_t)col[j]] = j;
+            if (col[j] == i) diag[(size_t)i] = j;
+        }
+        SCHWZ_REQUIRE(diag[(size_t)i] >= 0, "schwz_ilu0: structurally zero diagonal");
+        for (schwz_idx kk = rp[i]; kk < rp[i + 1] && col[kk] < i; ++kk) {
+            const schwz_idx k = col[kk];
+            a[(size_t)kk] /= a[(size_t)diag[(size_t)k]];
+            const double lik = a[(size_t)kk];
+            for (schwz_idx j = diag[(size_t)k] + 1; j < rp[k + 1]; ++j) {
+                const schwz_idx q = where[(size_t)col[j]];
+                if (q >= 0) a[(size_t)q] -= lik * a[(size_t)j];
+            }
+        }
+        if (a[(size_t)diag[(size_t)i]] == 0.0) {
+            set_error("schwz_ilu0: zero pivot");
+            return SCHWZ_ERR_NOT_SPD;
+        }
+        for (schwz_idx j = rp[i]; j < rp[i + 1]; ++j) where[(size_t)col[j]] = -1;
+    }
+    std::vector<schwz_idx> l_rp((size_t)n + 1, 0), u_rp((size_t)n + 1, 0), l_col, u_col;
+    std::vector<double> l_val, u_val;
+    l_col.reserve((size_t)nnz / 2 + (size_t)n);
+    l_val.reserve((size_t)nnz / 2 + (size_t)n);
+    u_col.reserve((size_t)nnz / 2 + (size_t)n);
+    u_val.reserve((size_t)nnz / 2 + (size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        for (schwz_idx j = rp[i]; j < rp[i + 1]; ++j) {
+            if (col[j] < i) {
+                l_col.push_back(col[j]);
+                l_val.push_back(a[(size_t)j]);
+            } else {
+                u_col.push_back(col[j]);
+                u_val.push_back(a[(size_t)j]);
+            }
+        }
+        l_col.push_back((schwz_idx)i);
+        l_val.push_back(1.0);
+        l_rp[(size_t)i + 1] = (schwz_idx)l_col.size();
+        u_rp[(size_t)i + 1] = (schwz_idx)u_col.size();
+    }
+    *l_rp_o = to_malloc(l_rp);
+    *l_col_o = to_malloc(l_col);
+    *l_val_o = to_malloc(l_val);
+    *u_rp_o = to_malloc(u_rp);
+    *u_col_o = to_malloc(u_col);
+    *u_val_o = to_malloc(u_val);
+    return SCHWZ_OK;
+}
+
 }  // extern "C"

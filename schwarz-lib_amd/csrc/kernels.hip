@@ -990,6 +990,7 @@ __global__ __launch_bounds__(kBlock) void cg_direction_kernel(int64_t n, double 
                                                               const double *partials_in, int nparts,
                                                               CgState *st, int it, double rtol)
 {
+    // with a general preconditioner `r` is already z = M^-1 r and dg.mode is 0
     __shared__ double red[4];
     __shared__ double ddict[256];
     if (it >= st->stop_iter) return;
@@ -1223,6 +1224,126 @@ __global__ __launch_bounds__(kTrsBlock) void trs_solve_kernel(
         __syncthreads();
     }
     for (int64_t i = tid; i < n; i += kTrsBlock) y[perm[i]] = w0[i];
+}
+
+// ---- the same solves level by level, for factors that do not fit one workgroup ----------------
+
+// w[i] = b[perm[i]] (perm == nullptr: identity)
+__global__ void trs_permute_in_kernel(int64_t n, const schwz_idx *__restrict__ perm, const double *__restrict__ b,
+                                      double *__restrict__ w)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        w[i] = perm ? b[perm[i]] : b[i];
+}
+
+// y[perm[i]] = w[i]
+__global__ void trs_permute_out_kernel(int64_t n, const schwz_idx *__restrict__ perm, const double *__restrict__ w,
+                                       double *__restrict__ y)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (perm)
+            y[perm[i]] = w[i];
+        else
+            y[i] = w[i];
+    }
+}
+
+// rows order[k0:k1) of one level: out[row] = (rhs[row] - sum_{deps} val * out[col]) / diag.
+// LOWER: diagonal is the row's last entry; else (upper) its first.  All dependencies belong to
+// earlier levels, i.e. to earlier launches.
+template <bool LOWER>
+__global__ __launch_bounds__(kBlock) void trs_level_kernel(int k0, int k1, const schwz_idx *__restrict__ order,
+                                                           const schwz_idx *__restrict__ rp,
+                                                           const schwz_idx *__restrict__ col,
+                                                           const double *__restrict__ val,
+                                                           const double *__restrict__ rhs, double *out)
+{
+#pragma clang fp contract(off)
+    const int k = k0 + blockIdx.x * kBlock + threadIdx.x;
+    if (k >= k1) return;
+    const int row = order[k];
+    const int s0 = rp[row], e = rp[row + 1];
+    double s = rhs[row];
+    if (LOWER) {
+        for (int j = s0; j < e - 1; ++j) s -= val[j] * out[col[j]];
+        out[row] = s / val[e - 1];
+    } else {
+        for (int j = s0 + 1; j < e; ++j) s -= val[j] * out[col[j]];
+        out[row] = s / val[s0];
+    }
+}
+
+// a run of narrow levels [lv0, lv1) in one workgroup
+template <bool LOWER>
+__global__ __launch_bounds__(kTrsBlock) void trs_narrow_kernel(int lv0, int lv1, const schwz_idx *__restrict__ lvl,
+                                                               const schwz_idx *__restrict__ order,
+                                                               const schwz_idx *__restrict__ rp,
+                                                               const schwz_idx *__restrict__ col,
+                                                               const double *__restrict__ val,
+                                                               const double *__restrict__ rhs, double *out)
+{
+#pragma clang fp contract(off)
+    for (int lv = lv0; lv < lv1; ++lv) {
+        for (int k = lvl[lv] + (int)threadIdx.x; k < lvl[lv + 1]; k += kTrsBlock) {
+            const int row = order[k];
+            const int s0 = rp[row], e = rp[row + 1];
+            double s = rhs[row];
+            if (LOWER) {
+                for (int j = s0; j < e - 1; ++j) s -= val[j] * out[col[j]];
+                out[row] = s / val[e - 1];
+            } else {
+                for (int j = s0 + 1; j < e; ++j) s -= val[j] * out[col[j]];
+                out[row] = s / val[s0];
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// ---- block-Jacobi apply and the vector pieces of the general preconditioned CG -------------
+
+// z[i] = sum_j inv[blk_id[i / bs]][i % bs][j] * r[(i / bs) * bs + j]
+__global__ __launch_bounds__(kBlock) void block_jacobi_apply_kernel(int64_t n, int bs,
+                                                                    const schwz_idx *__restrict__ blk_id,
+                                                                    const double *__restrict__ blk_inv,
+                                                                    const double *__restrict__ r,
+                                                                    double *__restrict__ z)
+{
+#pragma clang fp contract(off)
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const int64_t b = i / bs, r0 = b * bs;
+        const double *row = blk_inv + ((int64_t)blk_id[b] * bs + (i - r0)) * bs;
+        double s = 0.0;
+        for (int j = 0; j < bs && r0 + j < n; ++j) s += row[j] * r[r0 + j];
+        z[i] = s;
+    }
+}
+
+// partial sums of r.z and r.r (banks 0 and 1), optionally p := z
+__global__ __launch_bounds__(kBlock) void dot_rz_kernel(int64_t n, const double *__restrict__ r,
+                                                        const double *__restrict__ z, double *__restrict__ p_out,
+                                                        const CgState *st, int it, double *partials_out)
+{
+    __shared__ double red[4];
+    if (st && it >= st->stop_iter) return;
+    double a0 = 0.0, a1 = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const double rv = r[i], zv = z[i];
+        a0 += rv * zv;
+        a1 += rv * rv;
+        if (p_out) p_out[i] = zv;
+    }
+    const double s0 = block_sum(a0, red);
+    const double s1 = block_sum(a1, red);
+    if (threadIdx.x == 0) {
+        partials_out[blockIdx.x] = s0;
+        partials_out[gridDim.x + blockIdx.x] = s1;
+    }
 }
 
 }  // namespace schwz
@@ -1532,13 +1653,128 @@ int schwz_profile_end(double *h_total_ms, int64_t *h_launches)
 
 int schwz_pcg_create(const schwz_csr *A, int precond, schwz_pcg **out)
 {
+    return schwz_pcg_create_ex(A, precond, 1, out);
+}
+
+// block-Jacobi / ILU(0) setup: the (setup-time) host copy of the matrix comes back from HBM
+static int pcg_setup_general(schwz_pcg *s)
+{
+    const CsrView &A = s->A->v;
+    const int64_t n = s->n;
+    std::vector<schwz_idx> rp((size_t)n + 1), col((size_t)A.nnz);
+    std::vector<double> val((size_t)A.nnz);
+    SCHWZ_HIP_TRY(hipMemcpy(rp.data(), A.rp, rp.size() * sizeof(schwz_idx), hipMemcpyDeviceToHost));
+    if (A.nnz) {
+        SCHWZ_HIP_TRY(hipMemcpy(col.data(), A.col, col.size() * sizeof(schwz_idx), hipMemcpyDeviceToHost));
+        SCHWZ_HIP_TRY(hipMemcpy(val.data(), A.val, val.size() * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    SCHWZ_HIP_TRY(hipMalloc((void **)&s->z, (size_t)(n ? n : 1) * sizeof(double)));
+    if (s->precond == SCHWZ_PRECOND_ILU) {
+        schwz_idx *l_rp, *l_col, *u_rp, *u_col;
+        double *l_val, *u_val;
+        int rc = schwz_ilu0(n, rp.data(), col.data(), val.data(), &l_rp, &l_col, &l_val, &u_rp, &u_col, &u_val);
+        if (rc) return rc;
+        rc = schwz_trs_create(n, l_rp, l_col, l_val, u_rp, u_col, u_val, nullptr, &s->ilu);
+        schwz_free(l_rp);
+        schwz_free(l_col);
+        schwz_free(l_val);
+        schwz_free(u_rp);
+        schwz_free(u_col);
+        schwz_free(u_val);
+        return rc;
+    }
+    // block-Jacobi: consecutive blocks of bs rows, inverted by Gauss-Jordan with partial
+    // pivoting; identical inverse blocks are stored once (a stencil matrix has a handful)
+    const int bs = s->block_size;
+    const int64_t nb = (n + bs - 1) / bs;
+    std::vector<schwz_idx> id((size_t)nb);
+    std::vector<double> uniq, blk((size_t)bs * bs), inv((size_t)bs * bs);
+    std::unordered_multimap<uint64_t, schwz_idx> seen;
+    for (int64_t b = 0; b < nb; ++b) {
+        const int64_t r0 = b * bs;
+        std::fill(blk.begin(), blk.end(), 0.0);
+        for (int i = 0; i < bs; ++i) {
+            if (r0 + i >= n) {
+                blk[(size_t)i * bs + i] = 1.0;
+                continue;
+            }
+            for (schwz_idx j = rp[(size_t)(r0 + i)]; j < rp[(size_t)(r0 + i) + 1]; ++j)
+                if (col[(size_t)j] >= r0 && col[(size_t)j] < r0 + bs)
+                    blk[(size_t)i * bs + (col[(size_t)j] - r0)] = val[(size_t)j];
+        }
+        uint64_t h = 1469598103934665603ull;
+        for (double v : blk) {
+            uint64_t bits;
+            std::memcpy(&bits, &v, 8);
+            h = (h ^ bits) * 1099511628211ull;
+        }
+        // invert (the copy in blk is destroyed)
+        std::vector<double> a = blk;
+        for (int i = 0; i < bs; ++i)
+            for (int j = 0; j < bs; ++j) inv[(size_t)i * bs + j] = i == j ? 1.0 : 0.0;
+        for (int c = 0; c < bs; ++c) {
+            int piv = c;
+            for (int r = c + 1; r < bs; ++r)
+                if (std::fabs(a[(size_t)r * bs + c]) > std::fabs(a[(size_t)piv * bs + c])) piv = r;
+            if (a[(size_t)piv * bs + c] == 0.0) {
+                set_error("block-Jacobi: singular diagonal block");
+                return SCHWZ_ERR_NOT_SPD;
+            }
+            if (piv != c)
+                for (int j = 0; j < bs; ++j) {
+                    std::swap(a[(size_t)c * bs + j], a[(size_t)piv * bs + j]);
+                    std::swap(inv[(size_t)c * bs + j], inv[(size_t)piv * bs + j]);
+                }
+            const double d = a[(size_t)c * bs + c];
+            for (int j = 0; j < bs; ++j) {
+                a[(size_t)c * bs + j] /= d;
+                inv[(size_t)c * bs + j] /= d;
+            }
+            for (int r = 0; r < bs; ++r) {
+                if (r == c) continue;
+                const double f = a[(size_t)r * bs + c];
+                if (f == 0.0) continue;
+                for (int j = 0; j < bs; ++j) {
+                    a[(size_t)r * bs + j] -= f * a[(size_t)c * bs + j];
+                    inv[(size_t)r * bs + j] -= f * inv[(size_t)c * bs + j];
+                }
+            }
+        }
+        schwz_idx found = -1;
+        auto range = seen.equal_range(h);
+        for (auto it = range.first; it != range.second; ++it)
+            if (std::memcmp(&uniq[(size_t)it->second * bs * bs], inv.data(), sizeof(double) * bs * bs) == 0) {
+                found = it->second;
+                break;
+            }
+        if (found < 0) {
+            found = (schwz_idx)(uniq.size() / ((size_t)bs * bs));
+            uniq.insert(uniq.end(), inv.begin(), inv.end());
+            seen.emplace(h, found);
+        }
+        id[(size_t)b] = found;
+    }
+    int rc;
+    void *d;
+    if ((rc = upload(id.data(), id.size(), &d))) return rc;
+    s->d_blk_id = (schwz_idx *)d;
+    if ((rc = upload(uniq.data(), uniq.size(), &d))) return rc;
+    s->d_blk_inv = (double *)d;
+    return SCHWZ_OK;
+}
+
+int schwz_pcg_create_ex(const schwz_csr *A, int precond, int block_size, schwz_pcg **out)
+{
     SCHWZ_REQUIRE(A && out, "schwz_pcg_create: null argument");
     SCHWZ_REQUIRE(A->v.nrows == A->v.ncols, "schwz_pcg_create: matrix not square");
-    SCHWZ_REQUIRE(precond == SCHWZ_PRECOND_NONE || precond == SCHWZ_PRECOND_JACOBI,
+    SCHWZ_REQUIRE(precond >= SCHWZ_PRECOND_NONE && precond <= SCHWZ_PRECOND_ILU,
                   "schwz_pcg_create: unknown preconditioner");
+    SCHWZ_REQUIRE(block_size >= 1 && block_size <= 32, "schwz_pcg_create: block size must be in 1..32");
+    if (precond == SCHWZ_PRECOND_BLOCK_JACOBI && block_size == 1) precond = SCHWZ_PRECOND_JACOBI;
     schwz_pcg *s = new schwz_pcg();
     s->A = A;
     s->precond = precond;
+    s->block_size = block_size;
     s->n = A->v.nrows;
     const size_t nb = (size_t)(s->n ? s->n : 1) * sizeof(double);
     SCHWZ_HIP_TRY(hipMalloc((void **)&s->r, nb));
@@ -1599,6 +1835,13 @@ int schwz_pcg_create(const schwz_csr *A, int precond, schwz_pcg **out)
             }
         }
     }
+    if (precond == SCHWZ_PRECOND_BLOCK_JACOBI || precond == SCHWZ_PRECOND_ILU) {
+        int rc = pcg_setup_general(s);
+        if (rc) {
+            schwz_pcg_destroy(s);
+            return rc;
+        }
+    }
     *out = s;
     return SCHWZ_OK;
 }
@@ -1610,6 +1853,10 @@ void schwz_pcg_destroy(schwz_pcg *s)
     (void)hipFree(s->p);
     (void)hipFree(s->q);
     (void)hipFree(s->dinv);
+    (void)hipFree(s->z);
+    (void)hipFree(s->d_blk_id);
+    (void)hipFree(s->d_blk_inv);
+    schwz_trs_destroy(s->ilu);
     (void)hipFree(s->d_dcode);
     (void)hipFree(s->d_ddict);
     (void)hipFree(s->partials);
@@ -1624,6 +1871,21 @@ void schwz_pcg_destroy(schwz_pcg *s)
 }  // extern "C"
 
 namespace schwz {
+
+// z = M^-1 r for the preconditioners that are operators of their own
+static int pcg_apply_general(schwz_pcg *s, hipStream_t st)
+{
+    if (s->precond == SCHWZ_PRECOND_ILU) return schwz_trs_solve(s->ilu, s->r, s->z, (schwz_stream)st);
+    hipLaunchKernelGGL(block_jacobi_apply_kernel, dim3(grid_for(s->n)), dim3(kBlock), 0, st, s->n, s->block_size,
+                       s->d_blk_id, s->d_blk_inv, s->r, s->z);
+    SCHWZ_HIP_TRY(hipGetLastError());
+    return SCHWZ_OK;
+}
+
+static bool pcg_is_general(const schwz_pcg *s)
+{
+    return s->precond == SCHWZ_PRECOND_BLOCK_JACOBI || s->precond == SCHWZ_PRECOND_ILU;
+}
 
 // First half of a solve: r = b - A x, p = M^-1 r, rho, ||r||^2 -> CgState.  With
 // `fused` the same pass over the matrix also yields ||b - A x2||^2 over the rows
@@ -1644,8 +1906,25 @@ int pcg_begin(schwz_pcg *s, const double *d_b, double *d_x, double rtol, bool fu
     a.row_limit = row_limit;
     // x2 == x over all rows: the check residual IS the start residual (rr bank)
     const bool same = fused && d_x2 == nullptr && row_limit >= s->n;
+    if (pcg_is_general(s)) a.dinv = nullptr;  // p := r for now, z follows
     int rc = launch_spmv(A, (fused && !same) ? kSpmvResidDual : kSpmvResidInit, a, s->variant, st);
     if (rc) return rc;
+    if (pcg_is_general(s)) {
+        // the check-residual norm (bank 1 or 2 of the SpMV partials) first, then z = M^-1 r,
+        // p = z and rho = r.z, ||r||^2 from the vector-kernel partials
+        if (fused) {
+            hipLaunchKernelGGL(final_norm_kernel, dim3(1), dim3(kBlock), 0, st, s->partials + (same ? 1 : 2) * gs, gs,
+                               s->d_norm_sq);
+        }
+        if ((rc = pcg_apply_general(s, st))) return rc;
+        const int gv = grid_for(s->n);
+        double *part_vec = s->partials + 3 * kMaxGrid;
+        hipLaunchKernelGGL(dot_rz_kernel, dim3(gv), dim3(kBlock), 0, st, s->n, s->r, s->z, s->p, nullptr, 0, part_vec);
+        hipLaunchKernelGGL(cg_init_finalize_kernel, dim3(1), dim3(kBlock), 0, st, s->state, part_vec, gv, rtol, nullptr,
+                           1);
+        SCHWZ_HIP_TRY(hipGetLastError());
+        return SCHWZ_OK;
+    }
     hipLaunchKernelGGL(cg_init_finalize_kernel, dim3(1), dim3(kBlock), 0, st, s->state, s->partials, gs, rtol,
                        fused ? s->d_norm_sq : nullptr, same ? 1 : 2);
     SCHWZ_HIP_TRY(hipGetLastError());
@@ -1664,6 +1943,7 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
     double *part_spmv = s->partials;                // [3][gs]
     double *part_vec = s->partials + 3 * kMaxGrid;  // [2][gv]
     const bool poll = rtol > 0.0;
+    const bool general = pcg_is_general(s);
     int chunk = 16;
     int it = 0, pending = -1, bank = 0;
     bool stopped = false;
@@ -1690,8 +1970,21 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
 #define SCHWZ_LAUNCH_DIRECTION(U, NT)                                                                        \
     hipLaunchKernelGGL((cg_direction_kernel<U, NT>), dim3(gv), dim3(kBlock), 0, st, n, s->p, s->r, s->diag, \
                        part_vec, gv, s->state, it, rtol)
-            SCHWZ_LAUNCH_UPDATE(1, false);
-            SCHWZ_LAUNCH_DIRECTION(1, false);
+            if (!general) {
+                SCHWZ_LAUNCH_UPDATE(1, false);
+                SCHWZ_LAUNCH_DIRECTION(1, false);
+            } else {
+                // x, r update without a preconditioner; z = M^-1 r; rho' = r.z; p = z + beta p
+                const DiagView none;
+                const int gz = grid_for(n);
+                hipLaunchKernelGGL((cg_update_kernel<1, false>), dim3(gv), dim3(kBlock), 0, st, n, d_x, s->r, s->p, s->q,
+                                   none, part_spmv, gs, s->state, it, part_vec);
+                if ((rc = pcg_apply_general(s, st))) return rc;
+                hipLaunchKernelGGL(dot_rz_kernel, dim3(gz), dim3(kBlock), 0, st, n, s->r, s->z, (double *)nullptr,
+                                   s->state, it, part_vec);
+                hipLaunchKernelGGL((cg_direction_kernel<1, false>), dim3(gv), dim3(kBlock), 0, st, n, s->p, s->z, none,
+                                   part_vec, gz, s->state, it, rtol);
+            }
 #undef SCHWZ_LAUNCH_UPDATE
 #undef SCHWZ_LAUNCH_DIRECTION
         }
@@ -1776,13 +2069,13 @@ int schwz_trs_create(int64_t n, const schwz_idx *l_rp, const schwz_idx *l_col, c
                      const schwz_idx *u_rp, const schwz_idx *u_col, const double *u_val,
                      const schwz_idx *perm, schwz_trs **out)
 {
-    SCHWZ_REQUIRE(out && n >= 0 && l_rp && u_rp && perm, "schwz_trs_create: bad arguments");
+    SCHWZ_REQUIRE(out && n >= 0 && l_rp && u_rp, "schwz_trs_create: bad arguments");
     for (int64_t i = 0; i < n; ++i) {
         SCHWZ_REQUIRE(l_rp[i + 1] > l_rp[i] && l_col[l_rp[i + 1] - 1] == i,
                       "schwz_trs_create: L must hold its diagonal last in each row");
         SCHWZ_REQUIRE(u_rp[i + 1] > u_rp[i] && u_col[u_rp[i]] == i,
                       "schwz_trs_create: U must hold its diagonal first in each row");
-        SCHWZ_REQUIRE(perm[i] >= 0 && perm[i] < n, "schwz_trs_create: permutation out of range");
+        SCHWZ_REQUIRE(!perm || (perm[i] >= 0 && perm[i] < n), "schwz_trs_create: permutation out of range");
     }
     schwz_trs *t = new schwz_trs();
     t->n = n;
@@ -1791,6 +2084,28 @@ int schwz_trs_create(int64_t n, const schwz_idx *l_rp, const schwz_idx *l_col, c
     level_schedule(n, u_rp, u_col, false, uo, ul);
     t->l_nlvl = (int)ll.size() - 1;
     t->u_nlvl = (int)ul.size() - 1;
+    // One workgroup handles the whole solve while the factor is small; otherwise wide levels get
+    // a multi-workgroup launch each and runs of narrow levels share a one-workgroup launch.
+    t->fused = n <= 8192;
+    auto plan = [](const std::vector<schwz_idx> &lvl, std::vector<schwz_trs::Seg> &out) {
+        const int nl = (int)lvl.size() - 1;
+        int l = 0;
+        while (l < nl) {
+            if (lvl[(size_t)l + 1] - lvl[(size_t)l] >= 4 * kTrsBlock) {
+                out.push_back({l, l + 1, true});
+                ++l;
+            } else {
+                int e = l;
+                while (e < nl && lvl[(size_t)e + 1] - lvl[(size_t)e] < 4 * kTrsBlock) ++e;
+                out.push_back({l, e, false});
+                l = e;
+            }
+        }
+    };
+    plan(ll, t->l_plan);
+    plan(ul, t->u_plan);
+    t->h_l_lvl = ll;
+    t->h_u_lvl = ul;
     int rc = 0;
     void *d;
 #define UP(dst, src, cnt, T)                        \
@@ -1804,7 +2119,9 @@ int schwz_trs_create(int64_t n, const schwz_idx *l_rp, const schwz_idx *l_col, c
     UP(t->u_rp, u_rp, n + 1, schwz_idx)
     UP(t->u_col, u_col, u_rp[n], schwz_idx)
     UP(t->u_val, u_val, u_rp[n], double)
-    UP(t->perm, perm, n, schwz_idx)
+    if (perm) {
+        UP(t->perm, perm, n, schwz_idx)
+    }
     UP(t->l_order, lo.data(), lo.size(), schwz_idx)
     UP(t->l_lvl, ll.data(), ll.size(), schwz_idx)
     UP(t->u_order, uo.data(), uo.size(), schwz_idx)
@@ -1833,9 +2150,37 @@ int schwz_trs_solve(schwz_trs *t, const double *d_b, double *d_y, schwz_stream s
 {
     SCHWZ_REQUIRE(t && d_b && d_y, "schwz_trs_solve: null argument");
     if (t->n == 0) return SCHWZ_OK;
-    hipLaunchKernelGGL(trs_solve_kernel, dim3(1), dim3(kTrsBlock), 0, (hipStream_t)stream, t->n, t->perm,
-                       t->l_rp, t->l_col, t->l_val, t->l_order, t->l_lvl, t->l_nlvl, t->u_rp, t->u_col,
-                       t->u_val, t->u_order, t->u_lvl, t->u_nlvl, d_b, d_y, t->w0, t->w1);
+    hipStream_t st = (hipStream_t)stream;
+    if (t->fused && t->perm) {
+        hipLaunchKernelGGL(trs_solve_kernel, dim3(1), dim3(kTrsBlock), 0, st, t->n, t->perm, t->l_rp, t->l_col,
+                           t->l_val, t->l_order, t->l_lvl, t->l_nlvl, t->u_rp, t->u_col, t->u_val, t->u_order,
+                           t->u_lvl, t->u_nlvl, d_b, d_y, t->w0, t->w1);
+        SCHWZ_HIP_TRY(hipGetLastError());
+        return SCHWZ_OK;
+    }
+    // w0 = P b ; L w1 = w0 ; U w0 = w1 ; y = P^T w0
+    hipLaunchKernelGGL(trs_permute_in_kernel, dim3(grid_for(t->n)), dim3(kBlock), 0, st, t->n, t->perm, d_b, t->w0);
+    for (const auto &sg : t->l_plan) {
+        if (sg.wide) {
+            const int k0 = t->h_l_lvl[(size_t)sg.lvl0], k1 = t->h_l_lvl[(size_t)sg.lvl1];
+            hipLaunchKernelGGL((trs_level_kernel<true>), dim3((k1 - k0 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, k0,
+                               k1, t->l_order, t->l_rp, t->l_col, t->l_val, t->w0, t->w1);
+        } else {
+            hipLaunchKernelGGL((trs_narrow_kernel<true>), dim3(1), dim3(kTrsBlock), 0, st, sg.lvl0, sg.lvl1, t->l_lvl,
+                               t->l_order, t->l_rp, t->l_col, t->l_val, t->w0, t->w1);
+        }
+    }
+    for (const auto &sg : t->u_plan) {
+        if (sg.wide) {
+            const int k0 = t->h_u_lvl[(size_t)sg.lvl0], k1 = t->h_u_lvl[(size_t)sg.lvl1];
+            hipLaunchKernelGGL((trs_level_kernel<false>), dim3((k1 - k0 + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
+                               k0, k1, t->u_order, t->u_rp, t->u_col, t->u_val, t->w1, t->w0);
+        } else {
+            hipLaunchKernelGGL((trs_narrow_kernel<false>), dim3(1), dim3(kTrsBlock), 0, st, sg.lvl0, sg.lvl1, t->u_lvl,
+                               t->u_order, t->u_rp, t->u_col, t->u_val, t->w1, t->w0);
+        }
+    }
+    hipLaunchKernelGGL(trs_permute_out_kernel, dim3(grid_for(t->n)), dim3(kBlock), 0, st, t->n, t->perm, t->w0, d_y);
     SCHWZ_HIP_TRY(hipGetLastError());
     return SCHWZ_OK;
 }

@@ -163,6 +163,12 @@ struct schwz_pcg {
     int precond = 0;
     int64_t n = 0;
     double *r = nullptr, *p = nullptr, *q = nullptr, *dinv = nullptr;
+    // general preconditioners (block-Jacobi, ILU(0)): z = M^-1 r is a vector of its own
+    double *z = nullptr;
+    int block_size = 1;
+    schwz_idx *d_blk_id = nullptr;  // block-Jacobi: index of each block's inverse
+    double *d_blk_inv = nullptr;    // unique inverse blocks, [nunique][bs][bs]
+    schwz_trs *ilu = nullptr;       // ILU(0): level-scheduled L and U sweeps
     schwz::DiagView diag;
     void *d_dcode = nullptr, *d_ddict = nullptr;
     double *partials = nullptr;  // 3 * kMaxGrid (SpMV banks) + 2 * kMaxGrid (vector banks)
@@ -182,6 +188,15 @@ struct schwz_trs {
     schwz_idx *l_order = nullptr, *l_lvl = nullptr, *u_order = nullptr, *u_lvl = nullptr;
     int l_nlvl = 0, u_nlvl = 0;
     double *w0 = nullptr, *w1 = nullptr;
+    // launch plan for factors too large for the one-workgroup kernel: runs of narrow levels
+    // (one workgroup, barriers in between) and wide levels (one multi-workgroup launch each)
+    struct Seg {
+        int lvl0, lvl1;
+        bool wide;
+    };
+    std::vector<Seg> l_plan, u_plan;
+    std::vector<schwz_idx> h_l_lvl, h_u_lvl;
+    bool fused = true;  // whole solve in the single-workgroup kernel
 };
 
 // host-side global problem (explicit CSR or analytic stencil)

@@ -113,7 +113,8 @@ int schwz_subdomain_to_device(schwz_subdomain *sd, const double *h_local_rhs, co
     SCHWZ_HIP_TRY(hipHostGetDevicePointer((void **)&sd->d_h_scalar, sd->h_scalar, 0));
     SCHWZ_HIP_TRY(hipEventCreateWithFlags(&sd->ev_scalar, hipEventDisableTiming));
     if (opt->local_solver == SCHWZ_SOLVER_ITERATIVE) {
-        if ((rc = schwz_pcg_create(sd->A, opt->precond, &sd->cg))) return rc;
+        const int bsz = opt->precond_block_size < 1 ? 1 : opt->precond_block_size;
+        if ((rc = schwz_pcg_create_ex(sd->A, opt->precond, bsz, &sd->cg))) return rc;
         sd->cg->variant = opt->spmv_variant;
     } else {
         // Solve::compute_local_factors + the Ginkgo TRS setup (solve.cpp:75-143,281-399)

@@ -149,12 +149,14 @@ void SchwarzBase<V, I, M>::initialize()
     }
     if (m.local_precond == "null" || m.local_precond.empty()) {
         opt.precond = SCHWZ_PRECOND_NONE;
-    } else if (m.local_precond == "block-jacobi" && m.precond_max_block_size == 1) {
-        opt.precond = SCHWZ_PRECOND_JACOBI;
+    } else if (m.local_precond == "block-jacobi" && m.precond_max_block_size >= 1 && m.precond_max_block_size <= 32) {
+        opt.precond = m.precond_max_block_size == 1 ? SCHWZ_PRECOND_JACOBI : SCHWZ_PRECOND_BLOCK_JACOBI;
+        opt.precond_block_size = (int)m.precond_max_block_size;
+    } else if (m.local_precond == "ilu") {
+        opt.precond = SCHWZ_PRECOND_ILU;
     } else {
         throw ::NotImplemented(__FILE__, __LINE__,
-                               "local_precond '" + m.local_precond +
-                                   "' (available: null, block-jacobi with precond_max_block_size=1)");
+                               "local_precond '" + m.local_precond + "' (available: null, block-jacobi, ilu)");
     }
     opt.local_tol = m.local_solver_tolerance;
     opt.local_max_iters = (int)m.local_max_iters;

@@ -21,14 +21,14 @@ OK = 0
 ERR_INVALID, ERR_HIP, ERR_NOT_IMPLEMENTED, ERR_NOT_SPD, ERR_IO, ERR_DIVERGED = 1, 2, 3, 4, 5, 6
 OP_ADD, OP_COPY, OP_DIFF, OP_AVG = 0, 1, 2, 3
 SOLVER_ITERATIVE, SOLVER_DIRECT = 0, 1
-PRECOND_NONE, PRECOND_JACOBI = 0, 1
+PRECOND_NONE, PRECOND_JACOBI, PRECOND_BLOCK_JACOBI, PRECOND_ILU = 0, 1, 2, 3
 
 # every symbol include/schwz_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "schwz_last_error", "schwz_version", "schwz_device_count", "schwz_set_device",
     "schwz_gather", "schwz_scatter",
     "schwz_csr_create", "schwz_csr_destroy", "schwz_csr_nnz", "schwz_csr_format", "schwz_csr_spmv",
-    "schwz_pcg_create", "schwz_pcg_destroy", "schwz_pcg_solve",
+    "schwz_pcg_create", "schwz_pcg_create_ex", "schwz_pcg_destroy", "schwz_pcg_solve",
     "schwz_profile_begin", "schwz_profile_end", "schwz_stream_probe",
     "schwz_trs_create", "schwz_trs_destroy", "schwz_trs_solve",
     "schwz_problem_laplacian", "schwz_problem_from_csr", "schwz_problem_from_matrix_market",
@@ -40,7 +40,7 @@ SYMBOLS = [
     "schwz_subdomain_interface_matrix", "schwz_subdomain_get_list",
     "schwz_subdomain_add_put_list", "schwz_subdomain_put_list",
     "schwz_subdomain_send_offset", "schwz_subdomain_recv_offset",
-    "schwz_cholesky", "schwz_free",
+    "schwz_cholesky", "schwz_ilu0", "schwz_free",
     "schwz_subdomain_to_device", "schwz_ras_pack", "schwz_ras_unpack", "schwz_ras_pack_f32",
     "schwz_ras_unpack_f32",
     "schwz_ras_update_boundary", "schwz_ras_local_residual", "schwz_ras_local_residual_launch",
@@ -70,7 +70,7 @@ class SolverOptions(C.Structure):
         ("local_max_iters", C.c_int32),
         ("natural_factor_ordering", C.c_int32),
         ("spmv_variant", C.c_int32),
-        ("reserved", C.c_int32),
+        ("precond_block_size", C.c_int32),
     ]
 
 
@@ -103,6 +103,7 @@ _sig("schwz_csr_nnz", i64, [vp])
 _sig("schwz_csr_format", i32, [vp])
 _sig("schwz_csr_spmv", i32, [vp, dbl, vp, dbl, vp, i32, vp])
 _sig("schwz_pcg_create", i32, [vp, i32, pvp])
+_sig("schwz_pcg_create_ex", i32, [vp, i32, i32, pvp])
 _sig("schwz_pcg_destroy", None, [vp])
 _sig("schwz_pcg_solve", i32, [vp, vp, vp, dbl, i32, C.POINTER(C.c_int), C.POINTER(dbl), vp])
 _sig("schwz_profile_begin", i32, [i32])
@@ -135,6 +136,7 @@ _sig("schwz_subdomain_add_put_list", i32, [vp, i32, i64, vp])
 _sig("schwz_subdomain_send_offset", i32, [vp, i32, C.POINTER(i64)])
 _sig("schwz_subdomain_recv_offset", i32, [vp, i32, C.POINTER(i64)])
 _sig("schwz_cholesky", i32, [i64, vp, vp, vp, i32] + [pvp] * 7)
+_sig("schwz_ilu0", i32, [i64, vp, vp, vp] + [pvp] * 6)
 _sig("schwz_free", None, [vp])
 _sig("schwz_subdomain_to_device", i32, [vp, vp, C.POINTER(SolverOptions)])
 _sig("schwz_ras_pack", i32, [vp, vp, vp])

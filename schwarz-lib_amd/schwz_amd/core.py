@@ -65,10 +65,10 @@ class Csr:
 class Pcg:
     """Device-resident preconditioned CG (gko::solver::Cg + stop::Combined)."""
 
-    def __init__(self, csr, precond=capi.PRECOND_NONE):
+    def __init__(self, csr, precond=capi.PRECOND_NONE, block_size=1):
         self.csr = csr
         h = C.c_void_p()
-        check(lib.schwz_pcg_create(csr.h, precond, C.byref(h)))
+        check(lib.schwz_pcg_create_ex(csr.h, precond, block_size, C.byref(h)))
         self.h = h
 
     def solve(self, d_b, d_x, rtol, max_iters, stream=0, want_stats=True):
@@ -91,11 +91,12 @@ class Pcg:
 class Trs:
     """y = P^T L^-T L^-1 P b (gko LowerTrs/UpperTrs + Permutation)."""
 
-    def __init__(self, l_rp, l_col, l_val, u_rp, u_col, u_val, perm):
+    def __init__(self, l_rp, l_col, l_val, u_rp, u_col, u_val, perm=None):
         arrs = [np.ascontiguousarray(a, dtype=t) for a, t in
                 ((l_rp, IDX), (l_col, IDX), (l_val, np.float64), (u_rp, IDX), (u_col, IDX),
-                 (u_val, np.float64), (perm, IDX))]
-        self.n = len(perm)
+                 (u_val, np.float64))]
+        arrs.append(None if perm is None else np.ascontiguousarray(perm, dtype=IDX))
+        self.n = len(l_rp) - 1
         h = C.c_void_p()
         check(lib.schwz_trs_create(self.n, *[ptr(a) for a in arrs], C.byref(h)))
         self.h = h
@@ -110,6 +111,29 @@ class Trs:
 
     def __del__(self):
         self.close()
+
+
+def ilu0(rp, col, val):
+    """Host ILU(0) standing in for gko::factorization::ParIlu (solve.cpp:506-532)."""
+    rp = np.ascontiguousarray(rp, dtype=IDX)
+    col = np.ascontiguousarray(col, dtype=IDX)
+    val = np.ascontiguousarray(val, dtype=np.float64)
+    n = len(rp) - 1
+    out = [C.c_void_p() for _ in range(6)]
+    check(lib.schwz_ilu0(n, ptr(rp), ptr(col), ptr(val), *[C.byref(o) for o in out]))
+
+    def take(p, cnt, ctype, dtype):
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(ctype)), shape=(max(cnt, 1),))[:cnt].copy().astype(dtype)
+
+    l_rp = take(out[0], n + 1, C.c_int32, IDX)
+    u_rp = take(out[3], n + 1, C.c_int32, IDX)
+    res = dict(l_rp=l_rp, l_col=take(out[1], int(l_rp[-1]), C.c_int32, IDX),
+               l_val=take(out[2], int(l_rp[-1]), C.c_double, np.float64), u_rp=u_rp,
+               u_col=take(out[4], int(u_rp[-1]), C.c_int32, IDX),
+               u_val=take(out[5], int(u_rp[-1]), C.c_double, np.float64))
+    for o in out:
+        lib.schwz_free(o)
+    return res
 
 
 def cholesky(rp, col, val, natural=False):
@@ -331,11 +355,11 @@ class Subdomain:
 
     def to_device(self, local_rhs, local_solver=capi.SOLVER_ITERATIVE,
                   precond=capi.PRECOND_NONE, local_tol=1e-12, local_max_iters=-1,
-                  natural_factor_ordering=False, spmv_variant=0):
+                  natural_factor_ordering=False, spmv_variant=0, precond_block_size=1):
         local_rhs = np.ascontiguousarray(local_rhs, dtype=np.float64)
         assert len(local_rhs) == self.local_size_x
         opt = capi.SolverOptions(local_solver, precond, local_tol, local_max_iters,
-                                 int(natural_factor_ordering), spmv_variant, 0)
+                                 int(natural_factor_ordering), spmv_variant, int(precond_block_size))
         check(lib.schwz_subdomain_to_device(self.h, ptr(local_rhs), C.byref(opt)))
         self.on_device = True
 

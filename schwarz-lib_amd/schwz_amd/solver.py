@@ -180,12 +180,20 @@ def _precond_code(metadata):
     lp = metadata.local_precond
     if lp in ("null", "", None):
         return capi.PRECOND_NONE
-    if lp == "block-jacobi" and int(metadata.precond_max_block_size) == 1:
-        return capi.PRECOND_JACOBI
+    if lp == "block-jacobi":
+        bs = int(metadata.precond_max_block_size)
+        if bs == 1:
+            return capi.PRECOND_JACOBI
+        if 1 < bs <= 32:
+            return capi.PRECOND_BLOCK_JACOBI
+        raise capi.NotImplementedSchwz(capi.ERR_NOT_IMPLEMENTED,
+                                       "block-jacobi: precond_max_block_size must be in 1..32")
+    if lp == "ilu":
+        return capi.PRECOND_ILU
+    # unknown names only print to stderr in the reference (solve.cpp:568-570); refuse instead
     raise capi.NotImplementedSchwz(
         capi.ERR_NOT_IMPLEMENTED,
-        "local_precond '%s' (max block size %s) is not implemented; available: null, "
-        "block-jacobi with precond_max_block_size=1" % (lp, metadata.precond_max_block_size))
+        "local_precond '%s' is not implemented; available: null, block-jacobi, ilu" % lp)
 
 
 class SolverRAS:
@@ -302,7 +310,7 @@ class SolverRAS:
             sd.to_device(sd.local_rhs(self._rhs), local_solver=solver_code, precond=precond_code,
                          local_tol=m.local_solver_tolerance, local_max_iters=m.local_max_iters,
                          natural_factor_ordering=s.naturally_ordered_factor,
-                         spmv_variant=s.spmv_variant)
+                         spmv_variant=s.spmv_variant, precond_block_size=m.precond_max_block_size)
             # use_mixed_precision (MixedValueType = float): halos travel as fp32
             self.send_buf[me] = be.empty(sd.num_send, s.use_mixed_precision)
             self.recv_buf[me] = be.empty(sd.num_recv, s.use_mixed_precision)

@@ -74,7 +74,7 @@ class OracleSubdomain:
         return np.ascontiguousarray(rhs_fn(self.local_to_global[:self.local_size_x]))
 
     def to_device(self, local_rhs, local_solver=0, precond=0, local_tol=1e-12, local_max_iters=-1,
-                  natural_factor_ordering=False, spmv_variant=0):
+                  natural_factor_ordering=False, spmv_variant=0, precond_block_size=1):
         # the oracle state extracts the local rhs from a global vector: rebuild the entries it
         # will read
         rhs = np.zeros(self.sd.N)
@@ -82,7 +82,8 @@ class OracleSubdomain:
         self._rhs_global = rhs
         s = O.make_settings(overlap=self.overlap, local_solver=local_solver, precond=precond,
                             local_tol=local_tol, local_max_iters=local_max_iters,
-                            natural_factor_ordering=int(natural_factor_ordering))
+                            natural_factor_ordering=int(natural_factor_ordering),
+                            precond_block_size=int(precond_block_size))
         self._settings = s
         self.state = O.State(self.sd, rhs, s)
 
@@ -160,3 +161,4 @@ class OracleBackend:
 
     def subdomain(self, problem, P, me, overlap, first_row):
         return OracleSubdomain(problem, P, me, overlap, first_row)
+

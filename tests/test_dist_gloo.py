@@ -84,6 +84,13 @@ CASES = {
         world=3, settings=dict(laplacian_dim=3, laplacian_shape=(6, 5, 9)),
         metadata=dict(tolerance=1e-6, max_iters=300, local_precond="block-jacobi",
                       precond_max_block_size=1, local_solver_tolerance=0.0, local_max_iters=5)),
+    "lap2d_cg_ilu": dict(
+        world=2, settings=dict(),
+        metadata=dict(oned_laplacian_size=18, tolerance=1e-8, max_iters=300, local_precond="ilu")),
+    "lap2d_cg_block_jacobi8": dict(
+        world=3, settings=dict(),
+        metadata=dict(oned_laplacian_size=18, tolerance=1e-8, max_iters=300,
+                      local_precond="block-jacobi", precond_max_block_size=8)),
     "lap2d_direct_overlap3": dict(
         world=2, settings=dict(local_solver="direct-ginkgo", overlap=3),
         metadata=dict(oned_laplacian_size=16, tolerance=1e-9, max_iters=300)),
@@ -115,7 +122,8 @@ def test_distributed_run_reproduces_lockstep_oracle(oracle, name, tmp_path):
     s = oracle.make_settings(
         max_iters=md["max_iters"], tol=md["tolerance"], overlap=st.get("overlap", 2),
         local_solver=oracle.SOLVER_DIRECT if st.get("local_solver", "").startswith("direct") else 0,
-        precond=1 if md.get("local_precond") == "block-jacobi" else 0,
+        precond=oracle.precond_code(md.get("local_precond"), md.get("precond_max_block_size", 1))[0],
+        precond_block_size=oracle.precond_code(md.get("local_precond"), md.get("precond_max_block_size", 1))[1],
         local_tol=md.get("local_solver_tolerance", 1e-12), local_max_iters=md.get("local_max_iters", -1),
         enable_onesided=int(bool(case.get("onesided"))), enable_overlap=int(bool(case.get("overlap"))))
     fr = oracle.first_rows_regular(N, world)

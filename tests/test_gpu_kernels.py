@@ -186,6 +186,78 @@ def test_direct_solve_matches_oracle(schwz, oracle, torch_cuda, case, natural):
     assert np.abs(got - exp).max() <= 1e-10 * np.abs(exp).max()
 
 
+@pytest.mark.parametrize("pc", [(2, 2), (2, 7), (2, 16), (2, 32), (3, 1)])
+@pytest.mark.parametrize("case", ["lap2d", "lap3d", "ani3"])
+def test_pcg_block_jacobi_and_ilu_match_oracle(schwz, oracle, torch_cuda, case, pc):
+    """Block-Jacobi with consecutive blocks (gko preconditioner::Jacobi, solve.cpp:488-504) and
+    ILU(0) (solve.cpp:506-532) in the device-resident PCG against the oracle's recurrence."""
+    torch = torch_cuda
+    precond, bs = pc
+    if case == "lap2d":
+        rp, col, val = oracle.laplacian2d(50)
+    elif case == "lap3d":
+        rp, col, val = oracle.laplacian3d(21, 19, 23)   # n = 9177 > 8192: multi-launch trs plan
+    else:
+        g = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "ani3_crop.npz"))
+        rp, col, val = g["rp"], g["col"], g["val"]
+    n = len(rp) - 1
+    rng = np.random.default_rng(17)
+    b = rng.standard_normal(n)
+    x0 = rng.standard_normal(n) * 0.1
+    A = schwz.Csr(rp, col, val)
+    cg = schwz.Pcg(A, precond, bs)
+    for iters in (1, 6, 25):
+        exp, it_o, rn_o = oracle.pcg(rp, col, val, b, x0, precond, 0.0, iters, block_size=bs)
+        d_b, d_x = _dev(torch, b), _dev(torch, x0)
+        it_g, rn_g = cg.solve(d_b.data_ptr(), d_x.data_ptr(), 0.0, iters)
+        got = d_x.cpu().numpy()
+        assert it_g == it_o == iters
+        assert np.abs(got - exp).max() <= RTOL_CG * np.abs(exp).max()
+        assert abs(rn_g - rn_o) <= 1e-8 * max(rn_o, 1e-300) + 1e-14
+    # tolerance stop
+    exp, it_o, rn_o = oracle.pcg(rp, col, val, b, None, precond, 1e-10, n, block_size=bs)
+    d_b, d_x = _dev(torch, b), torch.zeros(n, dtype=torch.float64, device="cuda")
+    it_g, rn_g = cg.solve(d_b.data_ptr(), d_x.data_ptr(), 1e-10, n)
+    assert abs(it_g - it_o) <= 1, (it_g, it_o)
+    assert np.abs(d_x.cpu().numpy() - exp).max() <= 1e-7 * np.abs(exp).max()
+
+
+@pytest.mark.parametrize("kind", ["ilu_noperm", "chol_perm"])
+def test_triangular_solves_multi_launch_plan(schwz, oracle, torch_cuda, kind):
+    """n > 8192 rows: the level schedule runs as wide/narrow segment launches instead of the
+    single-workgroup kernel; same answer as the oracle's sequential sweeps."""
+    torch = torch_cuda
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as sl
+    rp, col, val = oracle.laplacian3d(27, 25, 22)
+    n = len(rp) - 1
+    assert n > 8192
+    b = np.random.default_rng(23).standard_normal(n)
+    if kind == "ilu_noperm":
+        f = schwz.ilu0(rp, col, val)
+        L = sp.csr_matrix((f["l_val"], f["l_col"], f["l_rp"]), shape=(n, n))
+        U = sp.csr_matrix((f["u_val"], f["u_col"], f["u_rp"]), shape=(n, n))
+        exp = sl.spsolve_triangular(U, sl.spsolve_triangular(L, b, lower=True), lower=False)
+        perm = None
+    else:
+        f = schwz.cholesky(rp, col, val, False)
+        fo = oracle.cholesky(rp, col, val, False)
+        exp = oracle.direct_solve(fo, b)
+        perm = f["perm"]
+    trs = schwz.Trs(f["l_rp"], f["l_col"], f["l_val"], f["u_rp"], f["u_col"], f["u_val"], perm)
+    d_b = _dev(torch, b)
+    d_y = torch.zeros(n, dtype=torch.float64, device="cuda")
+    for _ in range(2):   # second call reuses the plan and work vectors
+        trs.solve(d_b.data_ptr(), d_y.data_ptr())
+    torch.cuda.synchronize()
+    got = d_y.cpu().numpy()
+    assert np.abs(got - exp).max() <= 1e-10 * np.abs(exp).max()
+    # in place (b == y) is allowed, like gko apply(b, b) in solve.cpp:709-720
+    trs.solve(d_b.data_ptr(), d_b.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_b.cpu().numpy(), got)
+
+
 @pytest.mark.parametrize("case", ["lap3d", "ragged"])
 def test_spmv_with_forced_tile_order(schwz, oracle, torch_cuda, case, monkeypatch):
     """The BFS visiting order of the row tiles (a locality permutation of the launch schedule,

@@ -27,7 +27,8 @@ def _oracle_settings(oracle, m, s, **kw):
     return oracle.make_settings(
         max_iters=m.max_iters, tol=m.tolerance, overlap=s.overlap,
         local_solver=oracle.SOLVER_DIRECT if s.local_solver.startswith("direct") else oracle.SOLVER_ITERATIVE,
-        precond=1 if m.local_precond == "block-jacobi" else 0,
+        precond=oracle.precond_code(m.local_precond, m.precond_max_block_size)[0],
+        precond_block_size=oracle.precond_code(m.local_precond, m.precond_max_block_size)[1],
         local_tol=m.local_solver_tolerance, local_max_iters=m.local_max_iters,
         enable_global_check=int(s.convergence_settings.enable_global_check),
         enable_onesided=int(s.comm_settings.enable_onesided),
@@ -85,6 +86,26 @@ def test_ras_2d_iterative_matches_oracle(schwz, oracle, torch_cuda, P, precond):
         dict(oned_laplacian_size=n, tolerance=1e-8, max_iters=300, local_precond=precond,
              precond_max_block_size=1))
     _check_against_oracle(oracle, oracle.laplacian2d(n), P, solver, m, out)
+
+
+@pytest.mark.parametrize("P", [1, 3])
+@pytest.mark.parametrize("precond", [("block-jacobi", 4), ("block-jacobi", 32), ("ilu", 1)])
+def test_ras_block_jacobi_and_ilu_match_oracle(schwz, oracle, torch_cuda, P, precond):
+    """--local_precond=block-jacobi --precond_max_block_size=B and --local_precond=ilu
+    (solve.cpp:488-532) through the whole outer loop, 2-D and 3-D."""
+    name, bs = precond
+    n = 30
+    solver, m, out = _run_gpu(
+        schwz, P, dict(),
+        dict(oned_laplacian_size=n, tolerance=1e-8, max_iters=300, local_precond=name,
+             precond_max_block_size=bs))
+    _check_against_oracle(oracle, oracle.laplacian2d(n), P, solver, m, out)
+    shape = (22, 21, 40)   # subdomains above 8192 rows for P=1..3: multi-launch ILU sweeps
+    solver, m, out = _run_gpu(
+        schwz, P, dict(laplacian_dim=3, laplacian_shape=shape),
+        dict(tolerance=1e-7, max_iters=300, local_precond=name, precond_max_block_size=bs,
+             local_solver_tolerance=1e-10))
+    _check_against_oracle(oracle, oracle.laplacian3d(*shape), P, solver, m, out)
 
 
 @pytest.mark.parametrize("P", [2, 8])

@@ -195,3 +195,53 @@ def test_cholesky_rejects_indefinite(schwz):
     with pytest.raises(schwz.SchwzError) as e:
         schwz.cholesky(rp, col, val, True)
     assert e.value.code == schwz.capi.ERR_NOT_SPD
+
+
+@pytest.mark.parametrize("case", ["lap2d", "lap3d", "ani3"])
+def test_ilu0_matches_oracle_and_reproduces_pattern(schwz, oracle, case):
+    """ILU(0) standing in for gko ParIlu (solve.cpp:506-532): unit-lower L, U with the
+    diagonal, (L U)_ij = A_ij on the pattern of A."""
+    import scipy.sparse as sp
+    if case == "lap2d":
+        rp, col, val = oracle.laplacian2d(17)
+    elif case == "lap3d":
+        rp, col, val = oracle.laplacian3d(9, 7, 5)
+    else:
+        g = np.load(os.path.join(G, "ani3_crop.npz"))
+        rp, col, val = g["rp"], g["col"], g["val"]
+    n = len(rp) - 1
+    f, fo = schwz.ilu0(rp, col, val), oracle.ilu0(rp, col, val)
+    for k in ("l_rp", "l_col", "u_rp", "u_col"):
+        assert np.array_equal(f[k], fo[k]), k
+    for k in ("l_val", "u_val"):
+        assert np.array_equal(f[k], fo[k]), k   # same elimination order: bit-identical
+    L = sp.csr_matrix((f["l_val"], f["l_col"], f["l_rp"]), shape=(n, n))
+    U = sp.csr_matrix((f["u_val"], f["u_col"], f["u_rp"]), shape=(n, n))
+    assert np.array_equal(L.diagonal(), np.ones(n))
+    assert sp.tril(U, -1).nnz == 0 and sp.triu(L, 1).nnz == 0
+    A = sp.csr_matrix((val, col, rp), shape=(n, n))
+    pat = A.copy()
+    pat.data[:] = 1.0
+    assert abs((L @ U).multiply(pat) - A).max() <= 1e-13 * abs(A).max()
+
+
+def test_ilu0_rejects_zero_pivot(schwz):
+    rp = np.array([0, 2, 4], dtype=np.int32)
+    col = np.array([0, 1, 0, 1], dtype=np.int32)
+    val = np.array([0.0, 1.0, 1.0, 1.0])
+    with pytest.raises(schwz.SchwzError):
+        schwz.ilu0(rp, col, val)
+
+
+def test_precond_names_map_like_the_reference(schwz):
+    """solve.cpp:488-571: null / block-jacobi(max block size) / ilu; isai and unknown names are
+    refused here (the reference only prints for unknown names)."""
+    from schwz_amd import solver as sv
+    code = lambda name, bs=1: sv._precond_code(schwz.Metadata(local_precond=name, precond_max_block_size=bs))
+    assert code("null") == schwz.capi.PRECOND_NONE
+    assert code("block-jacobi", 1) == schwz.capi.PRECOND_JACOBI
+    assert code("block-jacobi", 16) == schwz.capi.PRECOND_BLOCK_JACOBI
+    assert code("ilu") == schwz.capi.PRECOND_ILU
+    for bad in (("isai", 1), ("block-jacobi", 64), ("nope", 1)):
+        with pytest.raises(schwz.capi.NotImplementedSchwz):
+            code(*bad)
