@@ -58,16 +58,16 @@ __device__ __forceinline__ double fold_partials(const double *part, int count, d
 // Returns -1 past the end.
 __device__ __forceinline__ int xcd_tile(const CsrView &A, int xcd, int j)
 {
-    const int B = A.xcd_block;
-    const int tile = (j / B) * (kXcds * B) + xcd * B + (j % B);
+    const int sh = A.xcd_shift;  // xcd_block = 1 << sh
+    const int tile = ((j >> sh) << (sh + 3)) + (xcd << sh) + (j & (A.xcd_block - 1));
     return tile < A.ntiles ? tile : -1;
 }
 
 // number of sequence slots per XCD
 __device__ __forceinline__ int xcd_slots(const CsrView &A)
 {
-    const int B = A.xcd_block;
-    return ((A.ntiles + kXcds * B - 1) / (kXcds * B)) * B;
+    const int sh = A.xcd_shift;
+    return ((A.ntiles + (kXcds << sh) - 1) >> (sh + 3)) << sh;
 }
 
 

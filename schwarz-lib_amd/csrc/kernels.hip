@@ -736,7 +736,12 @@ int spmv_grid(const CsrView &A, int variant)
 {
     // wave variants: four wave tiles per workgroup
     const int units = (variant == 3 || variant == 5) ? (A.nwtiles + 3) / 4 : A.ntiles;
-    int g = units < kMaxGrid ? units : kMaxGrid;
+    static const int cap = [] {  // SCHWZ_SPMV_GRID: smaller grids for occupancy experiments
+        const char *e = std::getenv("SCHWZ_SPMV_GRID");
+        const int v = e ? std::atoi(e) : 0;
+        return (v >= kXcds && v < kMaxGrid) ? v : kMaxGrid;
+    }();
+    int g = units < cap ? units : cap;
     g = ((g + kXcds - 1) / kXcds) * kXcds;
     return g < kXcds ? kXcds : g;
 }
@@ -1548,7 +1553,11 @@ int schwz_csr_create(int64_t nrows, int64_t ncols, const schwz_idx *h_rp, const 
         const char *be = std::getenv("SCHWZ_XCD_BLOCK");
         if (be && std::atoi(be) > 0) B = std::atoi(be);
         const int64_t cap = (ntl + kXcds - 1) / kXcds;
-        A->v.xcd_block = (int)std::max<int64_t>(1, std::min<int64_t>(B, cap));
+        B = std::max<int64_t>(1, std::min<int64_t>(B, cap));
+        int sh = 0;  // rounded down to a power of two: the deal is shifts and masks on the device
+        while ((int64_t(2) << sh) <= B) ++sh;
+        A->v.xcd_shift = sh;
+        A->v.xcd_block = 1 << sh;
     }
     A->v.nwtiles = (int)wtiles.size() - 1;
     A->v.wtile_row = (const schwz_idx *)A->d_wtile;

@@ -50,7 +50,8 @@ struct CsrView {
     int ntiles = 0;
     const schwz_idx *tile_row = nullptr;  // ntiles+1 row boundaries
     const schwz_idx *tile_order = nullptr;  // optional BFS visiting order (SCHWZ_TILE_ORDER=1)
-    int xcd_block = 0;  // tiles are dealt to the 8 XCDs block-cyclically in runs of this many
+    int xcd_block = 0;  // tiles are dealt to the 8 XCDs block-cyclically in runs of this many (a power of two)
+    int xcd_shift = 0;  // log2(xcd_block)
     // kSpmvResidDual: 1 where the tile's rows or columns reach past `dual_split` (where x2 may
     // differ from x); elsewhere the second product is skipped (nullptr: every tile)
     const uint8_t *tile_dual = nullptr;

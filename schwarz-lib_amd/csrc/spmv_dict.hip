@@ -252,12 +252,26 @@ struct TinyMap {
 constexpr int kPatMax = 64;       // patterns per table
 constexpr int kPatEntries = 1024;  // entries per table (npat * lmax)
 
-template <int MODE>
+// One staged table entry: the value and the BYTE offset of the column relative to the row
+// (col - row) * 8 (WIDE: col - row), read together by one ds_read_b128.  Pattern p starts at entry p * ls with
+// ls = lmax rounded up to kChunk, so entry k of a chunk sits at an immediate offset; the padding
+// entries are (0.0, 0): a lane past its row's length gathers x[row] and discards it.
+struct __attribute__((aligned(16))) PatEntry {
+    double val;
+    int off8;
+    int pad;
+};
+
+__host__ __device__ inline int pat_stride(int lmax) { return (lmax + kChunk - 1) / kChunk * kChunk; }
+
+// NT: tiles a workgroup works on at a time (NT rows per lane; 2 was measured and is slower: the
+// registers cost occupancy).  WIDE: x needs 64-bit offsets (>= 2^28 columns); otherwise the
+// gathers use the scalar-base + 32-bit-lane-offset form.
+template <int MODE, int NT, bool WIDE>
 __global__ __launch_bounds__(kBlock) void spmv_pattern_kernel(CsrView A, SpmvArgs a)
 {
 #pragma clang fp contract(off)
-    __shared__ double pval[kPatEntries];
-    __shared__ int pdelta[kPatEntries];
+    __shared__ PatEntry ptab[kPatEntries];
     __shared__ int plen[kPatMax];
     __shared__ double red[4];
     if (MODE == kSpmvDot || MODE == kSpmvResidInit) {
@@ -270,61 +284,99 @@ __global__ __launch_bounds__(kBlock) void spmv_pattern_kernel(CsrView A, SpmvArg
     const int chunk = xcd_slots(A);
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
     const bool dual = (MODE == kSpmvResidDual) && a.x2 != nullptr;
-    int cached = -1, lmax = 0;
+    int cached = -1, ls = 0;  // staged table and its row stride
 
-    for (int t = slot; t < chunk; t += per_xcd) {
-        const int tile = xcd_tile(A, xcd, t);
-        if (tile < 0) continue;
-        const int r0 = A.tile_row[tile], r1 = A.tile_row[tile + 1];
-        const int tb = A.tile_table[tile];
+    auto stage_table = [&](int tb) {  // workgroup-uniform
+        if (tb == cached) return;
+        const int eoff = A.tbl_desc[4 * tb], loff = A.tbl_desc[4 * tb + 1];
+        const int npat = A.tbl_desc[4 * tb + 2], lmax = A.tbl_desc[4 * tb + 3];
+        ls = pat_stride(lmax);
+        lds_barrier();  // everyone is done with the previous table
+        for (int i = tid; i < npat * ls; i += kBlock) {
+            const int pt = i / ls, k = i - pt * ls;
+            PatEntry e;
+            e.val = k < lmax ? A.tbl_val[eoff + pt * lmax + k] : 0.0;
+            e.off8 = k < lmax ? A.tbl_delta[eoff + pt * lmax + k] * (WIDE ? 1 : 8) : 0;
+            e.pad = 0;
+            ptab[i] = e;
+        }
+        if (tid < npat) plen[tid] = A.tbl_len[loff + tid];
+        lds_barrier();
+        cached = tb;
+    };
+    auto xload = [&](const double *xv, int row, int off8) -> double {
+        if (WIDE) return xv[(int64_t)row + off8];  // the entry holds col - row itself
+        const uint32_t o = (uint32_t)row * 8u + (uint32_t)off8;
+        return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(xv) + o);
+    };
+    // the row's own operands of the fused epilogue (requested ahead of the x gathers)
+    auto own_load = [&](bool have, int rw, double &ox, double &ob, double &od, bool with_x) {
+        ox = 0.0, ob = 0.0, od = 1.0;
+        if (!have) return;
+        if (MODE == kSpmvDot && with_x) ox = a.x[rw];
+        if (MODE == kSpmvResidInit || MODE == kSpmvResidDual) ob = a.b[rw];
+        if (MODE == kSpmvResidNorm && rw < a.row_limit) ob = a.b[rw];
+        if ((MODE == kSpmvResidInit || MODE == kSpmvResidDual) && a.dinv) od = a.dinv[rw];
+        if (MODE == kSpmvPlain && a.beta != 0.0) ob = a.y[rw];
+    };
+    auto epilogue = [&](int rw, double sum, double sum2, bool dual_t, double ox, double ob, double od) {
+        if (MODE == kSpmvPlain) {
+            a.y[rw] = (a.beta == 0.0) ? a.alpha * sum : a.alpha * sum + a.beta * ob;
+        } else if (MODE == kSpmvDot) {
+            a.y[rw] = sum;
+            acc0 += ox * sum;
+        } else if (MODE == kSpmvResidInit || MODE == kSpmvResidDual) {
+            const double r = ob - sum;
+            const double z = a.dinv ? od * r : r;
+            a.y[rw] = r;
+            a.p[rw] = z;
+            acc0 += r * z;
+            acc1 += r * r;
+            if (MODE == kSpmvResidDual && rw < a.row_limit) {
+                const double r2 = dual_t ? ob - sum2 : r;
+                acc2 += r2 * r2;
+            }
+        } else {  // kSpmvResidNorm
+            if (rw < a.row_limit) {
+                const double r = ob - sum;
+                acc1 += r * r;
+            }
+        }
+    };
+    // entries [j0, len) of the lane's pattern against vector xv, in entry order
+    auto row_tail = [&](const double *xv, int row, int base, int len, int j0, double &sum) {
+        for (int j = j0; j < len; j += kChunk) {
+            double v[kChunk], xg[kChunk];
+#pragma unroll
+            for (int k = 0; k < kChunk; ++k) {
+                const PatEntry e = ptab[base + j + k];
+                v[k] = e.val;
+                xg[k] = xload(xv, row, e.off8);
+            }
+#pragma unroll
+            for (int k = 0; k < kChunk; ++k)
+                if (j + k < len) sum += v[k] * xg[k];
+        }
+    };
+    // one tile on its own: any kind (pattern table, plain rows, one long row)
+    auto one_tile = [&](int tile, int r0, int r1, int tb) {
         const int row = r0 + tid;
-        const bool have_row = (r1 - r0 > 1) ? row < r1 : tid == 0;
+        const bool single = r1 - r0 == 1;
+        const bool have_row = single ? tid == 0 : row < r1;
+        const int rw = single ? r0 : row;
         const bool dual_t = dual && (!A.tile_dual || A.tile_dual[tile]);
+        double ox, ob, od;
+        own_load(have_row, rw, ox, ob, od, true);
         double sum = 0.0, sum2 = 0.0;
         if (tb >= 0) {
-            if (tb != cached) {  // workgroup-uniform
-                const int eoff = A.tbl_desc[4 * tb], loff = A.tbl_desc[4 * tb + 1];
-                const int npat = A.tbl_desc[4 * tb + 2];
-                lmax = A.tbl_desc[4 * tb + 3];
-                lds_barrier();  // everyone is done with the previous table
-                for (int i = tid; i < npat * lmax; i += kBlock) {
-                    pval[i] = A.tbl_val[eoff + i];
-                    pdelta[i] = A.tbl_delta[eoff + i];
-                }
-                if (tid < npat) plen[tid] = A.tbl_len[loff + tid];
-                lds_barrier();
-                cached = tb;
-            }
+            stage_table(tb);
             if (row < r1) {
                 const int pid = A.pat_id[row];
                 const int len = plen[pid];
-                const int base = pid * lmax;
-                for (int j = 0; j < len; j += kChunk) {
-                    double v[kChunk], xg[kChunk], xg2[kChunk];
-                    int c[kChunk];
-                    const int jl = base + len - 1;
-#pragma unroll
-                    for (int k = 0; k < kChunk; ++k) {
-                        const int q = min(base + j + k, jl);
-                        v[k] = pval[q];
-                        c[k] = row + pdelta[q];
-                    }
-#pragma unroll
-                    for (int k = 0; k < kChunk; ++k) xg[k] = a.x[c[k]];
-                    if (dual_t) {
-#pragma unroll
-                        for (int k = 0; k < kChunk; ++k) xg2[k] = a.x2[c[k]];
-                    }
-#pragma unroll
-                    for (int k = 0; k < kChunk; ++k) {
-                        if (j + k < len) {
-                            sum += v[k] * xg[k];
-                            if (dual_t) sum2 += v[k] * xg2[k];
-                        }
-                    }
-                }
+                row_tail(a.x, row, pid * ls, len, 0, sum);
+                if (dual_t) row_tail(a.x2, row, pid * ls, len, 0, sum2);
             }
-        } else if (r1 - r0 > 1) {
+        } else if (!single) {
             // tile without a pattern table: one lane per row straight from val/col
             if (row < r1) {
                 for (int j = A.rp[row]; j < A.rp[row + 1]; ++j) {
@@ -345,31 +397,80 @@ __global__ __launch_bounds__(kBlock) void spmv_pattern_kernel(CsrView A, SpmvArg
             sum = block_sum(part, red);
             if (dual_t) sum2 = block_sum(part2, red);
         }
-        if (have_row) {
-            const int rw = (r1 - r0 > 1) ? row : r0;
-            if (MODE == kSpmvPlain) {
-                a.y[rw] = (a.beta == 0.0) ? a.alpha * sum : a.alpha * sum + a.beta * a.y[rw];
-            } else if (MODE == kSpmvDot) {
-                a.y[rw] = sum;
-                acc0 += a.x[rw] * sum;
-            } else if (MODE == kSpmvResidInit || MODE == kSpmvResidDual) {
-                const double bb = a.b[rw];
-                const double r = bb - sum;
-                const double z = a.dinv ? a.dinv[rw] * r : r;
-                a.y[rw] = r;
-                a.p[rw] = z;
-                acc0 += r * z;
-                acc1 += r * r;
-                if (MODE == kSpmvResidDual && rw < a.row_limit) {
-                    const double r2 = dual_t ? bb - sum2 : r;
-                    acc2 += r2 * r2;
-                }
-            } else {  // kSpmvResidNorm
-                if (rw < a.row_limit) {
-                    const double r = a.b[rw] - sum;
-                    acc1 += r * r;
+        if (have_row) epilogue(rw, sum, sum2, dual_t, ox, ob, od);
+    };
+
+    // Per tile the fetches depend on each other (tile bounds -> pattern ids -> x -> y); with
+    // NT > 1 each step is issued for NT tiles of the workgroup's sequence before it is waited for.
+    for (int t = slot; t < chunk; t += NT * per_xcd) {
+        int tile[NT], r0[NT], r1[NT], tb[NT];
+        bool together = true;
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const int tt = t + u * per_xcd;
+            tile[u] = tt < chunk ? xcd_tile(A, xcd, tt) : -1;
+            r0[u] = r1[u] = 0;
+            tb[u] = -1;
+            if (tile[u] >= 0) {
+                r0[u] = A.tile_row[tile[u]];
+                r1[u] = A.tile_row[tile[u] + 1];
+                tb[u] = A.tile_table[tile[u]];
+            }
+            together = together && tile[u] >= 0 && tb[u] >= 0 && tb[u] == tb[0];
+        }
+        if (!together) {
+#pragma unroll
+            for (int u = 0; u < NT; ++u)
+                if (tile[u] >= 0) one_tile(tile[u], r0[u], r1[u], tb[u]);
+            continue;
+        }
+        stage_table(tb[0]);
+        int row[NT], pid[NT];
+        bool act[NT], dual_t[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            row[u] = r0[u] + tid;
+            act[u] = row[u] < r1[u];
+            pid[u] = act[u] ? (int)A.pat_id[row[u]] : 0;
+            dual_t[u] = dual && (!A.tile_dual || A.tile_dual[tile[u]]);
+        }
+        double ox[NT], ob[NT], od[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) own_load(act[u], row[u], ox[u], ob[u], od[u], false);
+        int len[NT], base[NT];
+        double v[NT][kChunk], xg[NT][kChunk];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            len[u] = act[u] ? plen[pid[u]] : 0;
+            base[u] = pid[u] * ls;
+            // One gather instruction per entry; the fused dot takes x[row] from the gathers instead
+            // of loading it again.  Measured in-box A/B (tools/ab.sh, 256^3, CG iteration time):
+            // this kernel -1..-3 % against the unpacked-table version; two tiles per workgroup at a
+            // time, an LDS ring of the in-plane x window, and lane shuffles for the near-diagonal
+            // entries all land within +-3 %, i.e. inside the drift of one box.
+            const int rsafe = act[u] ? row[u] : r0[u];  // idle lanes read a valid address
+            bool diag_seen = false;
+#pragma unroll
+            for (int k = 0; k < kChunk; ++k) {
+                const PatEntry e = ptab[base[u] + k];
+                v[u][k] = e.val;
+                xg[u][k] = xload(a.x, rsafe, act[u] ? e.off8 : 0);
+                if (MODE == kSpmvDot && e.off8 == 0) {
+                    ox[u] = xg[u][k];
+                    diag_seen = true;
                 }
             }
+            if (MODE == kSpmvDot && act[u] && !diag_seen) ox[u] = a.x[row[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            double sum = 0.0, sum2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < kChunk; ++k)
+                if (k < len[u]) sum += v[u][k] * xg[u][k];
+            if (len[u] > kChunk) row_tail(a.x, row[u], base[u], len[u], kChunk, sum);
+            if (dual_t[u] && act[u]) row_tail(a.x2, row[u], base[u], len[u], 0, sum2);
+            if (act[u]) epilogue(row[u], sum, sum2, dual_t[u], ox[u], ob[u], od[u]);
         }
     }
     if (MODE != kSpmvPlain) {
@@ -386,25 +487,24 @@ __global__ __launch_bounds__(kBlock) void spmv_pattern_kernel(CsrView A, SpmvArg
     }
 }
 
+
+
 int launch_spmv_pattern(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s)
 {
+    const bool wide = A.ncols >= (int64_t(1) << 28);
+#define SCHWZ_PAT_LAUNCH(M)                                                                          \
+    if (wide)                                                                                        \
+        hipLaunchKernelGGL((spmv_pattern_kernel<M, 1, true>), dim3(grid), dim3(kBlock), 0, s, A, a); \
+    else                                                                                             \
+        hipLaunchKernelGGL((spmv_pattern_kernel<M, 1, false>), dim3(grid), dim3(kBlock), 0, s, A, a);
     switch (mode) {
-    case kSpmvPlain:
-        hipLaunchKernelGGL(spmv_pattern_kernel<kSpmvPlain>, dim3(grid), dim3(kBlock), 0, s, A, a);
-        break;
-    case kSpmvDot:
-        hipLaunchKernelGGL(spmv_pattern_kernel<kSpmvDot>, dim3(grid), dim3(kBlock), 0, s, A, a);
-        break;
-    case kSpmvResidInit:
-        hipLaunchKernelGGL(spmv_pattern_kernel<kSpmvResidInit>, dim3(grid), dim3(kBlock), 0, s, A, a);
-        break;
-    case kSpmvResidDual:
-        hipLaunchKernelGGL(spmv_pattern_kernel<kSpmvResidDual>, dim3(grid), dim3(kBlock), 0, s, A, a);
-        break;
-    default:
-        hipLaunchKernelGGL(spmv_pattern_kernel<kSpmvResidNorm>, dim3(grid), dim3(kBlock), 0, s, A, a);
-        break;
+    case kSpmvPlain: SCHWZ_PAT_LAUNCH(kSpmvPlain) break;
+    case kSpmvDot: SCHWZ_PAT_LAUNCH(kSpmvDot) break;
+    case kSpmvResidInit: SCHWZ_PAT_LAUNCH(kSpmvResidInit) break;
+    case kSpmvResidDual: SCHWZ_PAT_LAUNCH(kSpmvResidDual) break;
+    default: SCHWZ_PAT_LAUNCH(kSpmvResidNorm) break;
     }
+#undef SCHWZ_PAT_LAUNCH
     SCHWZ_HIP_TRY(hipGetLastError());
     return SCHWZ_OK;
 }
@@ -484,7 +584,7 @@ static int build_spmv_pattern(schwz_csr *A, const schwz_idx *rp, const schwz_idx
             }
             pat_id[(size_t)r] = (uint8_t)id;
         }
-        if (!ok || (int64_t)pats.size() * std::max(lmax, 1) > kPatEntries) continue;
+        if (!ok || (int64_t)pats.size() * pat_stride(std::max(lmax, 1)) > kPatEntries) continue;
         Table tb;
         tb.npat = (int)pats.size();
         tb.lmax = std::max(lmax, 1);

@@ -15,7 +15,8 @@ import numpy as np
 import torch  # noqa: F401,E402
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_PKG), "lib", "libschwz_hip.so")
+# SCHWZ_HIP_LIB: another build of the same library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("SCHWZ_HIP_LIB") or os.path.join(os.path.dirname(_PKG), "lib", "libschwz_hip.so")
 
 OK = 0
 ERR_INVALID, ERR_HIP, ERR_NOT_IMPLEMENTED, ERR_NOT_SPD, ERR_IO, ERR_DIVERGED = 1, 2, 3, 4, 5, 6
