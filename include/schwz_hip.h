@@ -124,6 +124,18 @@ int schwz_pcg_solve(schwz_pcg *s, const double *d_b, double *d_x, double rtol,
                     int max_iters, int *h_iters, double *h_resnorm,
                     schwz_stream stream);
 
+/* Restarted GMRES(restart) with right preconditioning, device resident like the CG.
+ * Replaces gko::solver::Gmres with krylov_dim = settings.restart_iter and the same
+ * Combined(Iteration, ResidualNormReduction) criterion, the local solver of
+ * settings.non_symmetric_matrix (source/solve.cpp:486-520, applied at :750-753).
+ * max_iters counts Krylov vectors over all cycles; h_resnorm is the residual norm the
+ * stop test saw (the rotated right-hand side inside a cycle). */
+typedef struct schwz_gmres schwz_gmres;
+int schwz_gmres_create(const schwz_csr *A, int precond, int block_size, int restart, schwz_gmres **out);
+void schwz_gmres_destroy(schwz_gmres *s);
+int schwz_gmres_solve(schwz_gmres *s, const double *d_b, double *d_x, double rtol, int max_iters,
+                      int *h_iters, double *h_resnorm, schwz_stream stream);
+
 /* Profiling hooks for bench.py's roofline leg: between begin and end, every
  * launch of the dominant kernel (the CSR SpMV inside schwz_pcg_solve) is
  * bracketed by a HIP event pair on its launch stream; end synchronises and
@@ -267,6 +279,8 @@ typedef struct {
     int32_t natural_factor_ordering; /* settings.naturally_ordered_factor */
     int32_t spmv_variant;    /* 0 default */
     int32_t precond_block_size; /* metadata.precond_max_block_size (block-jacobi) */
+    int32_t non_symmetric;   /* settings.non_symmetric_matrix: GMRES instead of CG */
+    int32_t restart_iter;    /* settings.restart_iter (GMRES krylov_dim), >= 1 */
 } schwz_solver_options;
 
 /* Upload matrices / index lists, allocate x~=[interior|overlap|halo] (zero,
@@ -310,6 +324,10 @@ int schwz_ras_local_residual_wait(schwz_subdomain *sd, double *h_resnorm);
 /* step 3: y = solve(A_loc, b~), warm-started (Solve::local_solve,
  * source/solve.cpp:667-792).  h_inner_iters may be NULL (no sync). */
 int schwz_ras_local_solve(schwz_subdomain *sd, int *h_inner_iters, schwz_stream stream);
+/* Two-stage local solves: Solve::local_solve rebuilds the stopping criterion with a new
+ * iteration cap once iter_count > settings.reset_local_crit_iter (source/solve.cpp:723-742);
+ * max_iters = -1 means local_size_x.  Takes effect from the next local solve. */
+int schwz_ras_set_local_max_iters(schwz_subdomain *sd, int max_iters);
 /* steps 2+3 in one enqueue: the check residual of step 2 and the start residual of
  * the CG solve of step 3 come out of ONE pass over A_loc (two gathers per entry,
  * one matrix read), the norm's device->host copy is queued right behind it and

@@ -38,6 +38,10 @@ class Settings(C.Structure):
         ("enable_overlap", C.c_int32),
         ("use_mixed_precision", C.c_int32),
         ("precond_block_size", C.c_int32),
+        ("reset_local_crit_iter", C.c_int32),
+        ("updated_max_iters", C.c_int32),
+        ("non_symmetric", C.c_int32),
+        ("restart_iter", C.c_int32),
     ]
 
 
@@ -45,13 +49,15 @@ def make_settings(max_iters=100, tol=1e-6, overlap=2, local_solver=SOLVER_ITERAT
                   precond=PRECOND_NONE, local_tol=1e-12, local_max_iters=-1,
                   enable_global_check=1, enable_onesided=0, global_check_iter_offset=0,
                   natural_factor_ordering=0, num_threads=0, enable_overlap=0, use_mixed_precision=0,
-                  precond_block_size=1):
+                  precond_block_size=1, reset_local_crit_iter=-1, updated_max_iters=-1,
+                  non_symmetric=0, restart_iter=1):
     """Defaults follow benchmarking/bench_base.hpp:50-144 except
     enable_global_check (needed to ever stop)."""
     return Settings(max_iters, tol, overlap, local_solver, precond, local_tol,
                     local_max_iters, enable_global_check, enable_onesided,
                     global_check_iter_offset, natural_factor_ordering, num_threads, enable_overlap,
-                    use_mixed_precision, precond_block_size)
+                    use_mixed_precision, precond_block_size, reset_local_crit_iter, updated_max_iters,
+                    int(non_symmetric), restart_iter)
 
 
 class Result(C.Structure):
@@ -130,6 +136,8 @@ def lib():
     L.schwz_or_local_solve.restype = C.c_int
     L.schwz_or_local_solve.argtypes = [vp]
     L.schwz_or_restrict.argtypes = [vp]
+    L.schwz_or_state_set_local_max_iters.argtypes = [vp, C.c_int32]
+    L.schwz_or_state_set_local_max_iters.restype = None
     L.schwz_or_ras_run.restype = C.c_int
     L.schwz_or_ras_run.argtypes = [i64, vp, vp, vp, vp, C.c_int, vp, C.POINTER(Settings),
                                    vp, vp, vp, vp, C.POINTER(Result)]
@@ -140,6 +148,8 @@ def lib():
     L.schwz_or_pcg.argtypes = [i64, vp, vp, vp, vp, vp, C.c_int, C.c_double, C.c_int, vp]
     L.schwz_or_pcg_ex.restype = C.c_int
     L.schwz_or_pcg_ex.argtypes = [i64, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_double, C.c_int, vp]
+    L.schwz_or_gmres.restype = C.c_int
+    L.schwz_or_gmres.argtypes = [i64, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp]
     L.schwz_or_ilu0.argtypes = [i64, vp, vp, vp] + [C.POINTER(vp)] * 6
     L.schwz_or_cholesky.restype = C.c_int
     L.schwz_or_cholesky.argtypes = [i64, vp, vp, vp, C.c_int] + [C.POINTER(vp)] * 7
@@ -344,6 +354,9 @@ class State:
     def restrict(self):
         self._L.schwz_or_restrict(self.h)
 
+    def set_local_max_iters(self, max_iters):
+        self._L.schwz_or_state_set_local_max_iters(self.h, int(max_iters))
+
     def factors(self):
         ptrs = [C.c_void_p() for _ in range(7)]
         rc = self._L.schwz_or_state_factors(self.h, *[C.byref(p) for p in ptrs])
@@ -439,6 +452,18 @@ def pcg(rp, col, val, b, x0=None, precond=PRECOND_NONE, rtol=1e-12, max_iters=-1
         max_iters = n
     it = lib().schwz_or_pcg_ex(n, _p(rp), _p(col), _p(val), _p(b), _p(x), precond, block_size, rtol,
                                max_iters, C.byref(rn))
+    return x, it, rn.value
+
+
+def gmres(rp, col, val, b, x0=None, precond=PRECOND_NONE, rtol=1e-12, max_iters=-1, restart=1, block_size=1):
+    n = len(rp) - 1
+    x = np.zeros(n, dtype=np.float64) if x0 is None else np.array(x0, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    rn = C.c_double(0.0)
+    if max_iters < 0:
+        max_iters = n
+    it = lib().schwz_or_gmres(n, _p(rp), _p(col), _p(val), _p(b), _p(x), precond, block_size, restart, rtol,
+                              max_iters, C.byref(rn))
     return x, it, rn.value
 
 

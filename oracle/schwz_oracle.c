@@ -808,6 +808,108 @@ int schwz_or_pcg_ex(int64_t n, const or_idx *rp, const or_idx *col, const double
     return it;
 }
 
+/* Restarted GMRES(m) with right preconditioning, the non-symmetric local solver of
+ * solve.cpp:486-520 (gko::solver::Gmres with krylov_dim = settings.restart_iter and the same
+ * Combined(Iteration, ResidualNormReduction) criterion as the CG, solve.cpp:469-479).  Ginkgo's
+ * source is absent: restated from Saad & Schultz (1986) with modified Gram-Schmidt and Givens
+ * rotations; the correction of a cycle is M^-1 (V y).  The iteration count is the number of
+ * Krylov vectors built over all cycles; the stop test uses the rotated right-hand side |g_{j+1}|
+ * against rtol * ||b - A x_start||.  Returns the iterations done. */
+int schwz_or_gmres(int64_t n, const or_idx *rp, const or_idx *col, const double *val, const double *b,
+                   double *x, int precond, int block_size, int restart, double rtol, int max_iters,
+                   double *final_resnorm)
+{
+    const int m = restart < 1 ? 1 : restart;
+    const size_t nn = (size_t)(n ? n : 1);
+    double *V = (double *)xmalloc(sizeof(double) * nn * (size_t)(m + 1));
+    double *w = (double *)xmalloc(sizeof(double) * nn);
+    double *z = (double *)xmalloc(sizeof(double) * nn);
+    double *H = (double *)xcalloc((size_t)(m + 1) * (size_t)m, sizeof(double)); /* h(i,j) = H[i + j*(m+1)] */
+    double *cs = (double *)xcalloc((size_t)m, sizeof(double));
+    double *sn = (double *)xcalloc((size_t)m, sizeof(double));
+    double *g = (double *)xcalloc((size_t)m + 1, sizeof(double));
+    double *y = (double *)xcalloc((size_t)m, sizeof(double));
+    or_precond *M = precond_create(precond, block_size, n, rp, col, val);
+    int it = 0;
+    double r0 = -1.0, resn = 0.0;
+    for (;;) {
+        double *v0 = V;
+        memcpy(v0, b, sizeof(double) * (size_t)n);
+        schwz_or_spmv(n, rp, col, val, -1.0, x, 1.0, v0);
+        const double beta = sqrt(dot(n, v0, v0));
+        if (r0 < 0.0) r0 = beta;
+        resn = beta;
+        if (it >= max_iters || beta <= rtol * r0 || beta == 0.0) break;
+        for (int64_t i = 0; i < n; ++i) v0[i] /= beta;
+        memset(g, 0, sizeof(double) * ((size_t)m + 1));
+        g[0] = beta;
+        int k = 0;
+        for (int j = 0; j < m && it < max_iters; ++j) {
+            double *vj = V + (size_t)j * nn, *vn = V + (size_t)(j + 1) * nn;
+            double *h = H + (size_t)j * (size_t)(m + 1);
+            precond_apply(M, vj, z);
+            schwz_or_spmv(n, rp, col, val, 1.0, z, 0.0, w);
+            for (int i = 0; i <= j; ++i) {
+                const double *vi = V + (size_t)i * nn;
+                const double hij = dot(n, w, vi);
+                h[i] = hij;
+#pragma omp parallel for schedule(static) if (n > OMP_MIN_N)
+                for (int64_t q = 0; q < n; ++q) w[q] -= hij * vi[q];
+            }
+            const double hn = sqrt(dot(n, w, w));
+            h[j + 1] = hn;
+            for (int64_t q = 0; q < n; ++q) vn[q] = hn != 0.0 ? w[q] / hn : 0.0;
+            for (int i = 0; i < j; ++i) {
+                const double t = cs[i] * h[i] + sn[i] * h[i + 1];
+                h[i + 1] = -sn[i] * h[i] + cs[i] * h[i + 1];
+                h[i] = t;
+            }
+            if (h[j + 1] == 0.0) {
+                cs[j] = 1.0;
+                sn[j] = 0.0;
+            } else {
+                const double rr = hypot(h[j], h[j + 1]);
+                cs[j] = h[j] / rr;
+                sn[j] = h[j + 1] / rr;
+            }
+            h[j] = cs[j] * h[j] + sn[j] * h[j + 1];
+            h[j + 1] = 0.0;
+            g[j + 1] = -sn[j] * g[j];
+            g[j] = cs[j] * g[j];
+            ++it;
+            k = j + 1;
+            resn = fabs(g[j + 1]);
+            if (resn <= rtol * r0) break;
+        }
+        for (int i = k - 1; i >= 0; --i) { /* H(0:k,0:k) y = g(0:k) */
+            double sacc = g[i];
+            for (int q = i + 1; q < k; ++q) sacc -= H[i + (size_t)q * (size_t)(m + 1)] * y[q];
+            y[i] = sacc / H[i + (size_t)i * (size_t)(m + 1)];
+        }
+        memset(w, 0, sizeof(double) * (size_t)n);
+        for (int i = 0; i < k; ++i) {
+            const double *vi = V + (size_t)i * nn;
+            const double yi = y[i];
+#pragma omp parallel for schedule(static) if (n > OMP_MIN_N)
+            for (int64_t q = 0; q < n; ++q) w[q] += yi * vi[q];
+        }
+        precond_apply(M, w, z);
+        for (int64_t q = 0; q < n; ++q) x[q] += z[q];
+        if (resn <= rtol * r0 || it >= max_iters) break;
+    }
+    if (final_resnorm) *final_resnorm = resn;
+    free(V);
+    free(w);
+    free(z);
+    free(H);
+    free(cs);
+    free(sn);
+    free(g);
+    free(y);
+    precond_free(M);
+    return it;
+}
+
 int schwz_or_pcg(int64_t n, const or_idx *rp, const or_idx *col, const double *val, const double *b,
                  double *x, int precond, double rtol, int max_iters, double *final_resnorm)
 {
@@ -1207,12 +1309,20 @@ int schwz_or_local_solve(or_state *st)
     /* :721-781 : solver->apply(rhs=local_solution, x=init_guess) with the
      * warm start kept across outer iterations; local_solution <- init_guess */
     int maxit = st->s.local_max_iters == -1 ? (int)n : st->s.local_max_iters;
-    int it = schwz_or_pcg_ex(n, sd->l_rp, sd->l_col, sd->l_val, st->local_solution, st->init_guess,
+    int it;
+    if (st->s.non_symmetric) /* solve.cpp:486-520, 750-753 */
+        it = schwz_or_gmres(n, sd->l_rp, sd->l_col, sd->l_val, st->local_solution, st->init_guess, st->s.precond,
+                            st->s.precond_block_size, st->s.restart_iter, st->s.local_tol, maxit, NULL);
+    else
+        it = schwz_or_pcg_ex(n, sd->l_rp, sd->l_col, sd->l_val, st->local_solution, st->init_guess,
                              st->s.precond, st->s.precond_block_size, st->s.local_tol, maxit, NULL);
     memcpy(st->local_solution, st->init_guess, sizeof(double) * (size_t)n);
     st->last_inner = it;
     return it;
 }
+
+/* solve.cpp:723-742: the stopping criterion is rebuilt with a new iteration cap */
+void schwz_or_state_set_local_max_iters(or_state *st, int32_t max_iters) { st->s.local_max_iters = max_iters; }
 
 /* communicate.cpp:65-94 (solution_based branch, :91-93) */
 void schwz_or_restrict(or_state *st)
@@ -1339,6 +1449,8 @@ int schwz_or_ras_run(int64_t N, const or_idx *rp, const or_idx *col,
                 break;
             }
             for (int p = 0; p < P; ++p) {
+                if (s->reset_local_crit_iter != -1 && iter > s->reset_local_crit_iter)
+                    schwz_or_state_set_local_max_iters(st[p], s->updated_max_iters); /* solve.cpp:729-742 */
                 int it = schwz_or_local_solve(st[p]);
                 if (hist_inner) hist_inner[(size_t)iter * P + p] = it;
                 schwz_or_restrict(st[p]);
@@ -1402,6 +1514,8 @@ int schwz_or_ras_run(int64_t N, const or_idx *rp, const or_idx *col,
         if (num_converged == P) break;
         /* 3 local solve, 4 restrict */
         for (int p = 0; p < P; ++p) {
+            if (s->reset_local_crit_iter != -1 && iter > s->reset_local_crit_iter)
+                schwz_or_state_set_local_max_iters(st[p], s->updated_max_iters); /* solve.cpp:729-742 */
             int it = schwz_or_local_solve(st[p]);
             if (hist_inner) hist_inner[(size_t)iter * P + p] = it;
             schwz_or_restrict(st[p]);

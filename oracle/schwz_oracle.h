@@ -123,6 +123,13 @@ typedef struct {
      * on the wire (restricted_schwarz.cpp:898-903,952-954) */
     int32_t use_mixed_precision;
     int32_t precond_block_size; /* metadata.precond_max_block_size for OR_PRECOND_BLOCK_JACOBI */
+    /* two-stage local solves (solve.cpp:723-742): once iter_count > reset_local_crit_iter the
+     * inner iteration cap becomes updated_max_iters (-1 => local_size_x); -1 disables */
+    int32_t reset_local_crit_iter;
+    int32_t updated_max_iters;
+    /* settings.non_symmetric_matrix: GMRES(settings.restart_iter) instead of CG (solve.cpp:486-520) */
+    int32_t non_symmetric;
+    int32_t restart_iter;
 } or_settings;
 
 /* ---- per-subdomain state and the five loop steps (A.3) -------------------- */
@@ -152,6 +159,8 @@ double schwz_or_local_residual(or_state *st);
 int schwz_or_local_solve(or_state *st);
 /* step 4: communicate.cpp:65-94 */
 void schwz_or_restrict(or_state *st);
+/* the inner iteration cap of later local solves (solve.cpp:723-742 rebuilds the criterion) */
+void schwz_or_state_set_local_max_iters(or_state *st, int32_t max_iters);
 
 /* ---- whole run: all P subdomains in lockstep (schwarz_base.cpp:387-452) ---- */
 
@@ -193,6 +202,10 @@ int schwz_or_pcg(int64_t n, const or_idx *rp, const or_idx *col,
 int schwz_or_pcg_ex(int64_t n, const or_idx *rp, const or_idx *col, const double *val, const double *b,
                     double *x, int precond, int block_size, double rtol, int max_iters,
                     double *final_resnorm);
+/* restarted GMRES(restart), right preconditioned; same stop rule and return value as the CG */
+int schwz_or_gmres(int64_t n, const or_idx *rp, const or_idx *col, const double *val, const double *b,
+                   double *x, int precond, int block_size, int restart, double rtol, int max_iters,
+                   double *final_resnorm);
 void schwz_or_ilu0(int64_t n, const or_idx *rp, const or_idx *col, const double *val, or_idx **l_rp,
                    or_idx **l_col, double **l_val, or_idx **u_rp, or_idx **u_col, double **u_val);
 /* sparse LL^T of A(perm,perm); outputs malloc'd CSR L and U=L^T; perm is

@@ -1882,14 +1882,31 @@ void schwz_pcg_destroy(schwz_pcg *s)
 namespace schwz {
 
 // z = M^-1 r for the preconditioners that are operators of their own
-static int pcg_apply_general(schwz_pcg *s, hipStream_t st)
+__global__ __launch_bounds__(kBlock) void diag_scale_kernel(int64_t n, const double *__restrict__ dinv,
+                                                            const double *__restrict__ in, double *__restrict__ out)
 {
-    if (s->precond == SCHWZ_PRECOND_ILU) return schwz_trs_solve(s->ilu, s->r, s->z, (schwz_stream)st);
-    hipLaunchKernelGGL(block_jacobi_apply_kernel, dim3(grid_for(s->n)), dim3(kBlock), 0, st, s->n, s->block_size,
-                       s->d_blk_id, s->d_blk_inv, s->r, s->z);
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) out[i] = dinv[i] * in[i];
+}
+
+// out = M^-1 in for whichever preconditioner the object holds (in != out)
+int precond_apply(schwz_pcg *s, const double *in, double *out, hipStream_t st)
+{
+    if (s->n == 0) return SCHWZ_OK;
+    if (s->precond == SCHWZ_PRECOND_ILU) return schwz_trs_solve(s->ilu, in, out, (schwz_stream)st);
+    if (s->precond == SCHWZ_PRECOND_BLOCK_JACOBI) {
+        hipLaunchKernelGGL(block_jacobi_apply_kernel, dim3(grid_for(s->n)), dim3(kBlock), 0, st, s->n, s->block_size,
+                           s->d_blk_id, s->d_blk_inv, in, out);
+    } else if (s->precond == SCHWZ_PRECOND_JACOBI) {
+        hipLaunchKernelGGL(diag_scale_kernel, dim3(grid_for(s->n)), dim3(kBlock), 0, st, s->n, s->dinv, in, out);
+    } else {
+        hipLaunchKernelGGL(copy_kernel, dim3(grid_for(s->n)), dim3(kBlock), 0, st, s->n, in, out);
+    }
     SCHWZ_HIP_TRY(hipGetLastError());
     return SCHWZ_OK;
 }
+
+static int pcg_apply_general(schwz_pcg *s, hipStream_t st) { return precond_apply(s, s->r, s->z, st); }
 
 static bool pcg_is_general(const schwz_pcg *s)
 {

@@ -143,6 +143,7 @@ namespace schwz {
 int pcg_begin(schwz_pcg *s, const double *d_b, double *d_x, double rtol, bool fused, const double *d_x2,
               int64_t row_limit, hipStream_t st);
 int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream_t st);
+int precond_apply(schwz_pcg *s, const double *in, double *out, hipStream_t st);
 }  // namespace schwz
 
 // ---- opaque ABI types -------------------------------------------------------
@@ -241,6 +242,7 @@ struct schwz_subdomain {
     schwz_solver_options opt{};
     schwz_csr *A = nullptr;  // local_matrix
     schwz_pcg *cg = nullptr;
+    schwz_gmres *gmres = nullptr;  // non-symmetric local matrix
     schwz_trs *trs = nullptr;
     // interface rows: only overlap rows are non-empty; stored compactly
     schwz_idx *d_i_rp = nullptr, *d_i_col = nullptr;  // cols index x~ directly

@@ -49,6 +49,7 @@ void schwz_subdomain_destroy(schwz_subdomain *sd)
     if (!sd) return;
     if (sd->on_device) {
         schwz_pcg_destroy(sd->cg);
+        schwz_gmres_destroy(sd->gmres);
         schwz_trs_destroy(sd->trs);
         schwz_csr_destroy(sd->A);
         void *ptrs[] = {sd->d_i_rp, sd->d_i_col, sd->d_i_val, sd->d_put_idx, sd->d_get_idx, sd->d_x,
@@ -114,8 +115,15 @@ int schwz_subdomain_to_device(schwz_subdomain *sd, const double *h_local_rhs, co
     SCHWZ_HIP_TRY(hipEventCreateWithFlags(&sd->ev_scalar, hipEventDisableTiming));
     if (opt->local_solver == SCHWZ_SOLVER_ITERATIVE) {
         const int bsz = opt->precond_block_size < 1 ? 1 : opt->precond_block_size;
-        if ((rc = schwz_pcg_create_ex(sd->A, opt->precond, bsz, &sd->cg))) return rc;
-        sd->cg->variant = opt->spmv_variant;
+        if (opt->non_symmetric) {
+            // solve.cpp:486-520: GMRES(restart_iter); the preconditioner objects are the CG's
+            if ((rc = schwz_gmres_create(sd->A, opt->precond, bsz, opt->restart_iter < 1 ? 1 : opt->restart_iter,
+                                         &sd->gmres)))
+                return rc;
+        } else {
+            if ((rc = schwz_pcg_create_ex(sd->A, opt->precond, bsz, &sd->cg))) return rc;
+            sd->cg->variant = opt->spmv_variant;
+        }
     } else {
         // Solve::compute_local_factors + the Ginkgo TRS setup (solve.cpp:75-143,281-399)
         schwz_idx *l_rp, *l_col, *u_rp, *u_col, *perm;
@@ -245,6 +253,14 @@ int schwz_ras_true_residual_sq(schwz_subdomain *sd, double *h_out, schwz_stream 
     return SCHWZ_OK;
 }
 
+int schwz_ras_set_local_max_iters(schwz_subdomain *sd, int max_iters)
+{
+    SCHWZ_REQUIRE(sd && sd->on_device, "schwz_ras_set_local_max_iters: subdomain is not on the device");
+    SCHWZ_REQUIRE(max_iters >= -1, "schwz_ras_set_local_max_iters: max_iters must be -1 or >= 0");
+    sd->opt.local_max_iters = max_iters;
+    return SCHWZ_OK;
+}
+
 int schwz_ras_local_solve(schwz_subdomain *sd, int *h_inner_iters, schwz_stream stream)
 {
     REQUIRE_DEVICE(sd, "schwz_ras_local_solve");
@@ -254,6 +270,9 @@ int schwz_ras_local_solve(schwz_subdomain *sd, int *h_inner_iters, schwz_stream 
     }
     const int64_t n = sd->local_size_x;
     const int maxit = sd->opt.local_max_iters == -1 ? (int)n : sd->opt.local_max_iters;
+    if (sd->gmres)
+        return schwz_gmres_solve(sd->gmres, sd->d_btilde, sd->d_y, sd->opt.local_tol, maxit, h_inner_iters, nullptr,
+                                 stream);
     return schwz_pcg_solve(sd->cg, sd->d_btilde, sd->d_y, sd->opt.local_tol, maxit, h_inner_iters, nullptr,
                            stream);
 }
@@ -264,7 +283,7 @@ int schwz_ras_check_and_solve_launch(schwz_subdomain *sd, schwz_stream stream)
     hipStream_t st = (hipStream_t)stream;
     const int64_t n = sd->local_size_x;
     if (n == 0) return SCHWZ_OK;
-    if (sd->opt.local_solver != SCHWZ_SOLVER_ITERATIVE || (sd->opt.spmv_variant != 0 && sd->opt.spmv_variant != 4 && sd->opt.spmv_variant != 6 && sd->opt.spmv_variant != 7)) {
+    if (sd->opt.local_solver != SCHWZ_SOLVER_ITERATIVE || sd->gmres || (sd->opt.spmv_variant != 0 && sd->opt.spmv_variant != 4 && sd->opt.spmv_variant != 6 && sd->opt.spmv_variant != 7)) {
         // no fused kernel for this configuration: the two steps back to back
         int rc = schwz_ras_local_residual_launch(sd, stream);
         if (rc) return rc;

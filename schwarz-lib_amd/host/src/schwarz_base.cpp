@@ -134,7 +134,6 @@ void SchwarzBase<V, I, M>::initialize()
     const int me = m.my_rank;
 
     // ---- options the GPU path does not provide ------------------------------------------
-    if (s.non_symmetric_matrix) throw ::NotImplemented(__FILE__, __LINE__, "GMRES (non_symmetric_matrix)");
     schwz_solver_options opt{};
     switch (s.local_solver) {
     case Settings::local_solver_settings::iterative_solver_ginkgo:
@@ -160,6 +159,10 @@ void SchwarzBase<V, I, M>::initialize()
     }
     opt.local_tol = m.local_solver_tolerance;
     opt.local_max_iters = (int)m.local_max_iters;
+    opt.non_symmetric = s.non_symmetric_matrix ? 1 : 0;  // GMRES(restart_iter), solve.cpp:486-520
+    opt.restart_iter = (int)s.restart_iter;
+    if (s.non_symmetric_matrix && opt.local_solver != SCHWZ_SOLVER_ITERATIVE)
+        throw ::NotImplemented(__FILE__, __LINE__, "non_symmetric_matrix with a direct local solver (LL^T only)");
     opt.natural_factor_ordering = s.naturally_ordered_factor;
 
     // ---- Initialize::setup_global_matrix (initialization.cpp:197-272) ----------------------
@@ -375,9 +378,16 @@ void SchwarzBase<V, I, M>::run(std::shared_ptr<gko::matrix::Dense<V>> &solution)
     MPI_Barrier(MPI_COMM_WORLD);
     m.init_mpi_wtime = MPI_Wtime();
     const double start = now();
+    bool two_stage_on = false;
+    SCHWZ_CALL(schwz_ras_set_local_max_iters(im.sd, (int)m.local_max_iters));
     for (; m.iter_count < m.max_iters; ++m.iter_count) {
         const auto it = m.iter_count;
         const double t0 = now();
+        if (s.reset_local_crit_iter != -1 && it > s.reset_local_crit_iter && !two_stage_on) {
+            // solve.cpp:723-742: the local criterion is rebuilt with the second-stage iteration cap
+            SCHWZ_CALL(schwz_ras_set_local_max_iters(im.sd, (int)m.updated_max_iters));
+            two_stage_on = true;
+        }
         if (!(cs.enable_onesided && it == 0)) exchange();  // restricted_schwarz.cpp:725
         const double t1 = now();
         SCHWZ_CALL(schwz_ras_update_boundary(im.sd, im.stream));

@@ -30,6 +30,7 @@ SYMBOLS = [
     "schwz_gather", "schwz_scatter",
     "schwz_csr_create", "schwz_csr_destroy", "schwz_csr_nnz", "schwz_csr_format", "schwz_csr_spmv",
     "schwz_pcg_create", "schwz_pcg_create_ex", "schwz_pcg_destroy", "schwz_pcg_solve",
+    "schwz_gmres_create", "schwz_gmres_destroy", "schwz_gmres_solve",
     "schwz_profile_begin", "schwz_profile_end", "schwz_stream_probe",
     "schwz_trs_create", "schwz_trs_destroy", "schwz_trs_solve",
     "schwz_problem_laplacian", "schwz_problem_from_csr", "schwz_problem_from_matrix_market",
@@ -45,7 +46,8 @@ SYMBOLS = [
     "schwz_subdomain_to_device", "schwz_ras_pack", "schwz_ras_unpack", "schwz_ras_pack_f32",
     "schwz_ras_unpack_f32",
     "schwz_ras_update_boundary", "schwz_ras_local_residual", "schwz_ras_local_residual_launch",
-    "schwz_ras_local_residual_wait", "schwz_ras_local_solve", "schwz_ras_check_and_solve_launch",
+    "schwz_ras_local_residual_wait", "schwz_ras_local_solve", "schwz_ras_set_local_max_iters",
+    "schwz_ras_check_and_solve_launch",
     "schwz_ras_restrict", "schwz_ras_vector", "schwz_ras_local_csr", "schwz_ras_get_interior",
     "schwz_ras_true_residual_sq", "schwz_ras_algorithmic_bytes",
 ]
@@ -72,6 +74,8 @@ class SolverOptions(C.Structure):
         ("natural_factor_ordering", C.c_int32),
         ("spmv_variant", C.c_int32),
         ("precond_block_size", C.c_int32),
+        ("non_symmetric", C.c_int32),
+        ("restart_iter", C.c_int32),
     ]
 
 
@@ -106,6 +110,9 @@ _sig("schwz_csr_spmv", i32, [vp, dbl, vp, dbl, vp, i32, vp])
 _sig("schwz_pcg_create", i32, [vp, i32, pvp])
 _sig("schwz_pcg_create_ex", i32, [vp, i32, i32, pvp])
 _sig("schwz_pcg_destroy", None, [vp])
+_sig("schwz_gmres_create", i32, [vp, i32, i32, i32, pvp])
+_sig("schwz_gmres_destroy", None, [vp])
+_sig("schwz_gmres_solve", i32, [vp, vp, vp, dbl, i32, C.POINTER(C.c_int), C.POINTER(dbl), vp])
 _sig("schwz_pcg_solve", i32, [vp, vp, vp, dbl, i32, C.POINTER(C.c_int), C.POINTER(dbl), vp])
 _sig("schwz_profile_begin", i32, [i32])
 _sig("schwz_profile_end", i32, [C.POINTER(dbl), C.POINTER(i64)])
@@ -150,6 +157,7 @@ _sig("schwz_ras_local_residual_launch", i32, [vp, vp])
 _sig("schwz_ras_local_residual_wait", i32, [vp, C.POINTER(dbl)])
 _sig("schwz_ras_check_and_solve_launch", i32, [vp, vp])
 _sig("schwz_ras_local_solve", i32, [vp, C.POINTER(C.c_int), vp])
+_sig("schwz_ras_set_local_max_iters", i32, [vp, i32])
 _sig("schwz_ras_restrict", i32, [vp, vp])
 _sig("schwz_ras_vector", i32, [vp, i32, pvp, C.POINTER(i64)])
 _sig("schwz_ras_local_csr", i32, [vp, pvp])

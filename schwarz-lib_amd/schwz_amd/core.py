@@ -88,6 +88,33 @@ class Pcg:
         self.close()
 
 
+class Gmres:
+    """Device-resident restarted GMRES, right preconditioned (gko::solver::Gmres with
+    krylov_dim = restart; solve.cpp:486-520)."""
+
+    def __init__(self, csr, precond=capi.PRECOND_NONE, block_size=1, restart=1):
+        self.csr = csr
+        h = C.c_void_p()
+        check(lib.schwz_gmres_create(csr.h, precond, block_size, restart, C.byref(h)))
+        self.h = h
+
+    def solve(self, d_b, d_x, rtol, max_iters, stream=0, want_stats=True):
+        it = C.c_int(0)
+        rn = C.c_double(0.0)
+        check(lib.schwz_gmres_solve(self.h, ptr(d_b), ptr(d_x), rtol, max_iters,
+                                    C.byref(it) if want_stats else None,
+                                    C.byref(rn) if want_stats else None, _stream_arg(stream)))
+        return it.value, rn.value
+
+    def close(self):
+        if self.h and lib is not None:
+            lib.schwz_gmres_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
 class Trs:
     """y = P^T L^-T L^-1 P b (gko LowerTrs/UpperTrs + Permutation)."""
 
@@ -355,11 +382,13 @@ class Subdomain:
 
     def to_device(self, local_rhs, local_solver=capi.SOLVER_ITERATIVE,
                   precond=capi.PRECOND_NONE, local_tol=1e-12, local_max_iters=-1,
-                  natural_factor_ordering=False, spmv_variant=0, precond_block_size=1):
+                  natural_factor_ordering=False, spmv_variant=0, precond_block_size=1,
+                  non_symmetric=False, restart_iter=1):
         local_rhs = np.ascontiguousarray(local_rhs, dtype=np.float64)
         assert len(local_rhs) == self.local_size_x
         opt = capi.SolverOptions(local_solver, precond, local_tol, local_max_iters,
-                                 int(natural_factor_ordering), spmv_variant, int(precond_block_size))
+                                 int(natural_factor_ordering), spmv_variant, int(precond_block_size),
+                                 int(bool(non_symmetric)), int(restart_iter))
         check(lib.schwz_subdomain_to_device(self.h, ptr(local_rhs), C.byref(opt)))
         self.on_device = True
 
@@ -393,6 +422,10 @@ class Subdomain:
         out = C.c_double(0.0)
         check(lib.schwz_ras_local_residual_wait(self.h, C.byref(out)))
         return out.value
+
+    def set_local_max_iters(self, max_iters):
+        """Inner iteration cap of later local solves (two-stage criterion, solve.cpp:723-742)."""
+        check(lib.schwz_ras_set_local_max_iters(self.h, int(max_iters)))
 
     def local_solve(self, stream=0, want_iters=False):
         it = C.c_int(0)

@@ -292,9 +292,10 @@ class SolverRAS:
         s, m, be, comm = self.settings, self.metadata, self.backend, self.comm
         solver_code = _local_solver_code(s)
         precond_code = _precond_code(m)
-        if s.non_symmetric_matrix:
+        if s.non_symmetric_matrix and solver_code != capi.SOLVER_ITERATIVE:
             raise capi.NotImplementedSchwz(capi.ERR_NOT_IMPLEMENTED,
-                                           "GMRES (non_symmetric_matrix) is not implemented")
+                                           "non_symmetric_matrix needs the iterative local solver (GMRES); "
+                                           "the direct path is an LL^T factorization")
         prob = self._setup_global_matrix()
         prob = self._partition(prob)
         self.problem = prob
@@ -310,7 +311,8 @@ class SolverRAS:
             sd.to_device(sd.local_rhs(self._rhs), local_solver=solver_code, precond=precond_code,
                          local_tol=m.local_solver_tolerance, local_max_iters=m.local_max_iters,
                          natural_factor_ordering=s.naturally_ordered_factor,
-                         spmv_variant=s.spmv_variant, precond_block_size=m.precond_max_block_size)
+                         spmv_variant=s.spmv_variant, precond_block_size=m.precond_max_block_size,
+                         non_symmetric=s.non_symmetric_matrix, restart_iter=s.restart_iter)
             # use_mixed_precision (MixedValueType = float): halos travel as fp32
             self.send_buf[me] = be.empty(sd.num_send, s.use_mixed_precision)
             self.recv_buf[me] = be.empty(sd.num_recv, s.use_mixed_precision)
@@ -339,6 +341,16 @@ class SolverRAS:
             self._print(" Local direct solve with HIP TRS")
 
     # -------------------------------------------------------------------- run
+    def _two_stage(self):
+        """solve.cpp:723-742: once iter_count > reset_local_crit_iter the local stopping
+        criterion is rebuilt with updated_max_iters (-1: local_size_x) as its iteration cap."""
+        s, m = self.settings, self.metadata
+        if (s.reset_local_crit_iter != -1 and m.iter_count > s.reset_local_crit_iter
+                and not self._two_stage_on):
+            for _, sd in self.subdomains.items():
+                sd.set_local_max_iters(m.updated_max_iters)
+            self._two_stage_on = True
+
     def _pack(self, me, sd, stream):
         if self.settings.use_mixed_precision:
             sd.pack_f32(self.send_buf[me].data_ptr(), stream)
@@ -375,6 +387,10 @@ class SolverRAS:
         self._mask = {me: 0 for me in self.subdomains}
         self._stop = {me: NEVER for me in self.subdomains}
         self._pending = None
+        if getattr(self, "_two_stage_on", False):  # a re-run starts with the first-stage cap again
+            for _, sd in self.subdomains.items():
+                sd.set_local_max_iters(m.local_max_iters)
+        self._two_stage_on = False
         ppd = m.post_process_data
         for k in ppd:
             ppd[k] = []
@@ -392,6 +408,7 @@ class SolverRAS:
         conv_tools.hpp:213-275 on matched messages; the first subdomain that sees the full mask
         at iteration k proposes stop = k + P, the minimum wins, and everybody stops together."""
         s, m, be, comm = self.settings, self.metadata, self.backend, self.comm
+        self._two_stage()
         P = m.num_subdomains
         locals_ = list(self.subdomains.items())
         ppd = m.post_process_data
@@ -472,6 +489,7 @@ class SolverRAS:
         cs, cv = s.comm_settings, s.convergence_settings
         if cs.enable_onesided and cs.enable_overlap:
             return self._step_overlapped()
+        self._two_stage()
         P = m.num_subdomains
         locals_ = list(self.subdomains.items())
         ppd = m.post_process_data

@@ -49,3 +49,22 @@ def torch_cuda():
     assert torch.cuda.is_available()
     torch.cuda.set_device(0)
     return torch
+
+
+def convection_diffusion_2d(n, cx=6.0, cy=-3.0):
+    """Non-symmetric test matrix: 5-point diffusion plus first-order upwind convection on an
+    n x n grid (natural ordering).  Returns int32 CSR arrays with sorted columns."""
+    import numpy as np
+    import scipy.sparse as sp
+    eye = sp.identity(n, format="csr")
+    t = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(n, n), format="csr")
+    d = sp.diags([-1.0, 1.0], [-1, 0], shape=(n, n), format="csr")
+    a = (sp.kron(eye, t) + sp.kron(t, eye) + 0.5 * cx * sp.kron(eye, d) - 0.5 * cy * sp.kron(d.T, eye)).tocsr()
+    a.eliminate_zeros()
+    a.sort_indices()
+    return a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data.astype(np.float64)
+
+
+@pytest.fixture(scope="session")
+def convdiff():
+    return convection_diffusion_2d

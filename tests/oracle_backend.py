@@ -74,7 +74,8 @@ class OracleSubdomain:
         return np.ascontiguousarray(rhs_fn(self.local_to_global[:self.local_size_x]))
 
     def to_device(self, local_rhs, local_solver=0, precond=0, local_tol=1e-12, local_max_iters=-1,
-                  natural_factor_ordering=False, spmv_variant=0, precond_block_size=1):
+                  natural_factor_ordering=False, spmv_variant=0, precond_block_size=1, non_symmetric=False,
+                  restart_iter=1):
         # the oracle state extracts the local rhs from a global vector: rebuild the entries it
         # will read
         rhs = np.zeros(self.sd.N)
@@ -83,7 +84,8 @@ class OracleSubdomain:
         s = O.make_settings(overlap=self.overlap, local_solver=local_solver, precond=precond,
                             local_tol=local_tol, local_max_iters=local_max_iters,
                             natural_factor_ordering=int(natural_factor_ordering),
-                            precond_block_size=int(precond_block_size))
+                            precond_block_size=int(precond_block_size), non_symmetric=int(bool(non_symmetric)),
+                            restart_iter=int(restart_iter))
         self._settings = s
         self.state = O.State(self.sd, rhs, s)
 
@@ -104,6 +106,9 @@ class OracleSubdomain:
 
     def local_residual(self, stream=0):
         return self.state.local_residual()
+
+    def set_local_max_iters(self, max_iters):
+        self.state.set_local_max_iters(max_iters)
 
     def local_solve(self, stream=0, want_iters=False):
         return self.state.local_solve()

@@ -91,6 +91,11 @@ CASES = {
         world=3, settings=dict(),
         metadata=dict(oned_laplacian_size=18, tolerance=1e-8, max_iters=300,
                       local_precond="block-jacobi", precond_max_block_size=8)),
+    "lap2d_two_stage": dict(
+        world=2, settings=dict(reset_local_crit_iter=3),
+        metadata=dict(oned_laplacian_size=18, tolerance=1e-8, max_iters=300, local_precond="block-jacobi",
+                      precond_max_block_size=1, local_solver_tolerance=1e-10, local_max_iters=2,
+                      updated_max_iters=40)),
     "lap2d_direct_overlap3": dict(
         world=2, settings=dict(local_solver="direct-ginkgo", overlap=3),
         metadata=dict(oned_laplacian_size=16, tolerance=1e-9, max_iters=300)),
@@ -125,7 +130,8 @@ def test_distributed_run_reproduces_lockstep_oracle(oracle, name, tmp_path):
         precond=oracle.precond_code(md.get("local_precond"), md.get("precond_max_block_size", 1))[0],
         precond_block_size=oracle.precond_code(md.get("local_precond"), md.get("precond_max_block_size", 1))[1],
         local_tol=md.get("local_solver_tolerance", 1e-12), local_max_iters=md.get("local_max_iters", -1),
-        enable_onesided=int(bool(case.get("onesided"))), enable_overlap=int(bool(case.get("overlap"))))
+        enable_onesided=int(bool(case.get("onesided"))), enable_overlap=int(bool(case.get("overlap"))),
+        reset_local_crit_iter=st.get("reset_local_crit_iter", -1), updated_max_iters=md.get("updated_max_iters", -1))
     fr = oracle.first_rows_regular(N, world)
     assert np.array_equal(got["first_row"], fr)
     ref = oracle.ras_run(rp, col, val, np.ones(N), world, fr, s)

@@ -73,3 +73,41 @@ def test_bench_ras_refuses_cpu_executors():
     p = subprocess.run([MPIEXEC, "-n", "1", BIN, "--executor=reference", "--explicit_laplacian"],
                        capture_output=True, text=True, timeout=120)
     assert "is not implemented" in p.stderr + p.stdout
+
+
+def test_bench_ras_preconditioner_flags(oracle):
+    """--local_precond=ilu and block-jacobi with --precond_max_block_size through the unchanged
+    driver: same outer iteration counts as the oracle."""
+    n = 30
+    rp, col, val = oracle.laplacian2d(n)
+    N = n * n
+    for flags, (pc, bs) in ((("--local_precond=ilu",), (3, 1)),
+                            (("--local_precond=block-jacobi", "--precond_max_block_size=8"), (2, 8))):
+        out = _run(2, "--explicit_laplacian", "--set_1d_laplacian_size=%d" % n, "--enable_global_check",
+                   "--num_iters=500", "--set_tol=1e-8", *flags)
+        iters = set(int(x) for x in re.findall(r"converged in (\d+) iterations", out))
+        ref = oracle.ras_run(rp, col, val, np.ones(N), 2, oracle.first_rows_regular(N, 2),
+                             oracle.make_settings(max_iters=500, tol=1e-8, precond=pc, precond_block_size=bs))
+        assert ref["converged"] and iters == {ref["iter_count"]}, out
+
+
+def test_bench_ras_non_symmetric_gmres(oracle, convdiff, tmp_path):
+    """--non_symmetric_matrix --restart_iter=m on a Matrix-Market input (bench_ras.cpp:115-116)."""
+    rp, col, val = convdiff(26)
+    N = len(rp) - 1
+    path = str(tmp_path / "cd.mtx")
+    rows = np.repeat(np.arange(N), np.diff(rp))
+    with open(path, "w") as f:
+        f.write("%%%%MatrixMarket matrix coordinate real general\n%d %d %d\n" % (N, N, rp[-1]))
+        for r, c, v in zip(rows, col, val):
+            f.write("%d %d %.17g\n" % (r + 1, c + 1, v))
+    out = _run(2, "--matrix_filename=%s" % path, "--enable_global_check", "--num_iters=500", "--set_tol=1e-8",
+               "--non_symmetric_matrix", "--restart_iter=12", "--local_precond=block-jacobi",
+               "--precond_max_block_size=1", "--local_tol=1e-11", "--local_max_iters=500")
+    iters = sorted(set(int(x) for x in re.findall(r"converged in (\d+) iterations", out)))
+    ref = oracle.ras_run(rp, col, val, np.ones(N), 2, oracle.first_rows_regular(N, 2),
+                         oracle.make_settings(max_iters=500, tol=1e-8, precond=1, local_tol=1e-11,
+                                              local_max_iters=500, non_symmetric=1, restart_iter=12))
+    assert ref["converged"] and len(iters) == 1 and abs(iters[0] - ref["iter_count"]) <= 1, out
+    rel = float(re.search(r"relative residual norm of solution ([0-9.eE+-]+)", out).group(1))
+    assert rel <= 1e-6

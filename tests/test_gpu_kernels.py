@@ -222,6 +222,41 @@ def test_pcg_block_jacobi_and_ilu_match_oracle(schwz, oracle, torch_cuda, case, 
     assert np.abs(d_x.cpu().numpy() - exp).max() <= 1e-7 * np.abs(exp).max()
 
 
+@pytest.mark.parametrize("pc", [(0, 1), (1, 1), (2, 8), (3, 1)])
+@pytest.mark.parametrize("restart", [1, 4, 30])
+def test_gmres_matches_oracle(schwz, oracle, torch_cuda, convdiff, restart, pc):
+    """Device-resident GMRES(restart), right preconditioned (solve.cpp:486-520), against the
+    oracle's restatement on a non-symmetric convection-diffusion matrix: fixed numbers of Krylov
+    vectors (rtol = 0) give the same iterate, a tolerance stop the same count."""
+    torch = torch_cuda
+    precond, bs = pc
+    rp, col, val = convdiff(40)
+    n = len(rp) - 1
+    rng = np.random.default_rng(29)
+    b = rng.standard_normal(n)
+    x0 = rng.standard_normal(n) * 0.1
+    A = schwz.Csr(rp, col, val)
+    gm = schwz.Gmres(A, precond, bs, restart)
+    for iters in (1, 5, 23):
+        exp, it_o, rn_o = oracle.gmres(rp, col, val, b, x0, precond, 0.0, iters, restart, bs)
+        d_b, d_x = _dev(torch, b), _dev(torch, x0)
+        it_g, rn_g = gm.solve(d_b.data_ptr(), d_x.data_ptr(), 0.0, iters)
+        got = d_x.cpu().numpy()
+        assert it_g == it_o == iters
+        assert np.abs(got - exp).max() <= 1e-9 * np.abs(exp).max()
+        assert abs(rn_g - rn_o) <= 1e-8 * rn_o
+    exp, it_o, rn_o = oracle.gmres(rp, col, val, b, None, precond, 1e-9, 4000, restart, bs)
+    d_b, d_x = _dev(torch, b), torch.zeros(n, dtype=torch.float64, device="cuda")
+    it_g, rn_g = gm.solve(d_b.data_ptr(), d_x.data_ptr(), 1e-9, 4000)
+    assert abs(it_g - it_o) <= max(1, restart // 8), (it_g, it_o)
+    assert np.abs(d_x.cpu().numpy() - exp).max() <= 1e-6 * np.abs(exp).max()
+    # zero right-hand side: no iteration, x untouched
+    d_b = torch.zeros(n, dtype=torch.float64, device="cuda")
+    d_x = torch.zeros(n, dtype=torch.float64, device="cuda")
+    it_g, rn_g = gm.solve(d_b.data_ptr(), d_x.data_ptr(), 1e-9, 50)
+    assert it_g == 0 and rn_g == 0.0 and not d_x.cpu().numpy().any()
+
+
 @pytest.mark.parametrize("kind", ["ilu_noperm", "chol_perm"])
 def test_triangular_solves_multi_launch_plan(schwz, oracle, torch_cuda, kind):
     """n > 8192 rows: the level schedule runs as wide/narrow segment launches instead of the

@@ -34,7 +34,9 @@ def _oracle_settings(oracle, m, s, **kw):
         enable_onesided=int(s.comm_settings.enable_onesided),
         enable_overlap=int(s.comm_settings.enable_overlap),
         use_mixed_precision=int(s.use_mixed_precision),
-        natural_factor_ordering=int(s.naturally_ordered_factor), **kw)
+        natural_factor_ordering=int(s.naturally_ordered_factor),
+        reset_local_crit_iter=s.reset_local_crit_iter, updated_max_iters=m.updated_max_iters,
+        non_symmetric=int(s.non_symmetric_matrix), restart_iter=s.restart_iter, **kw)
 
 
 def _check_against_oracle(oracle, csr, P, solver, m, out, x_ref=None, exact_iters=True,
@@ -108,6 +110,24 @@ def test_ras_block_jacobi_and_ilu_match_oracle(schwz, oracle, torch_cuda, P, pre
     _check_against_oracle(oracle, oracle.laplacian3d(*shape), P, solver, m, out)
 
 
+def test_two_stage_local_criterion_matches_oracle(schwz, oracle, torch_cuda):
+    """--reset_local_crit_iter / --updated_max_iters (solve.cpp:723-742): a cheap first stage
+    (3 CG iterations per local solve) switches to converged local solves after outer iteration 4.
+    The inner iteration counts must show the switch and the run must match the oracle."""
+    n, P = 28, 3
+    solver, m, out = _run_gpu(
+        schwz, P, dict(reset_local_crit_iter=4),
+        dict(oned_laplacian_size=n, tolerance=1e-8, max_iters=300, local_precond="block-jacobi",
+             precond_max_block_size=1, local_solver_tolerance=1e-10, local_max_iters=3,
+             updated_max_iters=-1))
+    _check_against_oracle(oracle, oracle.laplacian2d(n), P, solver, m, out)
+    one_stage, _, out1 = _run_gpu(
+        schwz, P, dict(),
+        dict(oned_laplacian_size=n, tolerance=1e-8, max_iters=300, local_precond="block-jacobi",
+             precond_max_block_size=1, local_solver_tolerance=1e-10, local_max_iters=3))
+    assert out["converged"] and out["iter_count"] < out1["iter_count"]
+
+
 @pytest.mark.parametrize("P", [2, 8])
 def test_ras_3d_fixed_inner_work_matches_oracle(schwz, oracle, torch_cuda, P):
     """The bench operating point: CG + scalar Jacobi, K inner iterations, local_tol=0."""
@@ -155,6 +175,27 @@ def _write_mtx(tmp_path, g):
         for r, c, v in zip(rows, g["col"], g["val"]):
             f.write("%d %d %.17g\n" % (r + 1, c + 1, v))
     return path
+
+
+@pytest.mark.parametrize("P", [1, 4])
+@pytest.mark.parametrize("cfg", [("null", 1, 1), ("block-jacobi", 1, 10), ("block-jacobi", 8, 10), ("ilu", 1, 25)])
+def test_ras_non_symmetric_gmres_matches_oracle(schwz, oracle, torch_cuda, convdiff, tmp_path, P, cfg):
+    """--non_symmetric_matrix --restart_iter=m: GMRES(m) local solves (solve.cpp:486-520) on a
+    convection-diffusion matrix read from a Matrix-Market file, against the oracle and scipy."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as sl
+    precond, bs, restart = cfg
+    rp, col, val = convdiff(30)
+    n = len(rp) - 1
+    path = _write_mtx(tmp_path, dict(rp=rp, col=col, val=val))
+    solver, m, out = _run_gpu(
+        schwz, P, dict(matrix_filename=path, explicit_laplacian=False, non_symmetric_matrix=True,
+                       restart_iter=restart),
+        dict(tolerance=1e-8, max_iters=400, local_precond=precond, precond_max_block_size=bs,
+             local_solver_tolerance=1e-11, local_max_iters=600))
+    x_ref = sl.spsolve(sp.csr_matrix((val, col, rp), shape=(n, n)).tocsc(), np.ones(n))
+    _check_against_oracle(oracle, (rp, col, val), P, solver, m, out, x_ref=x_ref, exact_iters=False)
+    assert out["converged"]
 
 
 def test_ras_ani4_graph_partition(schwz, oracle, torch_cuda, tmp_path):

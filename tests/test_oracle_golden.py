@@ -228,3 +228,69 @@ def test_random_rhs_is_the_libstdcxx_sequence(oracle, schwz):
     ids = np.array([123456, 0, 7, 1000, 5, 99999], dtype=np.int64)
     assert np.array_equal(schwz.rhs_random(ids), r[ids])
     assert np.array_equal(schwz.rhs_random(np.arange(4096)), r[:4096])
+
+
+def test_two_stage_local_criterion(oracle):
+    """solve.cpp:723-742: after outer iteration `reset_local_crit_iter` the inner cap changes;
+    the inner iteration history shows it and the run still reaches the scipy solution."""
+    n = 24
+    rp, col, val = oracle.laplacian2d(n)
+    N = n * n
+    fr = oracle.first_rows_regular(N, 2)
+    s = oracle.make_settings(max_iters=300, tol=1e-9, precond=1, local_tol=1e-12, local_max_iters=2,
+                             reset_local_crit_iter=5, updated_max_iters=-1)
+    r = oracle.ras_run(rp, col, val, np.ones(N), 2, fr, s)
+    inner = r["hist_inner"]
+    assert r["converged"]
+    assert (inner[:6] == 2).all() and (inner[6:r["iter_count"]] > 2).all()
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as sl
+    x = sl.spsolve(sp.csr_matrix((val, col, rp), shape=(N, N)).tocsc(), np.ones(N))
+    assert np.abs(r["solution"] - x).max() <= 1e-6 * np.abs(x).max()
+
+
+@pytest.mark.parametrize("restart", [1, 5, 30, 100])
+def test_gmres_reproduces_scipy_iteration_for_iteration(oracle, convdiff, restart):
+    """The oracle's GMRES(m) (the non-symmetric local solver, solve.cpp:486-520) against an
+    independent implementation: scipy's restarted GMRES needs exactly the same number of inner
+    iterations for the same reduction and returns the same solution."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as sl
+    rp, col, val = convdiff(24)
+    n = len(rp) - 1
+    A = sp.csr_matrix((val, col, rp), shape=(n, n))
+    assert abs(A - A.T).max() > 1.0
+    b = np.ones(n)
+    count = [0]
+
+    def cb(_):
+        count[0] += 1
+
+    xs, info = sl.gmres(A, b, restart=restart, rtol=1e-10, atol=0.0, maxiter=5000, callback=cb,
+                        callback_type="pr_norm")
+    x, it, rn = oracle.gmres(rp, col, val, b, None, 0, 1e-10, 5000, restart)
+    assert info == 0 and it == count[0]
+    assert np.abs(x - xs).max() <= 1e-11 * np.abs(xs).max()
+    assert abs(np.linalg.norm(b - A @ x) - rn) <= 1e-6 * rn + 1e-13
+
+
+def test_gmres_preconditioners_and_iteration_cap(oracle, convdiff):
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as sl
+    rp, col, val = convdiff(20)
+    n = len(rp) - 1
+    A = sp.csr_matrix((val, col, rp), shape=(n, n))
+    b = np.linspace(1.0, 2.0, n)
+    xr = sl.spsolve(A.tocsc(), b)
+    _, it_plain, _ = oracle.gmres(rp, col, val, b, None, 0, 1e-10, 5000, 20)
+    for precond, bs in ((1, 1), (2, 8), (3, 1)):
+        x, it, rn = oracle.gmres(rp, col, val, b, None, precond, 1e-10, 5000, 20, bs)
+        assert np.abs(x - xr).max() <= 1e-8 * np.abs(xr).max()
+        assert precond == 1 or it < it_plain
+    # the cap counts Krylov vectors over all cycles; a warm start is honoured
+    x7, it7, _ = oracle.gmres(rp, col, val, b, None, 0, 0.0, 7, 3)
+    assert it7 == 7
+    x14, it14, _ = oracle.gmres(rp, col, val, b, x7, 0, 0.0, 7, 3)
+    assert it14 == 7 and np.linalg.norm(b - A @ x14) < np.linalg.norm(b - A @ x7)
+    x0, it0, rn0 = oracle.gmres(rp, col, val, np.zeros(n), None, 0, 1e-8, 50, 5)
+    assert it0 == 0 and rn0 == 0.0 and not x0.any()
