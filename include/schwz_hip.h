@@ -53,12 +53,13 @@ enum schwz_op { SCHWZ_OP_ADD = 0, SCHWZ_OP_COPY = 1, SCHWZ_OP_DIFF = 2, SCHWZ_OP
 enum schwz_local_solver { SCHWZ_SOLVER_ITERATIVE = 0, SCHWZ_SOLVER_DIRECT = 1 };
 /* metadata.local_precond (source/solve.cpp:486-652): "null", "block-jacobi"
  * (gko::preconditioner::Jacobi, :490-505,575-589) and "ilu" (ParIlu + LowerTrs/UpperTrs,
- * :506-532,590-615); "isai" is not provided */
+ * :506-532,590-615) and "isai" (Ilu<LowerIsai, UpperIsai>, :616-638) */
 enum schwz_precond {
     SCHWZ_PRECOND_NONE = 0,
     SCHWZ_PRECOND_JACOBI = 1,       /* block-jacobi, precond_max_block_size = 1 */
     SCHWZ_PRECOND_BLOCK_JACOBI = 2, /* block-jacobi, consecutive blocks of precond_max_block_size rows */
-    SCHWZ_PRECOND_ILU = 3           /* ilu: ILU(0) + lower/upper triangular sweeps per iteration */
+    SCHWZ_PRECOND_ILU = 3,          /* ilu: ILU(0) + lower/upper triangular sweeps per iteration */
+    SCHWZ_PRECOND_ISAI = 4          /* isai: ILU(0) factors replaced by their ISAIs, two SpMVs per application */
 };
 
 const char *schwz_last_error(void);
@@ -265,6 +266,12 @@ int schwz_cholesky(int64_t n, const schwz_idx *h_rp, const schwz_idx *h_col,
 int schwz_ilu0(int64_t n, const schwz_idx *h_rp, const schwz_idx *h_col, const double *h_val,
                schwz_idx **l_rp, schwz_idx **l_col, double **l_val, schwz_idx **u_rp,
                schwz_idx **u_col, double **u_val);
+/* Incomplete sparse approximate inverse of a triangular CSR factor on the factor's own pattern:
+ * row i of W solves W(i,S) T(S,S) = e_i(S), S = pattern of row i of T.  Replaces
+ * gko::preconditioner::LowerIsai / UpperIsai with sparsity power 1 (source/solve.cpp:616-638).
+ * *w_val (nnz(T) values on T's pattern) is malloc'd; free with schwz_free. */
+int schwz_isai(int64_t n, const schwz_idx *h_rp, const schwz_idx *h_col, const double *h_val, int lower,
+               double **w_val);
 void schwz_free(void *p);
 
 /* ------------------------------------------------------------------------ */

@@ -151,6 +151,8 @@ def lib():
     L.schwz_or_gmres.restype = C.c_int
     L.schwz_or_gmres.argtypes = [i64, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp]
     L.schwz_or_ilu0.argtypes = [i64, vp, vp, vp] + [C.POINTER(vp)] * 6
+    L.schwz_or_isai.argtypes = [i64, vp, vp, vp, C.c_int, C.POINTER(vp)]
+    L.schwz_or_isai.restype = None
     L.schwz_or_cholesky.restype = C.c_int
     L.schwz_or_cholesky.argtypes = [i64, vp, vp, vp, C.c_int] + [C.POINTER(vp)] * 7
     L.schwz_or_direct_solve.argtypes = [i64] + [vp] * 10
@@ -440,6 +442,8 @@ def precond_code(local_precond, block_size=1):
         return (1, 1) if int(block_size) == 1 else (2, int(block_size))
     if local_precond == "ilu":
         return 3, 1
+    if local_precond == "isai":
+        return 4, 1
     return 0, 1
 
 
@@ -480,6 +484,16 @@ def ilu0(rp, col, val):
                u_val=_np_from(C.cast(ptrs[5], c_dbl_p), int(u_rp[-1]), np.float64))
     for p in ptrs:
         L.schwz_or_free(p)
+    return out
+
+
+def isai(rp, col, val, lower):
+    L = lib()
+    n = len(rp) - 1
+    p = C.c_void_p()
+    L.schwz_or_isai(n, _p(rp), _p(col), _p(val), int(bool(lower)), C.byref(p))
+    out = _np_from(C.cast(p, c_dbl_p), int(rp[-1]), np.float64)
+    L.schwz_or_free(p)
     return out
 
 

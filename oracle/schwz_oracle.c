@@ -564,6 +564,7 @@ typedef struct {
     double *binv;     /* [nblocks][bs][bs], identity padded */
     or_idx *l_rp, *l_col, *u_rp, *u_col; /* ILU(0): L unit lower with the 1 stored LAST in each */
     double *l_val, *u_val;               /* row, U upper with its diagonal FIRST */
+    double *wl_val, *wu_val; /* ISAI: approximate inverses of L and U on the patterns of L and U */
     double *tmp;
 } or_precond;
 
@@ -690,6 +691,47 @@ static void build_ilu0(or_precond *M, const or_idx *rp, const or_idx *col, const
     free(pos);
 }
 
+/* entry (r, c) of a CSR matrix with sorted columns, 0 when absent */
+static double csr_entry(const or_idx *rp, const or_idx *col, const double *val, or_idx r, or_idx c)
+{
+    or_idx lo = rp[r], hi = rp[r + 1] - 1;
+    while (lo <= hi) {
+        const or_idx mid = (lo + hi) / 2;
+        if (col[mid] == c) return val[mid];
+        if (col[mid] < c) lo = mid + 1;
+        else hi = mid - 1;
+    }
+    return 0.0;
+}
+
+/* Incomplete sparse approximate inverse of a triangular factor T on T's own pattern
+ * (gko::preconditioner::LowerIsai / UpperIsai with sparsity power 1, solve.cpp:616-638;
+ * Anzt, Huckle, Braeckle, Dongarra 2018): row i of W solves  W(i,S) T(S,S) = e_i(S)  with
+ * S = pattern of row i of T.  T(S,S) is triangular, so each row is one small substitution. */
+static double *build_isai(int64_t n, const or_idx *rp, const or_idx *col, const double *val, int lower)
+{
+    double *w = (double *)xmalloc(sizeof(double) * (size_t)(rp[n] ? rp[n] : 1));
+    for (int64_t i = 0; i < n; ++i) {
+        const or_idx s0 = rp[i], k = rp[i + 1] - rp[i];
+        const or_idx *S = col + s0;
+        double *wi = w + s0;
+        if (lower) { /* i is the last index of S: columns from last to first */
+            for (or_idx j = k - 1; j >= 0; --j) {
+                double acc = (S[j] == (or_idx)i) ? 1.0 : 0.0;
+                for (or_idx a = j + 1; a < k; ++a) acc -= wi[a] * csr_entry(rp, col, val, S[a], S[j]);
+                wi[j] = acc / csr_entry(rp, col, val, S[j], S[j]);
+            }
+        } else { /* i is the first index of S */
+            for (or_idx j = 0; j < k; ++j) {
+                double acc = (S[j] == (or_idx)i) ? 1.0 : 0.0;
+                for (or_idx a = 0; a < j; ++a) acc -= wi[a] * csr_entry(rp, col, val, S[a], S[j]);
+                wi[j] = acc / csr_entry(rp, col, val, S[j], S[j]);
+            }
+        }
+    }
+    return w;
+}
+
 static or_precond *precond_create(int kind, int bs, int64_t n, const or_idx *rp, const or_idx *col,
                                   const double *val)
 {
@@ -708,9 +750,13 @@ static or_precond *precond_create(int kind, int bs, int64_t n, const or_idx *rp,
         }
     } else if (kind == OR_PRECOND_BLOCK_JACOBI) {
         build_block_jacobi(M, rp, col, val);
-    } else if (kind == OR_PRECOND_ILU) {
+    } else if (kind == OR_PRECOND_ILU || kind == OR_PRECOND_ISAI) {
         build_ilu0(M, rp, col, val);
         M->tmp = (double *)xmalloc(sizeof(double) * (size_t)(n ? n : 1));
+        if (kind == OR_PRECOND_ISAI) {
+            M->wl_val = build_isai(n, M->l_rp, M->l_col, M->l_val, 1);
+            M->wu_val = build_isai(n, M->u_rp, M->u_col, M->u_val, 0);
+        }
     }
     return M;
 }
@@ -726,6 +772,8 @@ static void precond_free(or_precond *M)
     free(M->u_rp);
     free(M->u_col);
     free(M->u_val);
+    free(M->wl_val);
+    free(M->wu_val);
     free(M->tmp);
     free(M);
 }
@@ -758,6 +806,9 @@ static void precond_apply(const or_precond *M, const double *r, double *z)
             for (or_idx j = M->u_rp[i] + 1; j < M->u_rp[i + 1]; ++j) s -= M->u_val[j] * z[M->u_col[j]];
             z[i] = s / M->u_val[M->u_rp[i]];
         }
+    } else if (M->kind == OR_PRECOND_ISAI) { /* z = W_U (W_L r): two sparse products */
+        schwz_or_spmv(n, M->l_rp, M->l_col, M->wl_val, 1.0, r, 0.0, M->tmp);
+        schwz_or_spmv(n, M->u_rp, M->u_col, M->wu_val, 1.0, M->tmp, 0.0, z);
     } else {
         memcpy(z, r, sizeof(double) * (size_t)n);
     }
@@ -914,6 +965,12 @@ int schwz_or_pcg(int64_t n, const or_idx *rp, const or_idx *col, const double *v
                  double *x, int precond, double rtol, int max_iters, double *final_resnorm)
 {
     return schwz_or_pcg_ex(n, rp, col, val, b, x, precond, 1, rtol, max_iters, final_resnorm);
+}
+
+/* ISAI values of a triangular CSR factor on its own pattern (malloc'd; free with schwz_or_free) */
+void schwz_or_isai(int64_t n, const or_idx *rp, const or_idx *col, const double *val, int lower, double **w_val)
+{
+    *w_val = build_isai(n, rp, col, val, lower);
 }
 
 /* ILU(0) factors for inspection by the tests (malloc'd; free with schwz_or_free) */

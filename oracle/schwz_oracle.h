@@ -100,7 +100,7 @@ void schwz_or_sd_add_put_list(or_subdomain *sd, int p, or_idx count,
 /* ---- solver settings ------------------------------------------------------ */
 
 enum { OR_SOLVER_ITERATIVE = 0, OR_SOLVER_DIRECT = 1 };
-enum { OR_PRECOND_NONE = 0, OR_PRECOND_JACOBI = 1, OR_PRECOND_BLOCK_JACOBI = 2, OR_PRECOND_ILU = 3 };
+enum { OR_PRECOND_NONE = 0, OR_PRECOND_JACOBI = 1, OR_PRECOND_BLOCK_JACOBI = 2, OR_PRECOND_ILU = 3, OR_PRECOND_ISAI = 4 };
 
 typedef struct {
     int32_t max_iters;        /* metadata.max_iters (--num_iters) */
@@ -206,6 +206,8 @@ int schwz_or_pcg_ex(int64_t n, const or_idx *rp, const or_idx *col, const double
 int schwz_or_gmres(int64_t n, const or_idx *rp, const or_idx *col, const double *val, const double *b,
                    double *x, int precond, int block_size, int restart, double rtol, int max_iters,
                    double *final_resnorm);
+/* ISAI of a triangular factor on its own pattern (LowerIsai / UpperIsai, solve.cpp:616-638) */
+void schwz_or_isai(int64_t n, const or_idx *rp, const or_idx *col, const double *val, int lower, double **w_val);
 void schwz_or_ilu0(int64_t n, const or_idx *rp, const or_idx *col, const double *val, or_idx **l_rp,
                    or_idx **l_col, double **l_val, or_idx **u_rp, or_idx **u_col, double **u_val);
 /* sparse LL^T of A(perm,perm); outputs malloc'd CSR L and U=L^T; perm is

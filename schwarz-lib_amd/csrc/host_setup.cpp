@@ -839,6 +839,53 @@ int schwz_cholesky(int64_t n, const schwz_idx *rp, const schwz_idx *col, const d
     return SCHWZ_OK;
 }
 
+// ISAI of a triangular factor on its own pattern (Anzt, Huckle, Braeckle, Dongarra 2018): per row
+// one small triangular substitution with T(S,S), S the row's pattern; rows are independent.
+int schwz_isai(int64_t n, const schwz_idx *rp, const schwz_idx *col, const double *val, int lower, double **w_val)
+{
+    if (!rp || !w_val || n < 0 || (n > 0 && (!col || !val))) {
+        set_error("schwz_isai: bad arguments");
+        return SCHWZ_ERR_INVALID;
+    }
+    const int64_t nnz = n ? rp[n] : 0;
+    std::vector<double> w((size_t)nnz);
+    auto entry = [&](schwz_idx r, schwz_idx c) {
+        const schwz_idx *b = col + rp[r], *e = col + rp[r + 1];
+        const schwz_idx *it = std::lower_bound(b, e, c);
+        return (it != e && *it == c) ? val[it - col] : 0.0;
+    };
+    bool singular = false;
+#pragma omp parallel for schedule(dynamic, 1024) reduction(|| : singular)
+    for (int64_t i = 0; i < n; ++i) {
+        const schwz_idx s0 = rp[i], k = rp[i + 1] - rp[i];
+        const schwz_idx *S = col + s0;
+        double *wi = w.data() + s0;
+        if (lower) {
+            for (schwz_idx j = k - 1; j >= 0; --j) {
+                double acc = (S[j] == (schwz_idx)i) ? 1.0 : 0.0;
+                for (schwz_idx a = j + 1; a < k; ++a) acc -= wi[a] * entry(S[a], S[j]);
+                const double d = entry(S[j], S[j]);
+                if (d == 0.0) singular = true;
+                wi[j] = acc / d;
+            }
+        } else {
+            for (schwz_idx j = 0; j < k; ++j) {
+                double acc = (S[j] == (schwz_idx)i) ? 1.0 : 0.0;
+                for (schwz_idx a = 0; a < j; ++a) acc -= wi[a] * entry(S[a], S[j]);
+                const double d = entry(S[j], S[j]);
+                if (d == 0.0) singular = true;
+                wi[j] = acc / d;
+            }
+        }
+    }
+    if (singular) {
+        set_error("schwz_isai: zero diagonal in the triangular factor");
+        return SCHWZ_ERR_INVALID;
+    }
+    *w_val = to_malloc(w);
+    return SCHWZ_OK;
+}
+
 // ILU(0), row by row (IKJ): for every k < i in row i: l_ik = a_ik / u_kk, then row i loses
 // l_ik * (row k of U) on the positions it stores.
 int schwz_ilu0(int64_t n, const schwz_idx *rp, const schwz_idx *col, const double *val, schwz_idx **l_rp_o,

@@ -1678,12 +1678,28 @@ static int pcg_setup_general(schwz_pcg *s)
         SCHWZ_HIP_TRY(hipMemcpy(val.data(), A.val, val.size() * sizeof(double), hipMemcpyDeviceToHost));
     }
     SCHWZ_HIP_TRY(hipMalloc((void **)&s->z, (size_t)(n ? n : 1) * sizeof(double)));
-    if (s->precond == SCHWZ_PRECOND_ILU) {
+    if (s->precond == SCHWZ_PRECOND_ILU || s->precond == SCHWZ_PRECOND_ISAI) {
         schwz_idx *l_rp, *l_col, *u_rp, *u_col;
         double *l_val, *u_val;
         int rc = schwz_ilu0(n, rp.data(), col.data(), val.data(), &l_rp, &l_col, &l_val, &u_rp, &u_col, &u_val);
         if (rc) return rc;
-        rc = schwz_trs_create(n, l_rp, l_col, l_val, u_rp, u_col, u_val, nullptr, &s->ilu);
+        if (s->precond == SCHWZ_PRECOND_ISAI) {
+            // Ilu<LowerIsai, UpperIsai> (solve.cpp:616-638): z = W_U (W_L r), two CSR products on
+            // the patterns of L and U, stored like any other matrix of this library
+            double *wl = nullptr, *wu = nullptr;
+            rc = schwz_isai(n, l_rp, l_col, l_val, 1, &wl);
+            if (!rc) rc = schwz_isai(n, u_rp, u_col, u_val, 0, &wu);
+            if (!rc) rc = schwz_csr_create(n, n, l_rp, l_col, wl, &s->isai_l);
+            if (!rc) rc = schwz_csr_create(n, n, u_rp, u_col, wu, &s->isai_u);
+            if (!rc && hipMalloc((void **)&s->isai_tmp, (size_t)(n ? n : 1) * sizeof(double)) != hipSuccess) {
+                set_error("schwz_pcg_create: out of device memory (ISAI work vector)");
+                rc = SCHWZ_ERR_HIP;
+            }
+            schwz_free(wl);
+            schwz_free(wu);
+        } else {
+            rc = schwz_trs_create(n, l_rp, l_col, l_val, u_rp, u_col, u_val, nullptr, &s->ilu);
+        }
         schwz_free(l_rp);
         schwz_free(l_col);
         schwz_free(l_val);
@@ -1776,7 +1792,7 @@ int schwz_pcg_create_ex(const schwz_csr *A, int precond, int block_size, schwz_p
 {
     SCHWZ_REQUIRE(A && out, "schwz_pcg_create: null argument");
     SCHWZ_REQUIRE(A->v.nrows == A->v.ncols, "schwz_pcg_create: matrix not square");
-    SCHWZ_REQUIRE(precond >= SCHWZ_PRECOND_NONE && precond <= SCHWZ_PRECOND_ILU,
+    SCHWZ_REQUIRE(precond >= SCHWZ_PRECOND_NONE && precond <= SCHWZ_PRECOND_ISAI,
                   "schwz_pcg_create: unknown preconditioner");
     SCHWZ_REQUIRE(block_size >= 1 && block_size <= 32, "schwz_pcg_create: block size must be in 1..32");
     if (precond == SCHWZ_PRECOND_BLOCK_JACOBI && block_size == 1) precond = SCHWZ_PRECOND_JACOBI;
@@ -1844,7 +1860,7 @@ int schwz_pcg_create_ex(const schwz_csr *A, int precond, int block_size, schwz_p
             }
         }
     }
-    if (precond == SCHWZ_PRECOND_BLOCK_JACOBI || precond == SCHWZ_PRECOND_ILU) {
+    if (precond == SCHWZ_PRECOND_BLOCK_JACOBI || precond == SCHWZ_PRECOND_ILU || precond == SCHWZ_PRECOND_ISAI) {
         int rc = pcg_setup_general(s);
         if (rc) {
             schwz_pcg_destroy(s);
@@ -1866,6 +1882,9 @@ void schwz_pcg_destroy(schwz_pcg *s)
     (void)hipFree(s->d_blk_id);
     (void)hipFree(s->d_blk_inv);
     schwz_trs_destroy(s->ilu);
+    schwz_csr_destroy(s->isai_l);
+    schwz_csr_destroy(s->isai_u);
+    (void)hipFree(s->isai_tmp);
     (void)hipFree(s->d_dcode);
     (void)hipFree(s->d_ddict);
     (void)hipFree(s->partials);
@@ -1894,6 +1913,16 @@ int precond_apply(schwz_pcg *s, const double *in, double *out, hipStream_t st)
 {
     if (s->n == 0) return SCHWZ_OK;
     if (s->precond == SCHWZ_PRECOND_ILU) return schwz_trs_solve(s->ilu, in, out, (schwz_stream)st);
+    if (s->precond == SCHWZ_PRECOND_ISAI) {
+        SpmvArgs a;
+        a.x = in;
+        a.y = s->isai_tmp;
+        int rc = launch_spmv(s->isai_l->v, kSpmvPlain, a, 0, st);
+        if (rc) return rc;
+        a.x = s->isai_tmp;
+        a.y = out;
+        return launch_spmv(s->isai_u->v, kSpmvPlain, a, 0, st);
+    }
     if (s->precond == SCHWZ_PRECOND_BLOCK_JACOBI) {
         hipLaunchKernelGGL(block_jacobi_apply_kernel, dim3(grid_for(s->n)), dim3(kBlock), 0, st, s->n, s->block_size,
                            s->d_blk_id, s->d_blk_inv, in, out);
@@ -1910,7 +1939,8 @@ static int pcg_apply_general(schwz_pcg *s, hipStream_t st) { return precond_appl
 
 static bool pcg_is_general(const schwz_pcg *s)
 {
-    return s->precond == SCHWZ_PRECOND_BLOCK_JACOBI || s->precond == SCHWZ_PRECOND_ILU;
+    return s->precond == SCHWZ_PRECOND_BLOCK_JACOBI || s->precond == SCHWZ_PRECOND_ILU ||
+           s->precond == SCHWZ_PRECOND_ISAI;
 }
 
 // First half of a solve: r = b - A x, p = M^-1 r, rho, ||r||^2 -> CgState.  With

@@ -171,6 +171,8 @@ struct schwz_pcg {
     schwz_idx *d_blk_id = nullptr;  // block-Jacobi: index of each block's inverse
     double *d_blk_inv = nullptr;    // unique inverse blocks, [nunique][bs][bs]
     schwz_trs *ilu = nullptr;       // ILU(0): level-scheduled L and U sweeps
+    schwz_csr *isai_l = nullptr, *isai_u = nullptr;  // ISAI: approximate inverses of L and U
+    double *isai_tmp = nullptr;
     schwz::DiagView diag;
     void *d_dcode = nullptr, *d_ddict = nullptr;
     double *partials = nullptr;  // 3 * kMaxGrid (SpMV banks) + 2 * kMaxGrid (vector banks)

@@ -153,9 +153,11 @@ void SchwarzBase<V, I, M>::initialize()
         opt.precond_block_size = (int)m.precond_max_block_size;
     } else if (m.local_precond == "ilu") {
         opt.precond = SCHWZ_PRECOND_ILU;
+    } else if (m.local_precond == "isai") {
+        opt.precond = SCHWZ_PRECOND_ISAI;
     } else {
         throw ::NotImplemented(__FILE__, __LINE__,
-                               "local_precond '" + m.local_precond + "' (available: null, block-jacobi, ilu)");
+                               "local_precond '" + m.local_precond + "' (available: null, block-jacobi, ilu, isai)");
     }
     opt.local_tol = m.local_solver_tolerance;
     opt.local_max_iters = (int)m.local_max_iters;

@@ -7,7 +7,7 @@ shared library and fails loudly if it has not been built.
 from . import _capi as capi  # noqa: F401  (loads libschwz_hip.so)
 from ._capi import SchwzError, NotImplementedSchwz  # noqa: F401
 from .comm import InProcessComm, TorchDistComm  # noqa: F401
-from .core import (Csr, Gmres, Pcg, Problem, Subdomain, Trs, cholesky, gather, ilu0, scatter,  # noqa: F401
+from .core import (Csr, Gmres, Pcg, Problem, Subdomain, Trs, cholesky, gather, ilu0, isai, scatter,  # noqa: F401
                    partition_regular, partition_regular2d, rhs_random)
 from .solver import (HipBackend, Metadata, Settings, SolverRAS,  # noqa: F401
                      PARTITION_CUSTOM, PARTITION_METIS, PARTITION_REGULAR, PARTITION_REGULAR2D,

@@ -22,7 +22,7 @@ OK = 0
 ERR_INVALID, ERR_HIP, ERR_NOT_IMPLEMENTED, ERR_NOT_SPD, ERR_IO, ERR_DIVERGED = 1, 2, 3, 4, 5, 6
 OP_ADD, OP_COPY, OP_DIFF, OP_AVG = 0, 1, 2, 3
 SOLVER_ITERATIVE, SOLVER_DIRECT = 0, 1
-PRECOND_NONE, PRECOND_JACOBI, PRECOND_BLOCK_JACOBI, PRECOND_ILU = 0, 1, 2, 3
+PRECOND_NONE, PRECOND_JACOBI, PRECOND_BLOCK_JACOBI, PRECOND_ILU, PRECOND_ISAI = 0, 1, 2, 3, 4
 
 # every symbol include/schwz_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -42,7 +42,7 @@ SYMBOLS = [
     "schwz_subdomain_interface_matrix", "schwz_subdomain_get_list",
     "schwz_subdomain_add_put_list", "schwz_subdomain_put_list",
     "schwz_subdomain_send_offset", "schwz_subdomain_recv_offset",
-    "schwz_cholesky", "schwz_ilu0", "schwz_free",
+    "schwz_cholesky", "schwz_ilu0", "schwz_isai", "schwz_free",
     "schwz_subdomain_to_device", "schwz_ras_pack", "schwz_ras_unpack", "schwz_ras_pack_f32",
     "schwz_ras_unpack_f32",
     "schwz_ras_update_boundary", "schwz_ras_local_residual", "schwz_ras_local_residual_launch",
@@ -145,6 +145,7 @@ _sig("schwz_subdomain_send_offset", i32, [vp, i32, C.POINTER(i64)])
 _sig("schwz_subdomain_recv_offset", i32, [vp, i32, C.POINTER(i64)])
 _sig("schwz_cholesky", i32, [i64, vp, vp, vp, i32] + [pvp] * 7)
 _sig("schwz_ilu0", i32, [i64, vp, vp, vp] + [pvp] * 6)
+_sig("schwz_isai", i32, [i64, vp, vp, vp, i32, pvp])
 _sig("schwz_free", None, [vp])
 _sig("schwz_subdomain_to_device", i32, [vp, vp, C.POINTER(SolverOptions)])
 _sig("schwz_ras_pack", i32, [vp, vp, vp])

@@ -163,6 +163,21 @@ def ilu0(rp, col, val):
     return res
 
 
+def isai(rp, col, val, lower):
+    """ISAI values of a triangular CSR factor on its own pattern (LowerIsai / UpperIsai,
+    solve.cpp:616-638)."""
+    rp = np.ascontiguousarray(rp, dtype=IDX)
+    col = np.ascontiguousarray(col, dtype=IDX)
+    val = np.ascontiguousarray(val, dtype=np.float64)
+    n = len(rp) - 1
+    out = C.c_void_p()
+    check(lib.schwz_isai(n, ptr(rp), ptr(col), ptr(val), int(bool(lower)), C.byref(out)))
+    nnz = int(rp[-1])
+    w = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_double)), shape=(max(nnz, 1),))[:nnz].copy()
+    lib.schwz_free(out)
+    return w
+
+
 def cholesky(rp, col, val, natural=False):
     """Host sparse LL^T standing in for CHOLMOD (solve.cpp:75-143)."""
     rp = np.ascontiguousarray(rp, dtype=IDX)

@@ -190,10 +190,12 @@ def _precond_code(metadata):
                                        "block-jacobi: precond_max_block_size must be in 1..32")
     if lp == "ilu":
         return capi.PRECOND_ILU
+    if lp == "isai":
+        return capi.PRECOND_ISAI
     # unknown names only print to stderr in the reference (solve.cpp:568-570); refuse instead
     raise capi.NotImplementedSchwz(
         capi.ERR_NOT_IMPLEMENTED,
-        "local_precond '%s' is not implemented; available: null, block-jacobi, ilu" % lp)
+        "local_precond '%s' is not implemented; available: null, block-jacobi, ilu, isai" % lp)
 
 
 class SolverRAS:

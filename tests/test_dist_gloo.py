@@ -87,6 +87,9 @@ CASES = {
     "lap2d_cg_ilu": dict(
         world=2, settings=dict(),
         metadata=dict(oned_laplacian_size=18, tolerance=1e-8, max_iters=300, local_precond="ilu")),
+    "lap2d_cg_isai": dict(
+        world=2, settings=dict(),
+        metadata=dict(oned_laplacian_size=18, tolerance=1e-8, max_iters=300, local_precond="isai")),
     "lap2d_cg_block_jacobi8": dict(
         world=3, settings=dict(),
         metadata=dict(oned_laplacian_size=18, tolerance=1e-8, max_iters=300,

@@ -186,7 +186,7 @@ def test_direct_solve_matches_oracle(schwz, oracle, torch_cuda, case, natural):
     assert np.abs(got - exp).max() <= 1e-10 * np.abs(exp).max()
 
 
-@pytest.mark.parametrize("pc", [(2, 2), (2, 7), (2, 16), (2, 32), (3, 1)])
+@pytest.mark.parametrize("pc", [(2, 2), (2, 7), (2, 16), (2, 32), (3, 1), (4, 1)])
 @pytest.mark.parametrize("case", ["lap2d", "lap3d", "ani3"])
 def test_pcg_block_jacobi_and_ilu_match_oracle(schwz, oracle, torch_cuda, case, pc):
     """Block-Jacobi with consecutive blocks (gko preconditioner::Jacobi, solve.cpp:488-504) and
@@ -222,7 +222,7 @@ def test_pcg_block_jacobi_and_ilu_match_oracle(schwz, oracle, torch_cuda, case, 
     assert np.abs(d_x.cpu().numpy() - exp).max() <= 1e-7 * np.abs(exp).max()
 
 
-@pytest.mark.parametrize("pc", [(0, 1), (1, 1), (2, 8), (3, 1)])
+@pytest.mark.parametrize("pc", [(0, 1), (1, 1), (2, 8), (3, 1), (4, 1)])
 @pytest.mark.parametrize("restart", [1, 4, 30])
 def test_gmres_matches_oracle(schwz, oracle, torch_cuda, convdiff, restart, pc):
     """Device-resident GMRES(restart), right preconditioned (solve.cpp:486-520), against the

@@ -91,7 +91,7 @@ def test_ras_2d_iterative_matches_oracle(schwz, oracle, torch_cuda, P, precond):
 
 
 @pytest.mark.parametrize("P", [1, 3])
-@pytest.mark.parametrize("precond", [("block-jacobi", 4), ("block-jacobi", 32), ("ilu", 1)])
+@pytest.mark.parametrize("precond", [("block-jacobi", 4), ("block-jacobi", 32), ("ilu", 1), ("isai", 1)])
 def test_ras_block_jacobi_and_ilu_match_oracle(schwz, oracle, torch_cuda, P, precond):
     """--local_precond=block-jacobi --precond_max_block_size=B and --local_precond=ilu
     (solve.cpp:488-532) through the whole outer loop, 2-D and 3-D."""

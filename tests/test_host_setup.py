@@ -242,6 +242,30 @@ def test_precond_names_map_like_the_reference(schwz):
     assert code("block-jacobi", 1) == schwz.capi.PRECOND_JACOBI
     assert code("block-jacobi", 16) == schwz.capi.PRECOND_BLOCK_JACOBI
     assert code("ilu") == schwz.capi.PRECOND_ILU
-    for bad in (("isai", 1), ("block-jacobi", 64), ("nope", 1)):
+    assert code("isai") == schwz.capi.PRECOND_ISAI
+    for bad in (("block-jacobi", 64), ("nope", 1)):
         with pytest.raises(schwz.capi.NotImplementedSchwz):
             code(*bad)
+
+
+@pytest.mark.parametrize("case", ["lap3d", "ani3"])
+def test_isai_of_ilu_factors_matches_oracle_and_inverts_on_the_pattern(schwz, oracle, case):
+    """LowerIsai / UpperIsai (solve.cpp:616-638): (W T)_ij = delta_ij on the pattern of T."""
+    import scipy.sparse as sp
+    if case == "lap3d":
+        rp, col, val = oracle.laplacian3d(9, 7, 5)
+    else:
+        g = np.load(os.path.join(G, "ani3_crop.npz"))
+        rp, col, val = g["rp"], g["col"], g["val"]
+    n = len(rp) - 1
+    f = schwz.ilu0(rp, col, val)
+    for name, lower in (("l", True), ("u", False)):
+        trp, tcol, tval = f[name + "_rp"], f[name + "_col"], f[name + "_val"]
+        w = schwz.isai(trp, tcol, tval, lower)
+        wo = oracle.isai(trp, tcol, tval, lower)
+        assert np.array_equal(w, wo)
+        T = sp.csr_matrix((tval, tcol, trp), shape=(n, n))
+        W = sp.csr_matrix((w, tcol, trp), shape=(n, n))
+        pat = T.copy()
+        pat.data[:] = 1.0
+        assert abs((W @ T).multiply(pat) - sp.identity(n)).max() <= 1e-13
