@@ -1,14 +1,17 @@
 // Host side of schwz::SchwarzBase / SolverRAS on top of the C ABI (include/schwz_hip.h).
 //
 // One MPI rank = one subdomain = one GPU, as in the reference (source/initialization.cpp:72-74,
-// source/schwarz_base.cpp:102-109).  MPI carries only host data here: the index handshake, the
-// per-iteration residual norms and -- in this C++ layer -- the halo values staged through pinned
-// host buffers (the reference's `stage_through_host` mode, restricted_schwarz.cpp:878-882).  The
-// multi-GPU product path with RCCL send/recv over xGMI is the Python host (schwz_amd/comm.py),
-// which is what bench.py measures.
+// source/schwarz_base.cpp:102-109).  MPI carries host data: the index handshake and the
+// per-iteration residual norms.  Halo values travel device to device with grouped
+// ncclSend/ncclRecv (RCCL over xGMI) on the compute stream when every rank owns a GPU of its
+// own; when ranks share a device (RCCL refuses that) or SCHWZ_HALO=mpi is set they are staged
+// through pinned host buffers over MPI instead (the reference's `stage_through_host` mode,
+// restricted_schwarz.cpp:878-882).
 #include <schwarz_base.hpp>
 
 #include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+#include <unistd.h>
 
 #include <chrono>
 #include <cmath>
@@ -46,6 +49,12 @@ namespace {
         if (rc_ != SCHWZ_OK) throw_status(rc_, __FILE__, __LINE__, #expr); \
     } while (0)
 
+#define NCCL_CALL(expr)                                                                        \
+    do {                                                                                       \
+        ncclResult_t r_ = (expr);                                                              \
+        if (r_ != ncclSuccess) throw ::HipError(__FILE__, __LINE__, #expr, ncclGetErrorString(r_)); \
+    } while (0)
+
 #define HIP_CALL(expr)                                                                        \
     do {                                                                                      \
         hipError_t e_ = (expr);                                                               \
@@ -74,9 +83,11 @@ struct SchwarzBase<ValueType, IndexType, MixedValueType>::Impl {
     hipStream_t stream = nullptr;
     int device = 0;
     double rhs_sq_interior = 0.0;
+    ncclComm_t nccl = nullptr;  // halo exchange over RCCL; nullptr: staged through host over MPI
 
     ~Impl()
     {
+        if (nccl) (void)ncclCommDestroy(nccl);
         if (sd) schwz_subdomain_destroy(sd);
         if (problem) schwz_problem_destroy(problem);
         (void)hipFree(d_send);
@@ -303,6 +314,40 @@ void SchwarzBase<V, I, M>::initialize()
     HIP_CALL(hipHostMalloc((void **)&im.h_send, nsend * sizeof(double), hipHostMallocDefault));
     HIP_CALL(hipHostMalloc((void **)&im.h_recv, nrecv * sizeof(double), hipHostMallocDefault));
 
+    // RCCL communicator for the halo exchange: only when no two ranks share a GPU (RCCL refuses
+    // duplicate devices); SCHWZ_HALO=mpi forces the staged path, SCHWZ_HALO=rccl forces RCCL
+    // even for a single rank
+    {
+        const char *mode = std::getenv("SCHWZ_HALO");
+        const bool force_mpi = mode && std::string(mode) == "mpi";
+        const bool force_rccl = mode && std::string(mode) == "rccl";
+        char host[256] = {0};
+        (void)gethostname(host, sizeof(host) - 1);
+        char bus[64] = {0};
+        HIP_CALL(hipDeviceGetPCIBusId(bus, (int)sizeof(bus), im.device));
+        const std::string mine = std::string(host) + "/" + bus;
+        std::vector<char> all((size_t)P * 320, 0), me_key(320, 0);
+        std::copy(mine.begin(), mine.begin() + std::min<size_t>(mine.size(), 319), me_key.begin());
+        MPI_Allgather(me_key.data(), 320, MPI_CHAR, all.data(), 320, MPI_CHAR, MPI_COMM_WORLD);
+        bool shared = false;
+        for (int a = 0; a < P && !shared; ++a)
+            for (int b = a + 1; b < P && !shared; ++b)
+                shared = std::string(&all[(size_t)a * 320]) == std::string(&all[(size_t)b * 320]);
+        const bool use_rccl = !force_mpi && !shared && (P > 1 || force_rccl);
+        if (use_rccl) {
+            ncclUniqueId id;
+            if (me == 0) NCCL_CALL(ncclGetUniqueId(&id));
+            MPI_Bcast(&id, (int)sizeof(id), MPI_BYTE, 0, MPI_COMM_WORLD);
+            NCCL_CALL(ncclCommInitRank(&im.nccl, P, id, me));
+        }
+        if (me == 0)
+            std::cout << " Halo exchange: "
+                      << (im.nccl ? "RCCL send/recv, device to device"
+                                  : (shared ? "staged through host over MPI (ranks share a GPU)"
+                                            : "staged through host over MPI"))
+                      << std::endl;
+    }
+
     // gather_comm_data (schwarz_base.cpp:275-319): one entry per subdomain, only mine is filled
     m.comm_data_struct.assign((size_t)P, {});
     {
@@ -347,9 +392,25 @@ void SchwarzBase<V, I, M>::run(std::shared_ptr<gko::matrix::Dense<V>> &solution)
     const int n_in = (int)im.nbr_in.size(), n_out = (int)im.nbr_out.size();
     std::vector<MPI_Request> reqs((size_t)(n_in + n_out));
 
-    // halo exchange staged through pinned host memory (see the file comment)
+    // halo exchange: RCCL send/recv on the compute stream, or staged through pinned host memory
     auto exchange = [&]() {
         SCHWZ_CALL(schwz_ras_pack(im.sd, im.d_send, im.stream));
+        if (im.nccl) {
+            // one group = one fused launch; the stream orders it after the pack and before the
+            // unpack, so the receive is complete before it is scattered (F8) without a host sync
+            NCCL_CALL(ncclGroupStart());
+            for (int k = 0; k < n_in; ++k)
+                NCCL_CALL(ncclRecv(im.d_recv + im.recv_off[(size_t)k],
+                                   (size_t)(im.recv_off[(size_t)k + 1] - im.recv_off[(size_t)k]), ncclDouble,
+                                   im.nbr_in[(size_t)k], im.nccl, im.stream));
+            for (int k = 0; k < n_out; ++k)
+                NCCL_CALL(ncclSend(im.d_send + im.send_off[(size_t)k],
+                                   (size_t)(im.send_off[(size_t)k + 1] - im.send_off[(size_t)k]), ncclDouble,
+                                   im.nbr_out[(size_t)k], im.nccl, im.stream));
+            NCCL_CALL(ncclGroupEnd());
+            SCHWZ_CALL(schwz_ras_unpack(im.sd, im.d_recv, im.stream));
+            return;
+        }
         if (im.sizes[9] > 0) {
             HIP_CALL(hipMemcpyAsync(im.h_send, im.d_send, (size_t)im.sizes[9] * sizeof(double), hipMemcpyDeviceToHost, im.stream));
             HIP_CALL(hipStreamSynchronize(im.stream));

@@ -18,13 +18,14 @@ BIN = os.path.join(ROOT, "schwarz-lib_amd", "build", "bench_ras")
 MPIEXEC = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
 
 
-def _run(nranks, *flags, cwd=None):
+def _run(nranks, *flags, cwd=None, env=None):
     if not os.path.exists(BIN):
         pytest.skip("bench_ras binary not built (needs the reference checkout at build time)")
     if not os.path.exists(MPIEXEC):
         pytest.skip("no mpiexec on this machine")
     cmd = [MPIEXEC, "-n", str(nranks), BIN, "--executor=hip"] + list(flags)
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=cwd)
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=cwd,
+                       env=dict(os.environ, **(env or {})))
     assert p.returncode == 0, p.stdout + p.stderr
     return p.stdout
 
@@ -111,3 +112,30 @@ def test_bench_ras_non_symmetric_gmres(oracle, convdiff, tmp_path):
     assert ref["converged"] and len(iters) == 1 and abs(iters[0] - ref["iter_count"]) <= 1, out
     rel = float(re.search(r"relative residual norm of solution ([0-9.eE+-]+)", out).group(1))
     assert rel <= 1e-6
+
+
+def test_bench_ras_halo_transport_selection(oracle):
+    """Halos go device to device over RCCL when every rank owns a GPU; ranks sharing the one GPU
+    of this box fall back to host staging over MPI, and a single rank can be forced onto the RCCL
+    path (communicator set-up, grouped launch with no peers)."""
+    n = 24
+    base = ("--explicit_laplacian", "--set_1d_laplacian_size=%d" % n, "--enable_global_check", "--num_iters=400",
+            "--set_tol=1e-8")
+    rp, col, val = oracle.laplacian2d(n)
+    N = n * n
+
+    def iters_of(out):
+        return set(int(x) for x in re.findall(r"converged in (\d+) iterations", out))
+
+    out = _run(2, *base)
+    assert "staged through host over MPI (ranks share a GPU)" in out
+    ref2 = oracle.ras_run(rp, col, val, np.ones(N), 2, oracle.first_rows_regular(N, 2),
+                          oracle.make_settings(max_iters=400, tol=1e-8))
+    assert iters_of(out) == {ref2["iter_count"]}
+    out = _run(1, *base, env={"SCHWZ_HALO": "rccl"})
+    assert "RCCL send/recv, device to device" in out
+    ref1 = oracle.ras_run(rp, col, val, np.ones(N), 1, oracle.first_rows_regular(N, 1),
+                          oracle.make_settings(max_iters=400, tol=1e-8))
+    assert iters_of(out) == {ref1["iter_count"]}
+    out = _run(1, *base, env={"SCHWZ_HALO": "mpi"})
+    assert "staged through host over MPI" in out and iters_of(out) == {ref1["iter_count"]}
