@@ -742,6 +742,7 @@ static or_precond *precond_create(int kind, int bs, int64_t n, const or_idx *rp,
     if (kind == OR_PRECOND_BLOCK_JACOBI && M->bs == 1) M->kind = kind = OR_PRECOND_JACOBI;
     if (kind == OR_PRECOND_JACOBI) {
         M->dinv = (double *)xmalloc(sizeof(double) * (size_t)(n ? n : 1));
+#pragma omp parallel for schedule(static) if (n > OMP_MIN_N)
         for (int64_t i = 0; i < n; ++i) {
             double d = 1.0;
             for (or_idx j = rp[i]; j < rp[i + 1]; ++j)
@@ -783,9 +784,11 @@ static void precond_apply(const or_precond *M, const double *r, double *z)
 {
     const int64_t n = M->n;
     if (M->kind == OR_PRECOND_JACOBI) {
+#pragma omp parallel for schedule(static) if (n > OMP_MIN_N)
         for (int64_t i = 0; i < n; ++i) z[i] = M->dinv[i] * r[i];
     } else if (M->kind == OR_PRECOND_BLOCK_JACOBI) {
         const int bs = M->bs;
+#pragma omp parallel for schedule(static) if (n > OMP_MIN_N)
         for (int64_t i = 0; i < n; ++i) {
             const int64_t b = i / bs, r0 = b * bs;
             const double *row = M->binv + ((size_t)b * bs + (size_t)(i - r0)) * bs;
@@ -891,6 +894,7 @@ int schwz_or_gmres(int64_t n, const or_idx *rp, const or_idx *col, const double 
         if (r0 < 0.0) r0 = beta;
         resn = beta;
         if (it >= max_iters || beta <= rtol * r0 || beta == 0.0) break;
+#pragma omp parallel for schedule(static) if (n > OMP_MIN_N)
         for (int64_t i = 0; i < n; ++i) v0[i] /= beta;
         memset(g, 0, sizeof(double) * ((size_t)m + 1));
         g[0] = beta;
@@ -909,6 +913,7 @@ int schwz_or_gmres(int64_t n, const or_idx *rp, const or_idx *col, const double 
             }
             const double hn = sqrt(dot(n, w, w));
             h[j + 1] = hn;
+#pragma omp parallel for schedule(static) if (n > OMP_MIN_N)
             for (int64_t q = 0; q < n; ++q) vn[q] = hn != 0.0 ? w[q] / hn : 0.0;
             for (int i = 0; i < j; ++i) {
                 const double t = cs[i] * h[i] + sn[i] * h[i + 1];
@@ -945,6 +950,7 @@ int schwz_or_gmres(int64_t n, const or_idx *rp, const or_idx *col, const double 
             for (int64_t q = 0; q < n; ++q) w[q] += yi * vi[q];
         }
         precond_apply(M, w, z);
+#pragma omp parallel for schedule(static) if (n > OMP_MIN_N)
         for (int64_t q = 0; q < n; ++q) x[q] += z[q];
         if (resn <= rtol * r0 || it >= max_iters) break;
     }
