@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--slab", default="512,512,64",
                     help="N>1: per-GPU slab nx,ny,nz (grid = nx x ny x nz*N; default = configs[2] at N=8)")
     ap.add_argument("--spmv-variant", type=int, default=0)
+    ap.add_argument("--overlapped", action="store_true",
+                    help="one-sided overlapped exchange with decentralised convergence (configs[4] flavour)")
+    ap.add_argument("--mixed-halo", action="store_true", help="fp32 halo wire format (use_mixed_precision)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ttr", action="store_true", help="skip the time-to-residual run")
     ap.add_argument("--cpu-iters", type=int, default=30,
@@ -45,10 +48,17 @@ def parse():
     return ap.parse_args()
 
 
-def make_solver(schwz, comm, shape, inner, tol, max_iters, local_tol, variant, quiet=True):
+def make_solver(schwz, comm, shape, inner, tol, max_iters, local_tol, variant, quiet=True, overlapped=False,
+                mixed=False):
     s = schwz.Settings(laplacian_dim=3, laplacian_shape=shape, overlap=2,
-                       partition=schwz.PARTITION_REGULAR, spmv_variant=variant)
+                       partition=schwz.PARTITION_REGULAR, spmv_variant=variant, use_mixed_precision=mixed)
     s.convergence_settings.enable_global_check = True
+    if overlapped:
+        # BASELINE configs[4] flavour: halos posted on a side stream and consumed one iteration late,
+        # decentralised stop agreement, no collective in the loop
+        s.comm_settings.enable_onesided = True
+        s.comm_settings.enable_overlap = True
+        s.convergence_settings.enable_decentralized_leader_election = True
     m = schwz.Metadata(tolerance=tol, max_iters=max_iters, local_precond="block-jacobi",
                        precond_max_block_size=1, local_solver_tolerance=local_tol,
                        local_max_iters=inner, num_subdomains=comm.size)
@@ -131,7 +141,7 @@ def main():
 
     t_setup = time.perf_counter()
     solver, m = make_solver(schwz, comm, shape, a.inner, 1e-30, a.warmup + 2 * a.steps + 2, 0.0,
-                            a.spmv_variant)
+                            a.spmv_variant, overlapped=a.overlapped, mixed=a.mixed_halo)
     setup_s = time.perf_counter() - t_setup
     sd = solver.subdomains[comm.local_ranks[0]]
     solver.begin_run()
@@ -222,7 +232,10 @@ def main():
         "config": {"workload": workload, "inner_cg_iters": a.inner, "precond": "jacobi",
                    "local_tol": 0.0, "overlap": 2, "partition": "regular",
                    "rows_per_gpu": sd.local_size_x, "nnz_per_gpu": sd.nnz_local,
-                   "spmv_variant": a.spmv_variant},
+                   "spmv_variant": a.spmv_variant,
+                   "exchange": ("one-sided overlapped, decentralised stop" if a.overlapped
+                                else "two-sided, all-gathered residual norms") +
+                               (", fp32 halos" if a.mixed_halo else "")},
         "ras_iters_per_s": iters_per_s,
         "setup_s": setup_s,
         "residual_reduction_in_timed_steps": (sum(h[-1] for h in hist) / sum(h[0] for h in hist))
