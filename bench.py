@@ -180,7 +180,8 @@ def main():
     hist = m.post_process_data["global_residual_vector_out"]
     fmt = int(schwz.capi.lib.schwz_csr_format(sd_csr(sd, schwz))) if a.spmv_variant == 0 else 0
     dict_coded = fmt != 0
-    kernel_name = {2: "spmv_pattern_kernel<kSpmvDot> (q = A p, fused p.q; row-pattern coded CSR tiles)",
+    kernel_name = {3: "spmv_pair_kernel<kSpmvDot> (q = A p, fused p.q; row-pair pattern coded CSR tiles)",
+                   2: "spmv_pattern_kernel<kSpmvDot> (q = A p, fused p.q; row-pattern coded CSR tiles)",
                    1: "spmv_dict_kernel<kSpmvDot> (q = A p, fused p.q; dictionary-coded CSR tiles)",
                    0: "spmv_tiled2_kernel<kSpmvDot> (q = A p, fused p.q; plain CSR)"}[fmt]
     traffic = None

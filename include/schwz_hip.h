@@ -93,15 +93,16 @@ int schwz_csr_create(int64_t nrows, int64_t ncols, const schwz_idx *h_row_ptr,
 void schwz_csr_destroy(schwz_csr *A);
 int64_t schwz_csr_nnz(const schwz_csr *A);
 /* encoding the default SpMV (variant 0) uses for this matrix: 0 = plain CSR, 1 = per-entry
- * dictionary tiles, 2 = row-pattern tiles (both lossless re-encodings built at upload,
- * csrc/spmv_dict.hip) */
+ * dictionary tiles, 2 = row-pattern tiles, 3 = row-PAIR pattern tiles (lossless re-encodings
+ * built at upload, csrc/spmv_dict.hip and csrc/spmv_pair.hip) */
 int schwz_csr_format(const schwz_csr *A);
 
 /* y = alpha*A*x + beta*y : gko Csr::apply(alpha,x,beta,y), call sites
  * source/restricted_schwarz.cpp:1014-1015, source/solve.cpp:834-835,1079-1080.
- * variant: 0 = default: dictionary-coded tiles where the matrix allows it (lossless,
- * bit-identical results; see csrc/spmv_dict.hip), else 6; 6 = plain CSR, LDS-staged row tiles
- * with 16-byte batched loads,
+ * variant: 0 = default: the best coded tiles the matrix allows (row pairs, row patterns,
+ * per-entry dictionaries; lossless, bit-identical results; see csrc/spmv_pair.hip,
+ * csrc/spmv_dict.hip), else 6; 8 = row-pattern tiles, 7 = per-entry dictionary tiles,
+ * 6 = plain CSR, LDS-staged row tiles with 16-byte batched loads,
  * 1 = one-row-per-lane baseline, 2 = first tiled version (scalar loads), 3/5 = wave-private
  * tiles (5: non-temporal matrix loads), 4 = software-pipelined tiles; 10.. = ablation builds
  * for tools/spmv_probe.py (deliberately wrong results). */
@@ -284,7 +285,7 @@ typedef struct {
     double local_tol;        /* metadata.local_solver_tolerance */
     int32_t local_max_iters; /* -1 => local_size_x (solve.cpp:458-463) */
     int32_t natural_factor_ordering; /* settings.naturally_ordered_factor */
-    int32_t spmv_variant;    /* 0 default */
+    int32_t spmv_variant;    /* 0 default (the best coding the matrix allows); see schwz_csr_spmv */
     int32_t precond_block_size; /* metadata.precond_max_block_size (block-jacobi) */
     int32_t non_symmetric;   /* settings.non_symmetric_matrix: GMRES instead of CG */
     int32_t restart_iter;    /* settings.restart_iter (GMRES krylov_dim), >= 1 */

@@ -749,7 +749,7 @@ int spmv_grid(const CsrView &A, int variant)
 int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipStream_t s)
 {
     if (A.nrows == 0) return SCHWZ_OK;
-    if (mode == kSpmvResidDual && variant != 0 && variant != 4 && variant != 6 && variant != 7) {
+    if (mode == kSpmvResidDual && variant != 0 && variant != 4 && variant != 6 && variant != 7 && variant != 8) {
         set_error("launch_spmv: the fused dual-residual mode exists for variants 0, 4 and 6 only");
         return SCHWZ_ERR_INVALID;
     }
@@ -769,7 +769,8 @@ int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipS
         hipLaunchKernelGGL((spmv_wave_kernel<kSpmvResidNorm, NTV>), dim3(wgrid), dim3(kBlock), 0, s, A, a); \
         break;                                                                                         \
     }
-    if (variant == 0 && A.pat_id) return launch_spmv_pattern(A, mode, a, grid, s);
+    if (variant == 0 && A.pair_id) return launch_spmv_pair(A, mode, a, grid, s);
+    if ((variant == 0 || variant == 8) && A.pat_id) return launch_spmv_pattern(A, mode, a, grid, s);
     if ((variant == 0 || variant == 7) && A.code) return launch_spmv_dict(A, mode, a, grid, s);
     if (variant >= 10 && variant < 74 && mode == kSpmvPlain) {
         switch (variant - 10) {
@@ -1585,7 +1586,10 @@ void schwz_csr_destroy(schwz_csr *A)
 
 int64_t schwz_csr_nnz(const schwz_csr *A) { return A ? A->v.nnz : 0; }
 
-int schwz_csr_format(const schwz_csr *A) { return !A ? 0 : (A->v.pat_id ? 2 : (A->v.code ? 1 : 0)); }
+int schwz_csr_format(const schwz_csr *A)
+{
+    return !A ? 0 : (A->v.pair_id ? 3 : (A->v.pat_id ? 2 : (A->v.code ? 1 : 0)));
+}
 
 int schwz_csr_spmv(const schwz_csr *A, double alpha, const double *d_x, double beta, double *d_y,
                    int variant, schwz_stream stream)
@@ -2285,7 +2289,7 @@ int csr_set_dual_split(schwz_csr *A, const schwz_idx *h_rp, const schwz_idx *h_c
     SCHWZ_HIP_TRY(hipMalloc(&A->d_tile_dual, flag.size()));
     SCHWZ_HIP_TRY(hipMemcpy(A->d_tile_dual, flag.data(), flag.size(), hipMemcpyHostToDevice));
     A->v.tile_dual = (const uint8_t *)A->d_tile_dual;
-    return SCHWZ_OK;
+    return pair_set_dual_split(A, h_rp, h_col, split);
 }
 
 int launch_gather_f32(int64_t n, const schwz_idx *idx, const double *from, float *into, hipStream_t s)

@@ -72,6 +72,16 @@ struct CsrView {
     const uint8_t *tbl_len = nullptr;       // pattern lengths, concatenated
     const double *tbl_val = nullptr;        // [npat][lmax] per table, concatenated
     const schwz_idx *tbl_delta = nullptr;
+    // row-pair pattern coding (spmv_pair.hip): one byte per PAIR of adjacent rows selects a merged
+    // (col - row, value of row r, value of row r+1, presence bits) sequence
+    const uint8_t *pair_id = nullptr;        // (nrows + 1) / 2: pattern of rows (2i, 2i + 1)
+    const schwz_idx *chunk_ptable = nullptr; // per chunk of 512 rows: pair table id, -1 = not pair coded
+    const uint8_t *chunk_dual = nullptr;     // per chunk: the fused dual residual needs its second product
+    int pair_shift = 0;                      // log2 of the run length of the XCD deal of the chunks
+    const schwz_idx *ptbl_desc = nullptr;    // per table: {entry offset, len offset, npat, lmax, max |col - row|}
+    const uint8_t *ptbl_len = nullptr;
+    const double *ptbl_val = nullptr;        // 2 per entry
+    const schwz_idx *ptbl_meta = nullptr;    // 2 per entry: offset, flags
 };
 
 // epilogues of the tiled SpMV kernel
@@ -104,6 +114,7 @@ int spmv_grid(const CsrView &A, int variant);
 int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipStream_t s);
 int launch_spmv_dict(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s);
 int launch_spmv_pattern(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s);
+int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s);
 
 // Jacobi scaling as the CG vector kernels see it.  The full 1/diag vector costs 8 B per row and
 // per kernel; matrices with few distinct diagonal values (every stencil) get a 1-byte code per
@@ -134,6 +145,10 @@ namespace schwz {
 int build_spmv_dict(schwz_csr *A, const schwz_idx *h_rp, const schwz_idx *h_col, const double *h_val,
                     const std::vector<schwz_idx> &tiles);
 void free_spmv_dict(schwz_csr *A);
+int build_spmv_pair(schwz_csr *A, const schwz_idx *h_rp, const schwz_idx *h_col, const double *h_val,
+                    const std::vector<schwz_idx> &tiles);
+void free_spmv_pair(schwz_csr *A);
+int pair_set_dual_split(schwz_csr *A, const schwz_idx *h_rp, const schwz_idx *h_col, int64_t split);
 // marks the tiles whose rows or columns reach index >= split (see CsrView::tile_dual)
 int csr_set_dual_split(schwz_csr *A, const schwz_idx *h_rp, const schwz_idx *h_col, int64_t split);
 }  // namespace schwz
@@ -154,10 +169,13 @@ struct schwz_csr {
     void *d_code = nullptr, *d_vptr = nullptr, *d_dptr = nullptr, *d_vdict = nullptr, *d_ddict = nullptr;
     void *d_pat_id = nullptr, *d_tile_table = nullptr, *d_tbl_desc = nullptr, *d_tbl_len = nullptr, *d_tbl_val = nullptr,
          *d_tbl_delta = nullptr;
+    void *d_pair_id = nullptr, *d_tile_ptable = nullptr, *d_ptbl_desc = nullptr, *d_ptbl_len = nullptr,
+         *d_ptbl_val = nullptr, *d_ptbl_meta = nullptr, *d_chunk_dual = nullptr;
     void *d_tile_dual = nullptr;
     std::vector<schwz_idx> h_tiles;  // host copy of the tile boundaries
     double dict_fraction = 0.0;  // share of the nonzeros that are dictionary coded
     double pattern_fraction = 0.0;  // share of the nonzeros in row-pattern coded tiles
+    double pair_fraction = 0.0;     // share of the nonzeros in row-pair coded tiles
 };
 
 struct schwz_pcg {

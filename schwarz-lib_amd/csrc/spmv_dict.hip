@@ -654,6 +654,7 @@ int build_spmv_dict(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, con
 {
     {
         int rc = build_spmv_pattern(A, rp, col, val, tiles);
+        if (!rc && A->v.pat_id) rc = build_spmv_pair(A, rp, col, val, tiles);  // stencil-like: pairs too
         if (rc) {
             free_spmv_dict(A);
             return rc;
@@ -734,6 +735,7 @@ void free_spmv_dict(schwz_csr *A)
     void *ptrs[] = {A->d_code, A->d_vptr, A->d_dptr, A->d_vdict, A->d_ddict, A->d_pat_id, A->d_tile_table,
                     A->d_tbl_desc, A->d_tbl_len, A->d_tbl_val, A->d_tbl_delta};
     for (void *p : ptrs) (void)hipFree(p);
+    free_spmv_pair(A);
     A->d_code = A->d_vptr = A->d_dptr = A->d_vdict = A->d_ddict = nullptr;
     A->d_pat_id = A->d_tile_table = A->d_tbl_desc = A->d_tbl_len = A->d_tbl_val = A->d_tbl_delta = nullptr;
     A->v.code = nullptr;

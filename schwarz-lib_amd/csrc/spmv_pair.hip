@@ -1,0 +1,505 @@
+// Row-PAIR pattern coding of the CSR SpMV: the third, and fastest, lossless coding of this library.
+//
+// Why.  tools/probes/gather_probe.hip times the bare gather + store structure of a 7-point SpMV at
+// 256^3 with no matrix data at all: one row per lane with 8-byte gathers 0.088-0.096 ms, two adjacent
+// rows per lane with 16-byte gathers 0.053-0.055 ms.  The row-pattern kernel (spmv_dict.hip, one row
+// per lane) sits at 0.115 ms, i.e. on that floor: it is bound by the number of vector-memory
+// instructions, not by bytes.  Here a lane owns rows (r, r+1): for an offset d present in either row
+// ONE 16-byte load fetches x[r+d] (row r's operand) and x[r+1+d] (row r+1's), halving the gather
+// instructions; the matrix costs one byte per PAIR.
+//
+// Coding.  For a pair, the entries of both rows are merged by offset d = col - row (both rows must
+// have strictly ascending columns, so each row still sees its own entries in CSR order); an entry is
+// (d, value for row r, value for row r+1, presence bits).  A tile's distinct merged sequences form
+// its table (<= 64 patterns, <= 512 entries, staged in LDS); tables are de-duplicated over the
+// matrix.  Products are rounded individually and added in the row's entry order: the result is
+// bit-identical to the plain CSR kernels.  Tiles that do not qualify run through the plain row code
+// of the same launch.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <unordered_map>
+#include <vector>
+
+#include "device_utils.hpp"
+#include "schwz_hip.h"
+#include "schwz_internal.hpp"
+
+namespace schwz {
+
+constexpr int kPairPats = 64;      // patterns per table
+constexpr int kPairEntries = 512;  // staged entries per table (npat * stride)
+constexpr int kPairChunk = 8;      // gathers issued back to back per lane
+
+__host__ __device__ inline int pair_stride(int lmax) { return (lmax + kPairChunk - 1) / kPairChunk * kPairChunk; }
+
+struct __attribute__((aligned(16))) PairVal {
+    double a, b;
+};
+struct __attribute__((aligned(8))) PairMeta {
+    int off;    // col - row
+    int flags;  // bit 0: row r has the entry, bit 1: row r+1 has it
+};
+
+typedef double pvd2 __attribute__((ext_vector_type(2)));
+
+constexpr int kPairRows = 2 * kBlock;  // rows per chunk: one pair per lane
+
+// chunk dealt to XCD `xcd` as its j-th one (block-cyclic in runs of 1 << sh), -1 past the end
+__device__ __forceinline__ int xcd_chunk(int nchunks, int sh, int xcd, int j)
+{
+    const int c = ((j >> sh) << (sh + 3)) + (xcd << sh) + (j & ((1 << sh) - 1));
+    return c < nchunks ? c : -1;
+}
+
+template <int MODE, bool WIDE>
+__global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a)
+{
+#pragma clang fp contract(off)
+    __shared__ PairVal pv[kPairEntries];
+    __shared__ int poff[kPairEntries];             // col - row of the entry
+    __shared__ int pmask[kPairEntries / kPairChunk];  // per chunk: bit k = row r has entry k, bit 8+k = row r+1
+    __shared__ int plen[kPairPats];
+    if (MODE == kSpmvDot || MODE == kSpmvResidInit) {
+        if (a.stop_iter && a.it >= *a.stop_iter) return;
+    }
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const int xcd = blockIdx.x % kXcds;
+    const int slot = blockIdx.x / kXcds;
+    const int per_xcd = gridDim.x / kXcds;
+    const int nrows = (int)A.nrows;
+    const int nchunks = (nrows + kPairRows - 1) / kPairRows;
+    const int sh = A.pair_shift;
+    const int slots = ((nchunks + (kXcds << sh) - 1) >> (sh + 3)) << sh;  // sequence slots per XCD
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+    const bool dual = (MODE == kSpmvResidDual) && a.x2 != nullptr;
+    int cached = -1, ls = 0, reach = 0;  // staged table, its row stride, its largest |col - row|
+
+    auto stage_table = [&](int tb) {  // workgroup-uniform
+        const int eoff = A.ptbl_desc[5 * tb], loff = A.ptbl_desc[5 * tb + 1];
+        const int npat = A.ptbl_desc[5 * tb + 2], lmax = A.ptbl_desc[5 * tb + 3];
+        ls = pair_stride(lmax);
+        reach = A.ptbl_desc[5 * tb + 4];
+        lds_barrier();  // everyone is done with the previous table
+        for (int i = tid; i < npat * ls; i += kBlock) {
+            const int pt = i / ls, k = i - pt * ls;
+            PairVal v = {0.0, 0.0};
+            int off = 0;
+            if (k < lmax) {
+                const int e = eoff + pt * lmax + k;
+                v.a = A.ptbl_val[2 * e];
+                v.b = A.ptbl_val[2 * e + 1];
+                off = A.ptbl_meta[2 * e];
+            }
+            pv[i] = v;
+            poff[i] = off;
+        }
+        for (int i = tid; i < npat * ls / kPairChunk; i += kBlock) {
+            const int pt = i / (ls / kPairChunk), k0 = (i - pt * (ls / kPairChunk)) * kPairChunk;
+            int m = 0;
+            for (int k = 0; k < kPairChunk && k0 + k < lmax; ++k) {
+                const int fl = A.ptbl_meta[2 * (eoff + pt * lmax + k0 + k) + 1];
+                m |= (fl & 1) << k;
+                m |= ((fl >> 1) & 1) << (kPairChunk + k);
+            }
+            pmask[i] = m;
+        }
+        if (tid < npat) plen[tid] = A.ptbl_len[loff + tid];
+        lds_barrier();
+        cached = tb;
+    };
+    // x[c], x[c + 1] -- the operands of one merged entry for rows r and r + 1 -- by ONE 16-byte load
+    auto ld16 = [&](const double *xv, int c) -> pvd2 {
+        pvd2 t;
+        if (WIDE) {
+            __builtin_memcpy(&t, xv + c, 16);
+        } else {
+            const uint32_t o = (uint32_t)c * 8u;  // scalar base + 32-bit lane offset
+            __builtin_memcpy(&t, reinterpret_cast<const char *>(xv) + o, 16);
+        }
+        return t;
+    };
+    // Both rows' dot products with xv.  `safe`: some lane of the wave sits within `reach` rows of the
+    // first or last column, where a 16-byte load could leave the vector: those waves load each
+    // operand that exists on its own.
+    auto accumulate = [&](const double *xv, int ra, int base, int len, bool safe, double &s0, double &s1,
+                          pvd2 &own, bool want_own) {
+        for (int j = 0; j < len; j += kPairChunk) {
+            const int mask = pmask[(base + j) / kPairChunk];
+            pvd2 t[kPairChunk];
+            if (!safe) {
+#pragma unroll
+                for (int k = 0; k < kPairChunk; ++k) {
+                    const int off = poff[base + j + k];
+                    t[k] = ld16(xv, ra + off);
+                    if (want_own && off == 0) own = t[k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < kPairChunk; ++k) {
+                    const int c = ra + poff[base + j + k];
+                    t[k].x = (mask >> k) & 1 ? xv[c] : 0.0;
+                    t[k].y = (mask >> (kPairChunk + k)) & 1 ? xv[c + 1] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kPairChunk; ++k) {
+                const PairVal v = pv[base + j + k];
+                if ((mask >> k) & 1) s0 += v.a * t[k].x;
+                if ((mask >> (kPairChunk + k)) & 1) s1 += v.b * t[k].y;
+            }
+        }
+    };
+    // one row straight from val / col (chunks that are not pair coded)
+    auto plain_row = [&](int row, bool dual_t, double &sum, double &sum2) {
+        for (int j = A.rp[row]; j < A.rp[row + 1]; ++j) {
+            const double vv = A.val[j];
+            const int cc = A.col[j];
+            sum += vv * a.x[cc];
+            if (dual_t) sum2 += vv * a.x2[cc];
+        }
+    };
+    auto finish = [&](int rw, double sum, double sum2, bool dual_t, double ox, double ob, double od, double &yv,
+                      double &pz) {
+        yv = sum;
+        pz = 0.0;
+        if (MODE == kSpmvPlain) {
+            yv = (a.beta == 0.0) ? a.alpha * sum : a.alpha * sum + a.beta * ob;
+        } else if (MODE == kSpmvDot) {
+            acc0 += ox * sum;
+        } else if (MODE == kSpmvResidInit || MODE == kSpmvResidDual) {
+            const double r = ob - sum;
+            const double z = a.dinv ? od * r : r;
+            yv = r;
+            pz = z;
+            acc0 += r * z;
+            acc1 += r * r;
+            if (MODE == kSpmvResidDual && rw < a.row_limit) {
+                const double r2 = dual_t ? ob - sum2 : r;
+                acc2 += r2 * r2;
+            }
+        } else {  // kSpmvResidNorm
+            if (rw < a.row_limit) {
+                const double r = ob - sum;
+                acc1 += r * r;
+            }
+        }
+    };
+
+    // Fixed chunks of 512 consecutive rows, one pair per lane: nothing but the chunk's table id has
+    // to be looked up before the pattern ids and the gathers can be requested.
+    for (int j = slot; j < slots; j += per_xcd) {
+        const int chunk = xcd_chunk(nchunks, sh, xcd, j);
+        if (chunk < 0) continue;
+        const int tb = A.chunk_ptable[chunk];
+        const bool dual_t = dual && (!A.chunk_dual || A.chunk_dual[chunk]);
+        if (tb >= 0 && tb != cached) stage_table(tb);
+        const int ra = chunk * kPairRows + 2 * tid;
+        if (ra >= nrows) continue;
+        const bool has_b = ra + 1 < nrows;
+        // own operands of the fused epilogues, requested ahead of the gathers
+        double ob0 = 0.0, ob1 = 0.0, od0 = 1.0, od1 = 1.0;
+        if (MODE == kSpmvResidInit || MODE == kSpmvResidDual || MODE == kSpmvResidNorm) {
+            if (MODE != kSpmvResidNorm || ra < a.row_limit) ob0 = a.b[ra];
+            if (has_b && (MODE != kSpmvResidNorm || ra + 1 < a.row_limit)) ob1 = a.b[ra + 1];
+        }
+        if ((MODE == kSpmvResidInit || MODE == kSpmvResidDual) && a.dinv) {
+            od0 = a.dinv[ra];
+            if (has_b) od1 = a.dinv[ra + 1];
+        }
+        if (MODE == kSpmvPlain && a.beta != 0.0) {
+            ob0 = a.y[ra];
+            if (has_b) ob1 = a.y[ra + 1];
+        }
+        double s0 = 0.0, s1 = 0.0, t0 = 0.0, t1 = 0.0;
+        pvd2 own = {0.0, 0.0};
+        bool own_from_gathers = false;
+        if (tb >= 0) {
+            const int pid = A.pair_id[ra >> 1];
+            const int len = plen[pid];
+            const int base = pid * ls;
+            const bool edge = ra < reach || ra + 1 + reach >= (int)A.ncols;
+            const bool safe = __builtin_amdgcn_ballot_w64(edge) != 0;
+            // the fused dot needs x[ra], x[ra + 1]: the padding entries (col - row = 0) gather exactly
+            // that pair, as does a diagonal entry; waves on the safe path load it themselves
+            own_from_gathers = MODE == kSpmvDot && !safe && (len % kPairChunk) != 0;
+            pvd2 unused = {0.0, 0.0};
+            accumulate(a.x, ra, base, len, safe, s0, s1, own, own_from_gathers);
+            if (dual_t) accumulate(a.x2, ra, base, len, safe, t0, t1, unused, false);
+        } else {
+            plain_row(ra, dual_t, s0, t0);
+            if (has_b) plain_row(ra + 1, dual_t, s1, t1);
+        }
+        if (MODE == kSpmvDot && !own_from_gathers) {
+            own.x = a.x[ra];
+            if (has_b) own.y = a.x[ra + 1];
+        }
+        double y0, y1 = 0.0, p0, p1 = 0.0;
+        finish(ra, s0, t0, dual_t, own.x, ob0, od0, y0, p0);
+        if (has_b) finish(ra + 1, s1, t1, dual_t, own.y, ob1, od1, y1, p1);
+        if (MODE != kSpmvResidNorm) {
+            if (has_b) {
+                const pvd2 yy = {y0, y1};
+                __builtin_memcpy(a.y + ra, &yy, 16);
+            } else {
+                a.y[ra] = y0;
+            }
+        }
+        if (MODE == kSpmvResidInit || MODE == kSpmvResidDual) {
+            if (has_b) {
+                const pvd2 pp = {p0, p1};
+                __builtin_memcpy(a.p + ra, &pp, 16);
+            } else {
+                a.p[ra] = p0;
+            }
+        }
+    }
+    if (MODE != kSpmvPlain) {
+        const double s0 = block_sum(acc0, red);
+        const double s1 = block_sum(acc1, red);
+        if (tid == 0) {
+            a.partials[blockIdx.x] = s0;
+            a.partials[gridDim.x + blockIdx.x] = s1;
+        }
+        if (MODE == kSpmvResidDual) {
+            const double s2v = block_sum(acc2, red);
+            if (tid == 0) a.partials[2 * gridDim.x + blockIdx.x] = s2v;
+        }
+    }
+}
+
+int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s)
+{
+    const bool wide = A.ncols >= (int64_t(1) << 28);  // byte offsets of x beyond 32 bits
+#define SCHWZ_PAIR_LAUNCH(M)                                                                  \
+    if (wide)                                                                                 \
+        hipLaunchKernelGGL((spmv_pair_kernel<M, true>), dim3(grid), dim3(kBlock), 0, s, A, a); \
+    else                                                                                      \
+        hipLaunchKernelGGL((spmv_pair_kernel<M, false>), dim3(grid), dim3(kBlock), 0, s, A, a);
+    switch (mode) {
+    case kSpmvPlain: SCHWZ_PAIR_LAUNCH(kSpmvPlain) break;
+    case kSpmvDot: SCHWZ_PAIR_LAUNCH(kSpmvDot) break;
+    case kSpmvResidInit: SCHWZ_PAIR_LAUNCH(kSpmvResidInit) break;
+    case kSpmvResidDual: SCHWZ_PAIR_LAUNCH(kSpmvResidDual) break;
+    default: SCHWZ_PAIR_LAUNCH(kSpmvResidNorm) break;
+    }
+#undef SCHWZ_PAIR_LAUNCH
+    SCHWZ_HIP_TRY(hipGetLastError());
+    return SCHWZ_OK;
+}
+
+namespace {
+
+struct PairEntryH {
+    schwz_idx off;
+    int flags;
+    uint64_t va, vb;
+    bool operator==(const PairEntryH &o) const { return off == o.off && flags == o.flags && va == o.va && vb == o.vb; }
+};
+
+struct PairTable {
+    int npat = 0, lmax = 0;
+    std::vector<uint8_t> len;
+    std::vector<PairEntryH> ent;  // [npat][lmax], padded with {0,0,0,0}
+    uint64_t hash = 0;
+    bool same(const PairTable &o) const { return npat == o.npat && lmax == o.lmax && len == o.len && ent == o.ent; }
+};
+
+template <typename T>
+int upv(const std::vector<T> &h, void **d)
+{
+    *d = nullptr;
+    SCHWZ_HIP_TRY(hipMalloc(d, (h.empty() ? 1 : h.size()) * sizeof(T)));
+    if (!h.empty()) SCHWZ_HIP_TRY(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return SCHWZ_OK;
+}
+
+}  // namespace
+
+// Leaves A->v.pair_id null when fewer than 90 % of the nonzeros sit in pair-coded chunks
+// (SCHWZ_SPMV_PAIR=0 disables, =2 forces whatever the coverage).
+int build_spmv_pair(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, const double *val,
+                    const std::vector<schwz_idx> &tiles)
+{
+    const char *env = std::getenv("SCHWZ_SPMV_PAIR");
+    if (env && env[0] == '0') return SCHWZ_OK;
+    if (tiles.size() < 2) return SCHWZ_OK;
+    const int64_t nrows = tiles.back(), nnz = rp[nrows];
+    if (nnz == 0 || A->v.ncols < 2 || A->v.ncols >= INT32_MAX || nrows >= INT32_MAX - kPairRows) return SCHWZ_OK;
+    const int nchunks = (int)((nrows + kPairRows - 1) / kPairRows);
+    std::vector<uint8_t> pair_id((size_t)(nrows + 1) / 2, 0);
+    std::vector<schwz_idx> chunk_ptable((size_t)nchunks, -1);
+    std::vector<PairTable> tables;
+    std::unordered_multimap<uint64_t, int> by_hash;
+    std::vector<std::vector<PairEntryH>> pats;
+    std::vector<PairEntryH> cur;
+    int64_t coded = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        const int64_t r0 = (int64_t)c * kPairRows, r1 = std::min<int64_t>(r0 + kPairRows, nrows);
+        if (rp[r1] == rp[r0]) continue;
+        bool ok = true;
+        for (int64_t r = r0; r < r1 && ok; ++r) {
+            if (rp[r + 1] - rp[r] > 127) ok = false;
+            for (schwz_idx j = rp[r] + 1; j < rp[r + 1] && ok; ++j)
+                if (col[j] <= col[j - 1]) ok = false;  // merged order == each row's order needs sorted rows
+        }
+        if (!ok) continue;
+        pats.clear();
+        int lmax = 0;
+        for (int64_t ra = r0; ra < r1 && ok; ra += 2) {
+            const bool has_b = ra + 1 < r1;
+            cur.clear();
+            schwz_idx ja = rp[ra], ea = rp[ra + 1];
+            schwz_idx jb = has_b ? rp[ra + 1] : 0, eb = has_b ? rp[ra + 2] : 0;
+            while (ja < ea || jb < eb) {
+                const int64_t da = ja < ea ? (int64_t)col[ja] - ra : INT64_MAX;
+                const int64_t db = jb < eb ? (int64_t)col[jb] - (ra + 1) : INT64_MAX;
+                PairEntryH e = {0, 0, 0, 0};
+                const int64_t d = std::min(da, db);
+                e.off = (schwz_idx)d;
+                if (da == d) {
+                    e.flags |= 1;
+                    std::memcpy(&e.va, &val[ja], 8);
+                    ++ja;
+                }
+                if (db == d) {
+                    e.flags |= 2;
+                    std::memcpy(&e.vb, &val[jb], 8);
+                    ++jb;
+                }
+                cur.push_back(e);
+            }
+            int id = -1;
+            for (size_t q = 0; q < pats.size(); ++q)
+                if (pats[q] == cur) {
+                    id = (int)q;
+                    break;
+                }
+            if (id < 0) {
+                if ((int)pats.size() == kPairPats) {
+                    ok = false;
+                    break;
+                }
+                id = (int)pats.size();
+                lmax = std::max(lmax, (int)cur.size());
+                pats.push_back(cur);
+            }
+            pair_id[(size_t)(ra >> 1)] = (uint8_t)id;
+        }
+        lmax = std::max(lmax, 1);
+        if (!ok || (int64_t)pats.size() * pair_stride(lmax) > kPairEntries) continue;
+        PairTable tb;
+        tb.npat = (int)pats.size();
+        tb.lmax = lmax;
+        tb.len.resize((size_t)tb.npat);
+        tb.ent.assign((size_t)tb.npat * lmax, PairEntryH{0, 0, 0, 0});
+        uint64_t h = 1469598103934665603ull;
+        for (int q = 0; q < tb.npat; ++q) {
+            tb.len[(size_t)q] = (uint8_t)pats[(size_t)q].size();
+            for (size_t k = 0; k < pats[(size_t)q].size(); ++k) {
+                const PairEntryH &e = pats[(size_t)q][k];
+                tb.ent[(size_t)q * lmax + k] = e;
+                h = (h ^ e.va) * 1099511628211ull;
+                h = (h ^ e.vb) * 1099511628211ull;
+                h = (h ^ (uint64_t)(int64_t)e.off) * 1099511628211ull;
+                h = (h ^ (uint64_t)e.flags) * 1099511628211ull;
+            }
+            h = (h ^ 0xffull ^ (uint64_t)tb.len[(size_t)q]) * 1099511628211ull;
+        }
+        tb.hash = h;
+        int id = -1;
+        auto range = by_hash.equal_range(h);
+        for (auto it = range.first; it != range.second; ++it)
+            if (tables[(size_t)it->second].same(tb)) {
+                id = it->second;
+                break;
+            }
+        if (id < 0) {
+            id = (int)tables.size();
+            by_hash.emplace(h, id);
+            tables.push_back(std::move(tb));
+        }
+        chunk_ptable[(size_t)c] = id;
+        coded += rp[r1] - rp[r0];
+    }
+    A->pair_fraction = (double)coded / (double)nnz;
+    const bool force = env && env[0] == '2';
+    if (A->pair_fraction < 0.9 && !force) return SCHWZ_OK;
+    if (tables.size() * 4 > (size_t)nchunks && !force) return SCHWZ_OK;  // a table must be shared to pay off
+    std::vector<schwz_idx> desc, meta;
+    std::vector<uint8_t> lens;
+    std::vector<double> vals;
+    for (const PairTable &tb : tables) {
+        desc.push_back((schwz_idx)(vals.size() / 2));
+        desc.push_back((schwz_idx)lens.size());
+        desc.push_back(tb.npat);
+        desc.push_back(tb.lmax);
+        schwz_idx reach = 0;
+        for (const PairEntryH &e : tb.ent) reach = std::max<schwz_idx>(reach, e.off < 0 ? -e.off : e.off);
+        desc.push_back(reach);
+        lens.insert(lens.end(), tb.len.begin(), tb.len.end());
+        for (const PairEntryH &e : tb.ent) {
+            double va, vb;
+            std::memcpy(&va, &e.va, 8);
+            std::memcpy(&vb, &e.vb, 8);
+            vals.push_back(va);
+            vals.push_back(vb);
+            meta.push_back(e.off);
+            meta.push_back(e.flags);
+        }
+    }
+    int rc;
+    if ((rc = upv(pair_id, &A->d_pair_id)) || (rc = upv(chunk_ptable, &A->d_tile_ptable)) ||
+        (rc = upv(desc, &A->d_ptbl_desc)) || (rc = upv(lens, &A->d_ptbl_len)) || (rc = upv(vals, &A->d_ptbl_val)) ||
+        (rc = upv(meta, &A->d_ptbl_meta)))
+        return rc;
+    A->v.pair_id = (const uint8_t *)A->d_pair_id;
+    A->v.chunk_ptable = (const schwz_idx *)A->d_tile_ptable;
+    A->v.ptbl_desc = (const schwz_idx *)A->d_ptbl_desc;
+    A->v.ptbl_len = (const uint8_t *)A->d_ptbl_len;
+    A->v.ptbl_val = (const double *)A->d_ptbl_val;
+    A->v.ptbl_meta = (const schwz_idx *)A->d_ptbl_meta;
+    // the XCD deal of the chunks: the tile deal's run length in rows, in chunks (a power of two)
+    int sh = A->v.xcd_shift;
+    const int64_t rows_per_tile = std::max<int64_t>(1, nrows / std::max<int64_t>(1, (int64_t)tiles.size() - 1));
+    for (int64_t f = kPairRows / std::max<int64_t>(1, rows_per_tile); f > 1 && sh > 0; f >>= 1) --sh;
+    A->v.pair_shift = sh;
+    return SCHWZ_OK;
+}
+
+// chunks whose rows or columns reach `split` need the second product of the fused dual residual
+int pair_set_dual_split(schwz_csr *A, const schwz_idx *h_rp, const schwz_idx *h_col, int64_t split)
+{
+    if (!A->v.pair_id) return SCHWZ_OK;
+    const int64_t nrows = A->v.nrows;
+    const int nchunks = (int)((nrows + kPairRows - 1) / kPairRows);
+    std::vector<uint8_t> flag((size_t)nchunks, 0);
+    for (int c = 0; c < nchunks; ++c) {
+        const int64_t r0 = (int64_t)c * kPairRows, r1 = std::min<int64_t>(r0 + kPairRows, nrows);
+        bool f = r1 > split;
+        for (int64_t j = h_rp[r0]; j < h_rp[r1] && !f; ++j) f = h_col[j] >= split;
+        flag[(size_t)c] = f ? 1 : 0;
+    }
+    (void)hipFree(A->d_chunk_dual);
+    A->d_chunk_dual = nullptr;
+    int rc = upv(flag, &A->d_chunk_dual);
+    if (rc) return rc;
+    A->v.chunk_dual = (const uint8_t *)A->d_chunk_dual;
+    return SCHWZ_OK;
+}
+
+void free_spmv_pair(schwz_csr *A)
+{
+    void *ptrs[] = {A->d_pair_id, A->d_tile_ptable, A->d_ptbl_desc, A->d_ptbl_len, A->d_ptbl_val, A->d_ptbl_meta,
+                    A->d_chunk_dual};
+    for (void *p : ptrs) (void)hipFree(p);
+    A->d_pair_id = A->d_tile_ptable = A->d_ptbl_desc = A->d_ptbl_len = A->d_ptbl_val = A->d_ptbl_meta = nullptr;
+    A->d_chunk_dual = nullptr;
+    A->v.pair_id = nullptr;
+    A->v.chunk_dual = nullptr;
+}
+
+}  // namespace schwz

@@ -49,6 +49,10 @@ class Csr:
         check(lib.schwz_csr_spmv(self.h, alpha, ptr(d_x), beta, ptr(d_y), variant,
                                  _stream_arg(stream)))
 
+    def format(self):
+        """Coding variant 0 uses: 0 plain CSR, 1 per-entry dictionaries, 2 row patterns, 3 row pairs."""
+        return int(lib.schwz_csr_format(self.h))
+
     def algorithmic_bytes(self):
         # SURVEY 8(d): 12 nnz + 4 (rows+1) + 16 rows
         return 12 * self.nnz + 4 * (self.nrows + 1) + 16 * self.nrows

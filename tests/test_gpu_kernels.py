@@ -334,6 +334,71 @@ def _mixed_matrix(oracle, rng):
     return rp, col, val
 
 
+@pytest.mark.parametrize("case", ["lap3d_even", "lap3d_odd_rows", "lap2d", "ani3_forced", "mixed_forced",
+                                  "unsorted_rows"])
+def test_row_pair_coding_is_bit_identical_to_plain_csr(schwz, oracle, torch_cuda, monkeypatch, case):
+    """The row-pair coding (spmv_pair.hip, the default for stencil-like matrices): y = alpha A x +
+    beta y bit for bit equal to the plain CSR kernel and to the row-pattern kernel -- full and
+    partial last chunks, odd row counts (a pair without a second row), chunks that fall back to
+    CSR rows, the safe path near the first / last column -- and the fused epilogues through a
+    CG solve against the oracle.  Rows with unsorted columns must not be pair coded at all."""
+    torch = torch_cuda
+    rng = np.random.default_rng(31)
+    want = 3
+    if case == "lap3d_even":
+        rp, col, val = oracle.laplacian3d(64, 64, 40)
+    elif case == "lap3d_odd_rows":
+        rp, col, val = oracle.laplacian3d(45, 41, 39)     # 71955 rows: odd, partial last chunk
+    elif case == "lap2d":
+        rp, col, val = oracle.laplacian2d(301)
+    elif case == "ani3_forced":
+        monkeypatch.setenv("SCHWZ_SPMV_PAIR", "2")
+        monkeypatch.setenv("SCHWZ_SPMV_PATTERN", "2")
+        g = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "ani3_crop.npz"))
+        rp, col, val = g["rp"], g["col"], g["val"]
+    elif case == "mixed_forced":
+        monkeypatch.setenv("SCHWZ_SPMV_PAIR", "2")
+        monkeypatch.setenv("SCHWZ_SPMV_PATTERN", "2")
+        rp, col, val = _mixed_matrix(oracle, rng)
+    else:
+        rp, col, val = oracle.laplacian3d(40, 40, 40)
+        col, val = col.copy(), val.copy()
+        for i in range(0, len(rp) - 1, 7):               # swap two entries: same matrix, unsorted rows
+            s, e = rp[i], rp[i + 1]
+            if e - s >= 2:
+                col[s], col[s + 1] = col[s + 1], col[s]
+                val[s], val[s + 1] = val[s + 1], val[s]
+        want = None
+    n = len(rp) - 1
+    A = schwz.Csr(rp, col, val)
+    if want is None:
+        assert A.format() != 3
+    else:
+        assert A.format() == want
+    x = _dev(torch, rng.standard_normal(n))
+    y0 = _dev(torch, rng.standard_normal(n))
+    for alpha, beta in ((1.0, 0.0), (-0.75, 2.5)):
+        ys = {}
+        for v in (0, 8, 6):
+            ys[v] = y0.clone()
+            A.spmv(x.data_ptr(), ys[v].data_ptr(), alpha, beta, v)
+        torch.cuda.synchronize()
+        assert torch.equal(ys[0], ys[6]) and torch.equal(ys[8], ys[6])
+    exp = oracle.spmv(rp, col, val, x.cpu().numpy())
+    y = torch.zeros(n, dtype=torch.float64, device="cuda")
+    A.spmv(x.data_ptr(), y.data_ptr())
+    assert np.abs(y.cpu().numpy() - exp).max() <= 1e-12 * max(np.abs(exp).max(), 1.0)
+    if case in ("lap3d_even", "lap3d_odd_rows", "lap2d"):
+        b = rng.standard_normal(n)
+        cg = schwz.Pcg(A, 1)
+        expx, it_o, rn_o = oracle.pcg(rp, col, val, b, None, 1, 0.0, 12)
+        d_b, d_x = _dev(torch, b), torch.zeros(n, dtype=torch.float64, device="cuda")
+        it_g, rn_g = cg.solve(d_b.data_ptr(), d_x.data_ptr(), 0.0, 12)
+        assert it_g == it_o == 12
+        assert np.abs(d_x.cpu().numpy() - expx).max() <= RTOL_CG * np.abs(expx).max()
+        assert abs(rn_g - rn_o) <= 1e-8 * rn_o
+
+
 def test_coded_tiles_are_bit_identical_to_plain_csr(schwz, oracle, torch_cuda, monkeypatch):
     """Variant 0 (row-pattern coded tiles), variant 7 (per-entry dictionary tiles) and variant 6
     (plain CSR) sum the same individually rounded products in the same order => identical bits,

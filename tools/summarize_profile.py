@@ -21,7 +21,7 @@ import shutil
 import sys
 from collections import defaultdict
 
-DOMINANT = ("spmv_pattern_kernel<1,", "spmv_dict_kernel<1>", "spmv_tiled2_kernel<1>")  # first one present wins
+DOMINANT = ("spmv_pair_kernel<1,", "spmv_pattern_kernel<1,", "spmv_dict_kernel<1>", "spmv_tiled2_kernel<1>")  # first one present wins
 
 
 def read_counter(dirname, counter):
