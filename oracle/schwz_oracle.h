@@ -17,9 +17,12 @@
  *        (tests/golden/make_golden.py), and
  *   (ii) structural known answers derived by hand from the reference's index
  *        set construction (source/restricted_schwarz.cpp:56-304).
- * Third-party arithmetic the reference delegates to Ginkgo (CG recurrence,
- * Jacobi, triangular solves) and CHOLMOD (LL^T) is restated from the
- * published algorithms.
+ * Third-party arithmetic the reference delegates to Ginkgo (CG and GMRES
+ * recurrences, Jacobi / block-Jacobi, ILU(0) standing in for ParILU, ISAI,
+ * triangular solves) and CHOLMOD (LL^T) is restated from the published
+ * algorithms.  GMRES is additionally pinned by scipy's implementation (same
+ * inner iteration counts and solution, tests/test_oracle_golden.py), ILU(0) and
+ * ISAI by their defining identities on the sparsity pattern.
  */
 #ifndef SCHWZ_ORACLE_H
 #define SCHWZ_ORACLE_H
@@ -107,7 +110,7 @@ typedef struct {
     double tol;               /* metadata.tolerance (--set_tol) */
     int32_t overlap;          /* settings.overlap */
     int32_t local_solver;     /* OR_SOLVER_* (settings.local_solver) */
-    int32_t precond;          /* OR_PRECOND_* (block-jacobi, block size 1) */
+    int32_t precond;          /* OR_PRECOND_* */
     double local_tol;         /* metadata.local_solver_tolerance */
     int32_t local_max_iters;  /* -1 => local_size_x (solve.cpp:458-463) */
     int32_t enable_global_check;     /* convergence_settings.enable_global_check */
