@@ -84,10 +84,15 @@ struct SchwarzBase<ValueType, IndexType, MixedValueType>::Impl {
     int device = 0;
     double rhs_sq_interior = 0.0;
     ncclComm_t nccl = nullptr;  // halo exchange over RCCL; nullptr: staged through host over MPI
+    hipStream_t side = nullptr;  // overlapped mode: the halo transfers run here, beside the local solve
+    hipEvent_t ev_packed = nullptr, ev_arrived = nullptr;
 
     ~Impl()
     {
         if (nccl) (void)ncclCommDestroy(nccl);
+        if (side) (void)hipStreamDestroy(side);
+        if (ev_packed) (void)hipEventDestroy(ev_packed);
+        if (ev_arrived) (void)hipEventDestroy(ev_arrived);
         if (sd) schwz_subdomain_destroy(sd);
         if (problem) schwz_problem_destroy(problem);
         (void)hipFree(d_send);
@@ -443,7 +448,141 @@ void SchwarzBase<V, I, M>::run(std::shared_ptr<gko::matrix::Dense<V>> &solution)
     const double start = now();
     bool two_stage_on = false;
     SCHWZ_CALL(schwz_ras_set_local_max_iters(im.sd, (int)m.local_max_iters));
-    for (; m.iter_count < m.max_iters; ++m.iter_count) {
+    const bool overlapped = cs.enable_onesided && cs.enable_overlap;
+    if (overlapped) {
+        // The asynchronous flavour of this build (BASELINE config 5; same model as
+        // schwz_amd/solver.py::_step_overlapped and the oracle): the halo exchange of iteration k
+        // is posted before the local solve of iteration k -- on a side stream under RCCL -- and
+        // consumed at the start of iteration k + 1; there is no collective: every subdomain tests
+        // itself (solve.cpp:913-915) and floods (mask of converged subdomains, agreed stop
+        // iteration) to its neighbours with each message (conv_tools.hpp:213-275 on matched
+        // messages); the first full mask at iteration k proposes stop = k + P, the minimum wins.
+        if (P > 62) throw ::NotImplemented(__FILE__, __LINE__, "overlapped mode with more than 62 subdomains");
+        const long long never = 1LL << 62;
+        const unsigned long long full = (1ULL << P) - 1ULL;
+        unsigned long long mask = 0;
+        long long stop = never;
+        if (im.nccl && !im.side) {
+            HIP_CALL(hipStreamCreateWithFlags(&im.side, hipStreamNonBlocking));
+            HIP_CALL(hipEventCreateWithFlags(&im.ev_packed, hipEventDisableTiming));
+            HIP_CALL(hipEventCreateWithFlags(&im.ev_arrived, hipEventDisableTiming));
+        }
+        std::vector<long long> flag_out(2), flag_in((size_t)(2 * std::max(n_in, 1)));
+        std::vector<MPI_Request> freqs((size_t)(n_in + n_out));
+        bool pending = false;
+        int nreq_halo = 0, nreq_flag = 0;
+        for (; m.iter_count < m.max_iters; ++m.iter_count) {
+            const long long it = (long long)m.iter_count;
+            const double t0 = now();
+            if (s.reset_local_crit_iter != -1 && it > s.reset_local_crit_iter && !two_stage_on) {
+                SCHWZ_CALL(schwz_ras_set_local_max_iters(im.sd, (int)m.updated_max_iters));
+                two_stage_on = true;
+            }
+            // (a) consume what was posted one iteration ago
+            if (pending) {
+                if (im.nccl) {
+                    HIP_CALL(hipStreamWaitEvent(im.stream, im.ev_arrived, 0));
+                } else {
+                    MPI_Waitall(nreq_halo, reqs.data(), MPI_STATUSES_IGNORE);
+                    if (im.sizes[8] > 0)
+                        HIP_CALL(hipMemcpyAsync(im.d_recv, im.h_recv, (size_t)im.sizes[8] * sizeof(double),
+                                                hipMemcpyHostToDevice, im.stream));
+                }
+                SCHWZ_CALL(schwz_ras_unpack(im.sd, im.d_recv, im.stream));
+                MPI_Waitall(nreq_flag, freqs.data(), MPI_STATUSES_IGNORE);
+                for (int k = 0; k < n_in; ++k) {
+                    mask |= (unsigned long long)flag_in[(size_t)(2 * k)];
+                    stop = std::min(stop, flag_in[(size_t)(2 * k + 1)]);
+                }
+                pending = false;
+            }
+            const bool last = it == (long long)m.max_iters - 1 || stop == it;
+            // (b) post this iteration's halos: x~ after the previous restriction
+            if (!last) {
+                SCHWZ_CALL(schwz_ras_pack(im.sd, im.d_send, im.stream));
+                if (im.nccl) {
+                    HIP_CALL(hipEventRecord(im.ev_packed, im.stream));
+                    HIP_CALL(hipStreamWaitEvent(im.side, im.ev_packed, 0));
+                    NCCL_CALL(ncclGroupStart());
+                    for (int k = 0; k < n_in; ++k)
+                        NCCL_CALL(ncclRecv(im.d_recv + im.recv_off[(size_t)k],
+                                           (size_t)(im.recv_off[(size_t)k + 1] - im.recv_off[(size_t)k]), ncclDouble,
+                                           im.nbr_in[(size_t)k], im.nccl, im.side));
+                    for (int k = 0; k < n_out; ++k)
+                        NCCL_CALL(ncclSend(im.d_send + im.send_off[(size_t)k],
+                                           (size_t)(im.send_off[(size_t)k + 1] - im.send_off[(size_t)k]), ncclDouble,
+                                           im.nbr_out[(size_t)k], im.nccl, im.side));
+                    NCCL_CALL(ncclGroupEnd());
+                    HIP_CALL(hipEventRecord(im.ev_arrived, im.side));
+                } else {
+                    if (im.sizes[9] > 0) {
+                        HIP_CALL(hipMemcpyAsync(im.h_send, im.d_send, (size_t)im.sizes[9] * sizeof(double),
+                                                hipMemcpyDeviceToHost, im.stream));
+                        HIP_CALL(hipStreamSynchronize(im.stream));
+                    }
+                    nreq_halo = 0;
+                    for (int k = 0; k < n_in; ++k)
+                        MPI_Irecv(im.h_recv + im.recv_off[(size_t)k],
+                                  (int)(im.recv_off[(size_t)k + 1] - im.recv_off[(size_t)k]), MPI_DOUBLE,
+                                  im.nbr_in[(size_t)k], 0, MPI_COMM_WORLD, &reqs[(size_t)nreq_halo++]);
+                    for (int k = 0; k < n_out; ++k)
+                        MPI_Isend(im.h_send + im.send_off[(size_t)k],
+                                  (int)(im.send_off[(size_t)k + 1] - im.send_off[(size_t)k]), MPI_DOUBLE,
+                                  im.nbr_out[(size_t)k], 0, MPI_COMM_WORLD, &reqs[(size_t)nreq_halo++]);
+                }
+            }
+            const double t1 = now();
+            // (c) boundary update, local test + local solve (enqueued together), restriction
+            SCHWZ_CALL(schwz_ras_update_boundary(im.sd, im.stream));
+            const double t2 = now();
+            local_res = -1.0;
+            if (tol >= 0.0) {
+                SCHWZ_CALL(schwz_ras_check_and_solve_launch(im.sd, im.stream));
+                double r = 0.0;
+                SCHWZ_CALL(schwz_ras_local_residual_wait(im.sd, &r));
+                local_res = (V)r;
+                if (local_res0 < 0.0) local_res0 = local_res;
+            } else {
+                SCHWZ_CALL(schwz_ras_local_solve(im.sd, nullptr, im.stream));
+            }
+            if (std::isnan(local_res)) std::exit(-1);  // solve.cpp:982-984
+            ppd.local_residual_vector_out.push_back(local_res);
+            ppd.local_converged_resnorm.push_back(local_res / local_res0);
+            m.current_residual_norm = local_res;
+            if (tol > 0.0 && local_res / local_res0 <= tol) mask |= 1ULL << me;
+            if (mask == full && stop == never) stop = it + P;
+            if (!last) {
+                flag_out[0] = (long long)mask;
+                flag_out[1] = stop;
+                nreq_flag = 0;
+                for (int k = 0; k < n_in; ++k)
+                    MPI_Irecv(&flag_in[(size_t)(2 * k)], 2, MPI_LONG_LONG, im.nbr_in[(size_t)k], 7, MPI_COMM_WORLD,
+                              &freqs[(size_t)nreq_flag++]);
+                for (int k = 0; k < n_out; ++k)
+                    MPI_Isend(flag_out.data(), 2, MPI_LONG_LONG, im.nbr_out[(size_t)k], 7, MPI_COMM_WORLD,
+                              &freqs[(size_t)nreq_flag++]);
+                pending = true;
+            }
+            const double t3 = now();
+            timings[0].push_back((V)(t1 - t0));
+            timings[1].push_back((V)(t2 - t1));
+            timings[2].push_back((V)(t3 - t2));
+            if (stop == it) {
+                num_converged = P;
+                break;
+            }
+            const double t4 = now();
+            SCHWZ_CALL(schwz_ras_restrict(im.sd, im.stream));
+            timings[3].push_back((V)(t4 - t3));
+            timings[4].push_back((V)(now() - t4));
+        }
+        if (pending) {  // only when the iteration cap ended the loop with messages in flight
+            if (im.nccl) HIP_CALL(hipStreamWaitEvent(im.stream, im.ev_arrived, 0));
+            else MPI_Waitall(nreq_halo, reqs.data(), MPI_STATUSES_IGNORE);
+            MPI_Waitall(nreq_flag, freqs.data(), MPI_STATUSES_IGNORE);
+        }
+    }
+    for (; !overlapped && m.iter_count < m.max_iters; ++m.iter_count) {
         const auto it = m.iter_count;
         const double t0 = now();
         if (s.reset_local_crit_iter != -1 && it > s.reset_local_crit_iter && !two_stage_on) {

@@ -139,3 +139,21 @@ def test_bench_ras_halo_transport_selection(oracle):
     assert iters_of(out) == {ref1["iter_count"]}
     out = _run(1, *base, env={"SCHWZ_HALO": "mpi"})
     assert "staged through host over MPI" in out and iters_of(out) == {ref1["iter_count"]}
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_bench_ras_overlapped_onesided_matches_oracle(oracle, nranks):
+    """--enable_onesided --enable_comm_overlap --global_convergence_type=decentralized: halos one
+    iteration late, decentralised stop agreement (BASELINE config 5 flavour) through the unchanged
+    driver.  The model is deterministic: same outer iteration count as the oracle."""
+    n = 24
+    out = _run(nranks, "--explicit_laplacian", "--set_1d_laplacian_size=%d" % n, "--num_iters=600",
+               "--set_tol=1e-6", "--enable_onesided", "--enable_comm_overlap", "--global_convergence_type=decentralized")
+    iters = sorted(set(int(x) for x in re.findall(r"converged in (\d+) iterations", out)))
+    rp, col, val = oracle.laplacian2d(n)
+    N = n * n
+    ref = oracle.ras_run(rp, col, val, np.ones(N), nranks, oracle.first_rows_regular(N, nranks),
+                         oracle.make_settings(max_iters=600, tol=1e-6, enable_onesided=1, enable_overlap=1))
+    assert ref["converged"] and iters == [ref["iter_count"]], out
+    rel = float(re.search(r"relative residual norm of solution ([0-9.eE+-]+)", out).group(1))
+    assert abs(rel - ref["residual_norm"] / ref["rhs_norm"]) <= 1e-6 * rel + 1e-12
