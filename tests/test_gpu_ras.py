@@ -128,6 +128,18 @@ def test_two_stage_local_criterion_matches_oracle(schwz, oracle, torch_cuda):
     assert out["converged"] and out["iter_count"] < out1["iter_count"]
 
 
+@pytest.mark.parametrize("P", [3, 5])
+@pytest.mark.parametrize("solver_kind", ["iterative-ginkgo", "direct-ginkgo"])
+def test_more_subdomains_than_rows_leaves_empty_subdomains(schwz, oracle, torch_cuda, P, solver_kind):
+    """Edge case: a 2x2 grid (4 rows) on 3 and 5 subdomains -- the regular partition leaves the
+    last subdomain(s) without rows.  Empty subdomains must take part in the exchange and the
+    convergence rule without launching anything."""
+    solver, m, out = _run_gpu(schwz, P, dict(local_solver=solver_kind),
+                              dict(oned_laplacian_size=2, tolerance=1e-8, max_iters=50))
+    _check_against_oracle(oracle, oracle.laplacian2d(2), P, solver, m, out)
+    assert out["converged"] and np.allclose(out["solution"], 0.5)
+
+
 @pytest.mark.parametrize("P", [2, 8])
 def test_ras_3d_fixed_inner_work_matches_oracle(schwz, oracle, torch_cuda, P):
     """The bench operating point: CG + scalar Jacobi, K inner iterations, local_tol=0."""
