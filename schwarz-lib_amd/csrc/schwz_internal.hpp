@@ -78,6 +78,7 @@ struct CsrView {
     const schwz_idx *chunk_ptable = nullptr; // per chunk of 512 rows: pair table id, -1 = not pair coded
     const uint8_t *chunk_dual = nullptr;     // per chunk: the fused dual residual needs its second product
     int pair_shift = 0;                      // log2 of the run length of the XCD deal of the chunks
+    int pair_single = 0;                     // 1: every chunk uses table 0
     const schwz_idx *ptbl_desc = nullptr;    // per table: {entry offset, len offset, npat, lmax, max |col - row|}
     const uint8_t *ptbl_len = nullptr;
     const double *ptbl_val = nullptr;        // 2 per entry

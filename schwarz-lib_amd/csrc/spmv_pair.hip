@@ -54,7 +54,9 @@ __device__ __forceinline__ int xcd_chunk(int nchunks, int sh, int xcd, int j)
     return c < nchunks ? c : -1;
 }
 
-template <int MODE, bool WIDE>
+// SINGLE: the whole matrix shares one table (every chunk is coded with table 0): it is staged once
+// and no per-chunk lookup precedes the pattern ids.
+template <int MODE, bool WIDE, bool SINGLE>
 __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a)
 {
 #pragma clang fp contract(off)
@@ -191,12 +193,13 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
 
     // Fixed chunks of 512 consecutive rows, one pair per lane: nothing but the chunk's table id has
     // to be looked up before the pattern ids and the gathers can be requested.
+    if (SINGLE) stage_table(0);
     for (int j = slot; j < slots; j += per_xcd) {
         const int chunk = xcd_chunk(nchunks, sh, xcd, j);
         if (chunk < 0) continue;
-        const int tb = A.chunk_ptable[chunk];
+        const int tb = SINGLE ? 0 : A.chunk_ptable[chunk];
         const bool dual_t = dual && (!A.chunk_dual || A.chunk_dual[chunk]);
-        if (tb >= 0 && tb != cached) stage_table(tb);
+        if (!SINGLE && tb >= 0 && tb != cached) stage_table(tb);
         const int ra = chunk * kPairRows + 2 * tid;
         if (ra >= nrows) continue;
         const bool has_b = ra + 1 < nrows;
@@ -274,11 +277,13 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
 int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s)
 {
     const bool wide = A.ncols >= (int64_t(1) << 28);  // byte offsets of x beyond 32 bits
-#define SCHWZ_PAIR_LAUNCH(M)                                                                  \
-    if (wide)                                                                                 \
-        hipLaunchKernelGGL((spmv_pair_kernel<M, true>), dim3(grid), dim3(kBlock), 0, s, A, a); \
-    else                                                                                      \
-        hipLaunchKernelGGL((spmv_pair_kernel<M, false>), dim3(grid), dim3(kBlock), 0, s, A, a);
+#define SCHWZ_PAIR_LAUNCH(M)                                                                          \
+    if (wide)                                                                                         \
+        hipLaunchKernelGGL((spmv_pair_kernel<M, true, false>), dim3(grid), dim3(kBlock), 0, s, A, a);  \
+    else if (A.pair_single)                                                                           \
+        hipLaunchKernelGGL((spmv_pair_kernel<M, false, true>), dim3(grid), dim3(kBlock), 0, s, A, a);  \
+    else                                                                                              \
+        hipLaunchKernelGGL((spmv_pair_kernel<M, false, false>), dim3(grid), dim3(kBlock), 0, s, A, a);
     switch (mode) {
     case kSpmvPlain: SCHWZ_PAIR_LAUNCH(kSpmvPlain) break;
     case kSpmvDot: SCHWZ_PAIR_LAUNCH(kSpmvDot) break;
@@ -337,7 +342,87 @@ int build_spmv_pair(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, con
     std::vector<std::vector<PairEntryH>> pats;
     std::vector<PairEntryH> cur;
     int64_t coded = 0;
-    for (int c = 0; c < nchunks; ++c) {
+    // merged (offset, values, presence) sequence of the pair starting at row ra
+    auto merge_pair = [&](int64_t ra, bool has_b) {
+        cur.clear();
+        schwz_idx ja = rp[ra], ea = rp[ra + 1];
+        schwz_idx jb = has_b ? rp[ra + 1] : 0, eb = has_b ? rp[ra + 2] : 0;
+        while (ja < ea || jb < eb) {
+            const int64_t da = ja < ea ? (int64_t)col[ja] - ra : INT64_MAX;
+            const int64_t db = jb < eb ? (int64_t)col[jb] - (ra + 1) : INT64_MAX;
+            PairEntryH e = {0, 0, 0, 0};
+            const int64_t d = std::min(da, db);
+            e.off = (schwz_idx)d;
+            if (da == d) {
+                e.flags |= 1;
+                std::memcpy(&e.va, &val[ja], 8);
+                ++ja;
+            }
+            if (db == d) {
+                e.flags |= 2;
+                std::memcpy(&e.vb, &val[jb], 8);
+                ++jb;
+            }
+            cur.push_back(e);
+        }
+    };
+    // First choice: ONE table for the whole matrix (a constant-coefficient stencil has a few dozen
+    // distinct pairs in total); the kernel then stages it once and looks nothing up per chunk.
+    bool single = !(env && env[0] == '3');  // SCHWZ_SPMV_PAIR=3: per-chunk tables even if one would do
+    {
+        bool sorted = true;
+        for (int64_t r = 0; r < nrows && sorted; ++r) {
+            if (rp[r + 1] - rp[r] > 127) sorted = false;
+            for (schwz_idx j = rp[r] + 1; j < rp[r + 1] && sorted; ++j)
+                if (col[j] <= col[j - 1]) sorted = false;
+        }
+        single = single && sorted;
+        int lmax = 1;
+        std::unordered_multimap<uint64_t, int> seen;
+        for (int64_t ra = 0; ra < nrows && single; ra += 2) {
+            merge_pair(ra, ra + 1 < nrows);
+            uint64_t h = 1469598103934665603ull;
+            for (const PairEntryH &e : cur) {
+                h = (h ^ e.va) * 1099511628211ull;
+                h = (h ^ e.vb) * 1099511628211ull;
+                h = (h ^ (uint64_t)(int64_t)e.off) * 1099511628211ull;
+                h = (h ^ (uint64_t)e.flags) * 1099511628211ull;
+            }
+            int id = -1;
+            auto range = seen.equal_range(h);
+            for (auto it = range.first; it != range.second; ++it)
+                if (pats[(size_t)it->second] == cur) {
+                    id = it->second;
+                    break;
+                }
+            if (id < 0) {
+                id = (int)pats.size();
+                lmax = std::max(lmax, (int)cur.size());
+                if (id == kPairPats || (int64_t)(id + 1) * pair_stride(lmax) > kPairEntries) {
+                    single = false;
+                    break;
+                }
+                seen.emplace(h, id);
+                pats.push_back(cur);
+            }
+            pair_id[(size_t)(ra >> 1)] = (uint8_t)id;
+        }
+        if (single) {
+            PairTable tb;
+            tb.npat = (int)pats.size();
+            tb.lmax = lmax;
+            tb.len.resize((size_t)tb.npat);
+            tb.ent.assign((size_t)tb.npat * lmax, PairEntryH{0, 0, 0, 0});
+            for (int q = 0; q < tb.npat; ++q) {
+                tb.len[(size_t)q] = (uint8_t)pats[(size_t)q].size();
+                for (size_t k = 0; k < pats[(size_t)q].size(); ++k) tb.ent[(size_t)q * lmax + k] = pats[(size_t)q][k];
+            }
+            tables.push_back(std::move(tb));
+            std::fill(chunk_ptable.begin(), chunk_ptable.end(), 0);
+            coded = nnz;
+        }
+    }
+    for (int c = 0; c < nchunks && !single; ++c) {
         const int64_t r0 = (int64_t)c * kPairRows, r1 = std::min<int64_t>(r0 + kPairRows, nrows);
         if (rp[r1] == rp[r0]) continue;
         bool ok = true;
@@ -350,28 +435,7 @@ int build_spmv_pair(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, con
         pats.clear();
         int lmax = 0;
         for (int64_t ra = r0; ra < r1 && ok; ra += 2) {
-            const bool has_b = ra + 1 < r1;
-            cur.clear();
-            schwz_idx ja = rp[ra], ea = rp[ra + 1];
-            schwz_idx jb = has_b ? rp[ra + 1] : 0, eb = has_b ? rp[ra + 2] : 0;
-            while (ja < ea || jb < eb) {
-                const int64_t da = ja < ea ? (int64_t)col[ja] - ra : INT64_MAX;
-                const int64_t db = jb < eb ? (int64_t)col[jb] - (ra + 1) : INT64_MAX;
-                PairEntryH e = {0, 0, 0, 0};
-                const int64_t d = std::min(da, db);
-                e.off = (schwz_idx)d;
-                if (da == d) {
-                    e.flags |= 1;
-                    std::memcpy(&e.va, &val[ja], 8);
-                    ++ja;
-                }
-                if (db == d) {
-                    e.flags |= 2;
-                    std::memcpy(&e.vb, &val[jb], 8);
-                    ++jb;
-                }
-                cur.push_back(e);
-            }
+            merge_pair(ra, ra + 1 < r1);
             int id = -1;
             for (size_t q = 0; q < pats.size(); ++q)
                 if (pats[q] == cur) {
@@ -428,7 +492,7 @@ int build_spmv_pair(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, con
     A->pair_fraction = (double)coded / (double)nnz;
     const bool force = env && env[0] == '2';
     if (A->pair_fraction < 0.9 && !force) return SCHWZ_OK;
-    if (tables.size() * 4 > (size_t)nchunks && !force) return SCHWZ_OK;  // a table must be shared to pay off
+    if (!single && tables.size() * 4 > (size_t)nchunks && !force) return SCHWZ_OK;  // tables must be shared to pay off
     std::vector<schwz_idx> desc, meta;
     std::vector<uint8_t> lens;
     std::vector<double> vals;
@@ -462,6 +526,7 @@ int build_spmv_pair(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, con
     A->v.ptbl_len = (const uint8_t *)A->d_ptbl_len;
     A->v.ptbl_val = (const double *)A->d_ptbl_val;
     A->v.ptbl_meta = (const schwz_idx *)A->d_ptbl_meta;
+    A->v.pair_single = single ? 1 : 0;
     // the XCD deal of the chunks: the tile deal's run length in rows, in chunks (a power of two)
     int sh = A->v.xcd_shift;
     const int64_t rows_per_tile = std::max<int64_t>(1, nrows / std::max<int64_t>(1, (int64_t)tiles.size() - 1));
