@@ -770,6 +770,10 @@ int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipS
         break;                                                                                         \
     }
     if (variant == 0 && A.pair_id) return launch_spmv_pair(A, mode, a, grid, s);
+    if (mode == kSpmvDotOnly || mode == kSpmvCgUpdate) {
+        set_error("launch_spmv: the q-free CG modes exist for row-pair coded matrices only");
+        return SCHWZ_ERR_INVALID;
+    }
     if ((variant == 0 || variant == 8) && A.pat_id) return launch_spmv_pattern(A, mode, a, grid, s);
     if ((variant == 0 || variant == 7) && A.code) return launch_spmv_dict(A, mode, a, grid, s);
     if (variant >= 10 && variant < 74 && mode == kSpmvPlain) {
@@ -2004,6 +2008,12 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
     double *part_vec = s->partials + 3 * kMaxGrid;  // [2][gv]
     const bool poll = rtol > 0.0;
     const bool general = pcg_is_general(s);
+    // SCHWZ_CG_QFREE=0 keeps the stored-q iteration for row-pair coded matrices too (A/B runs)
+    static const bool qfree_on = [] {
+        const char *e = std::getenv("SCHWZ_CG_QFREE");
+        return !(e && e[0] == '0');
+    }();
+    const bool qfree = qfree_on && !general && A.pair_id && s->variant == 0 && s->diag.mode != 2;
     int chunk = 16;
     int it = 0, pending = -1, bank = 0;
     bool stopped = false;
@@ -2018,11 +2028,32 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
             a.it = it;
             const bool prof = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
             if (prof) SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used], st));
-            int rc = launch_spmv(A, kSpmvDot, a, s->variant, st);
+            int rc = launch_spmv(A, qfree ? kSpmvDotOnly : kSpmvDot, a, s->variant, st);
             if (rc) return rc;
             if (prof) {
                 SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used + 1], st));
                 g_prof.used += 2;
+            }
+            if (qfree) {
+                // q = A p is never stored: the update pass recomputes (A p)_i row by row while it
+                // streams x and r (spmv_pair.hip, kSpmvCgUpdate): 16 B per row less HBM traffic, a
+                // third of the stores of these two launches
+                SpmvArgs u;
+                u.x = s->p;
+                u.cg_x = d_x;
+                u.cg_r = s->r;
+                u.cg_state = s->state;
+                u.pq_partials = part_spmv;
+                u.pq_nparts = gs;
+                u.diag_mode = s->diag.mode;
+                u.diag_uniform = s->diag.uniform;
+                u.dinv = s->dinv;
+                u.partials = part_vec;
+                u.it = it;
+                if ((rc = launch_spmv(A, kSpmvCgUpdate, u, s->variant, st))) return rc;
+                hipLaunchKernelGGL((cg_direction_kernel<1, false>), dim3(gv), dim3(kBlock), 0, st, n, s->p, s->r, s->diag,
+                                   part_vec, gs, s->state, it, rtol);
+                continue;
             }
 #define SCHWZ_LAUNCH_UPDATE(U, NT)                                                                        \
     hipLaunchKernelGGL((cg_update_kernel<U, NT>), dim3(gv), dim3(kBlock), 0, st, n, d_x, s->r, s->p, s->q, \

@@ -94,7 +94,12 @@ enum SpmvMode {
     // kSpmvResidInit on x plus, in the same pass over the matrix, the partial sum
     // (b - A*x2)^2 over rows < row_limit (third partial bank): the convergence-check
     // residual (solve.cpp:834-841) and the CG start residual share one matrix read
-    kSpmvResidDual = 4
+    kSpmvResidDual = 4,
+    // row-pair kernel only (spmv_pair.hip): the CG iteration without a stored q = A p.
+    kSpmvDotOnly = 5,    // partial sum x_i*(A x)_i, nothing stored
+    // alpha = rho / fold(p.q partials); per row q_i = (A p)_i recomputed, x_i += alpha p_i,
+    // r_i -= alpha q_i, partials r.z and r.r (what cg_update_kernel does, minus 16 B/row of q)
+    kSpmvCgUpdate = 6
 };
 
 struct SpmvArgs {
@@ -109,6 +114,13 @@ struct SpmvArgs {
     const int *stop_iter = nullptr;  // device flag checked by CG launches
     int it = 0;
     int64_t row_limit = 0;  // rows >= row_limit are skipped in kSpmvResidNorm
+    // kSpmvCgUpdate
+    double *cg_x = nullptr, *cg_r = nullptr;
+    const struct CgState *cg_state = nullptr;
+    const double *pq_partials = nullptr;
+    int pq_nparts = 0;
+    int diag_mode = 0;          // 0 none, 1 full vector (dinv), 3 uniform scalar
+    double diag_uniform = 1.0;
 };
 
 int spmv_grid(const CsrView &A, int variant);

@@ -64,10 +64,15 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
     __shared__ int poff[kPairEntries];             // col - row of the entry
     __shared__ int pmask[kPairEntries / kPairChunk];  // per chunk: bit k = row r has entry k, bit 8+k = row r+1
     __shared__ int plen[kPairPats];
-    if (MODE == kSpmvDot || MODE == kSpmvResidInit) {
+    if (MODE == kSpmvDot || MODE == kSpmvResidInit || MODE == kSpmvDotOnly) {
         if (a.stop_iter && a.it >= *a.stop_iter) return;
     }
     __shared__ double red[4];
+    double cg_alpha = 0.0;
+    if (MODE == kSpmvCgUpdate) {
+        if (a.it >= a.cg_state->stop_iter) return;
+        cg_alpha = a.cg_state->rho[a.it & 1] / fold_partials(a.pq_partials, a.pq_nparts, red);
+    }
     const int tid = threadIdx.x;
     const int xcd = blockIdx.x % kXcds;
     const int slot = blockIdx.x / kXcds;
@@ -78,6 +83,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
     const int slots = ((nchunks + (kXcds << sh) - 1) >> (sh + 3)) << sh;  // sequence slots per XCD
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
     const bool dual = (MODE == kSpmvResidDual) && a.x2 != nullptr;
+    constexpr bool kWantOwn = MODE == kSpmvDot || MODE == kSpmvDotOnly || MODE == kSpmvCgUpdate;  // x[row] itself
     int cached = -1, ls = 0, reach = 0;  // staged table, its row stride, its largest |col - row|
 
     auto stage_table = [&](int tb) {  // workgroup-uniform
@@ -170,8 +176,16 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
         pz = 0.0;
         if (MODE == kSpmvPlain) {
             yv = (a.beta == 0.0) ? a.alpha * sum : a.alpha * sum + a.beta * ob;
-        } else if (MODE == kSpmvDot) {
+        } else if (MODE == kSpmvDot || MODE == kSpmvDotOnly) {
             acc0 += ox * sum;
+        } else if (MODE == kSpmvCgUpdate) {
+            // ob: r_i, od: 1/diag_i, ox: p_i, sum: q_i = (A p)_i; yv <- new r_i; pz <- alpha p_i (x increment)
+            const double r = ob - cg_alpha * sum;
+            const double z = a.diag_mode ? od * r : r;
+            yv = r;
+            pz = cg_alpha * ox;
+            acc0 += r * z;
+            acc1 += r * r;
         } else if (MODE == kSpmvResidInit || MODE == kSpmvResidDual) {
             const double r = ob - sum;
             const double z = a.dinv ? od * r : r;
@@ -217,6 +231,25 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
             ob0 = a.y[ra];
             if (has_b) ob1 = a.y[ra + 1];
         }
+        pvd2 cgx = {0.0, 0.0};
+        if (MODE == kSpmvCgUpdate) {  // r and x of the pair, 1/diag
+            if (has_b) {
+                pvd2 rr;
+                __builtin_memcpy(&rr, a.cg_r + ra, 16);
+                __builtin_memcpy(&cgx, a.cg_x + ra, 16);
+                ob0 = rr.x;
+                ob1 = rr.y;
+            } else {
+                ob0 = a.cg_r[ra];
+                cgx.x = a.cg_x[ra];
+            }
+            if (a.diag_mode == 1) {
+                od0 = a.dinv[ra];
+                if (has_b) od1 = a.dinv[ra + 1];
+            } else if (a.diag_mode == 3) {
+                od0 = od1 = a.diag_uniform;
+            }
+        }
         double s0 = 0.0, s1 = 0.0, t0 = 0.0, t1 = 0.0;
         pvd2 own = {0.0, 0.0};
         bool own_from_gathers = false;
@@ -228,7 +261,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
             const bool safe = __builtin_amdgcn_ballot_w64(edge) != 0;
             // the fused dot needs x[ra], x[ra + 1]: the padding entries (col - row = 0) gather exactly
             // that pair, as does a diagonal entry; waves on the safe path load it themselves
-            own_from_gathers = MODE == kSpmvDot && !safe && (len % kPairChunk) != 0;
+            own_from_gathers = kWantOwn && !safe && (len % kPairChunk) != 0;
             pvd2 unused = {0.0, 0.0};
             accumulate(a.x, ra, base, len, safe, s0, s1, own, own_from_gathers);
             if (dual_t) accumulate(a.x2, ra, base, len, safe, t0, t1, unused, false);
@@ -236,14 +269,24 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
             plain_row(ra, dual_t, s0, t0);
             if (has_b) plain_row(ra + 1, dual_t, s1, t1);
         }
-        if (MODE == kSpmvDot && !own_from_gathers) {
+        if (kWantOwn && !own_from_gathers) {
             own.x = a.x[ra];
             if (has_b) own.y = a.x[ra + 1];
         }
         double y0, y1 = 0.0, p0, p1 = 0.0;
         finish(ra, s0, t0, dual_t, own.x, ob0, od0, y0, p0);
         if (has_b) finish(ra + 1, s1, t1, dual_t, own.y, ob1, od1, y1, p1);
-        if (MODE != kSpmvResidNorm) {
+        if (MODE == kSpmvCgUpdate) {
+            if (has_b) {
+                const pvd2 rr = {y0, y1};
+                const pvd2 xx = {cgx.x + p0, cgx.y + p1};
+                __builtin_memcpy(a.cg_r + ra, &rr, 16);
+                __builtin_memcpy(a.cg_x + ra, &xx, 16);
+            } else {
+                a.cg_r[ra] = y0;
+                a.cg_x[ra] = cgx.x + p0;
+            }
+        } else if (MODE != kSpmvResidNorm && MODE != kSpmvDotOnly) {
             if (has_b) {
                 const pvd2 yy = {y0, y1};
                 __builtin_memcpy(a.y + ra, &yy, 16);
@@ -289,6 +332,8 @@ int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hi
     case kSpmvDot: SCHWZ_PAIR_LAUNCH(kSpmvDot) break;
     case kSpmvResidInit: SCHWZ_PAIR_LAUNCH(kSpmvResidInit) break;
     case kSpmvResidDual: SCHWZ_PAIR_LAUNCH(kSpmvResidDual) break;
+    case kSpmvDotOnly: SCHWZ_PAIR_LAUNCH(kSpmvDotOnly) break;
+    case kSpmvCgUpdate: SCHWZ_PAIR_LAUNCH(kSpmvCgUpdate) break;
     default: SCHWZ_PAIR_LAUNCH(kSpmvResidNorm) break;
     }
 #undef SCHWZ_PAIR_LAUNCH
