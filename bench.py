@@ -161,7 +161,7 @@ def main():
     # event record costs ~5 us of GPU idle (measured with rocprofv3 --kernel-trace), which
     # would tax the headline value; the kernel durations themselves are unaffected.
     import ctypes
-    schwz.capi.check(schwz.capi.lib.schwz_profile_begin(a.steps * a.inner + 8))
+    schwz.capi.check(schwz.capi.lib.schwz_profile_begin(2 * a.steps * a.inner + 8))
     t1 = time.perf_counter()
     for _ in range(a.steps):
         solver.step()
@@ -173,27 +173,47 @@ def main():
     if N > 1:
         elapsed = max(comm.allgather_scalars({rank: elapsed}))
         elapsed_instrumented = max(comm.allgather_scalars({rank: elapsed_instrumented}))
+    upd_ms, upd_launches = ctypes.c_double(0.0), ctypes.c_int64(0)
+    schwz.capi.check(schwz.capi.lib.schwz_profile_kind(1, ctypes.byref(upd_ms), ctypes.byref(upd_launches)))
     iters_per_s = a.steps / elapsed
     alg_spmv = sd.algorithmic_bytes(0)
-    avg_ms = tot_ms.value / max(launches.value, 1)
-    achieved = alg_spmv / (avg_ms * 1e-3) / 1e9 if launches.value else 0.0
+    n_rows = sd.local_size_x
     hist = m.post_process_data["global_residual_vector_out"]
     fmt = int(schwz.capi.lib.schwz_csr_format(sd_csr(sd, schwz))) if a.spmv_variant == 0 else 0
     dict_coded = fmt != 0
-    kernel_name = {3: "spmv_pair_kernel<kSpmvDot> (q = A p, fused p.q; row-pair pattern coded CSR tiles)",
-                   2: "spmv_pattern_kernel<kSpmvDot> (q = A p, fused p.q; row-pattern coded CSR tiles)",
-                   1: "spmv_dict_kernel<kSpmvDot> (q = A p, fused p.q; dictionary-coded CSR tiles)",
-                   0: "spmv_tiled2_kernel<kSpmvDot> (q = A p, fused p.q; plain CSR)"}[fmt]
+    qfree = upd_launches.value > 0
+    spmv_avg_ms = tot_ms.value / max(launches.value, 1)
+    spmv_name = {3: "spmv_pair_kernel<kSpmvDot> (q = A p, fused p.q; row-pair pattern coded CSR)",
+                 2: "spmv_pattern_kernel<kSpmvDot> (q = A p, fused p.q; row-pattern coded CSR tiles)",
+                 1: "spmv_dict_kernel<kSpmvDot> (q = A p, fused p.q; dictionary-coded CSR tiles)",
+                 0: "spmv_tiled2_kernel<kSpmvDot> (q = A p, fused p.q; plain CSR)"}[fmt]
+    spmv_tag = {3: "spmv_pair_kernel<1,", 2: "spmv_pattern_kernel<1,", 1: "spmv_dict_kernel<1>",
+                0: "spmv_tiled2_kernel<1>"}[fmt]
+    if qfree:
+        # q-free CG iteration (row-pair coded matrix): the launch that recomputes (A p)_i row by row
+        # while it updates x and r is the longest one.  Algorithmic bytes, SURVEY 8(d): the SpMV
+        # (B_spmv) + the x and r updates (2 x 24n) + Jacobi (24n) + the r.z dot (16n) + the norm (8n).
+        kernel_name = ("spmv_pair_kernel<kSpmvCgUpdate> (row-pair coded A: q_i = (A p)_i recomputed, "
+                       "x += alpha p, r -= alpha q, z = D^-1 r, partial r.z and r.r)")
+        dom_tag = "spmv_pair_kernel<6,"
+        alg_dom = alg_spmv + 96 * n_rows
+        avg_ms = upd_ms.value / upd_launches.value
+        dom_launches = upd_launches.value
+        spmv_name = "spmv_pair_kernel<kSpmvDotOnly> (partial sums of p.(A p), nothing stored; row-pair coded CSR)"
+        spmv_tag = "spmv_pair_kernel<5,"
+    else:
+        kernel_name, dom_tag, alg_dom, avg_ms, dom_launches = spmv_name, spmv_tag, alg_spmv, spmv_avg_ms, launches.value
+    achieved = alg_dom / (avg_ms * 1e-3) / 1e9 if dom_launches else 0.0
     traffic = None
+    spmv_traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            key = "%dx%dx%d" % shape
-            ent = tj.get(key, {})
-            # only quote the PMC figure if it was taken for the kernel this run is using
-            if ent.get("kernel", "").split("<")[0] == kernel_name.split("<")[0]:
-                traffic = ent.get("hbm_bytes_per_launch")
+            ent = tj.get("%dx%dx%d" % shape, {})
+            # only quote a PMC figure taken for the very kernel this run is using
+            traffic = ent.get(dom_tag, {}).get("hbm_bytes_per_launch")
+            spmv_traffic = ent.get(spmv_tag, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     # the plain-CSR kernel on the same matrix (variant 6), timed on its own: the figure the
@@ -244,9 +264,15 @@ def main():
         "roofline": {"kernel": kernel_name, "bound": "hbm",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": alg_spmv, "launches": launches.value,
+                     "algorithmic_bytes_per_launch": alg_dom, "launches": dom_launches,
                      "avg_launch_ms": avg_ms,
                      "ms_per_step_instrumented": 1e3 * elapsed_instrumented / a.steps},
+        "roofline_spmv": {"kernel": spmv_name, "bound": "hbm",
+                          "achieved": alg_spmv / (spmv_avg_ms * 1e-3) / 1e9 if launches.value else 0.0,
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": (alg_spmv / (spmv_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if launches.value else 0.0,
+                          "traffic": spmv_traffic, "algorithmic_bytes_per_launch": alg_spmv,
+                          "launches": launches.value, "avg_launch_ms": spmv_avg_ms},
         "roofline_csr_plain": csr_plain,
     }
     # time-to-residual(1e-6) at the authors' inexact setting (SURVEY 8d ii)

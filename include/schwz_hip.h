@@ -151,6 +151,10 @@ int schwz_profile_begin(int capacity);
 int schwz_stream_probe(int64_t n, int mode, const double *d_src, double *d_dst,
                        schwz_stream stream);
 int schwz_profile_end(double *h_total_ms, int64_t *h_launches);
+/* after schwz_profile_end: the same figures per launch kind of a CG iteration, 0 = the SpMV (+ p.Ap)
+ * launch, 1 = the fused recompute-and-update launch of the q-free iteration (zero launches when the
+ * solver stores q) */
+int schwz_profile_kind(int kind, double *h_total_ms, int64_t *h_launches);
 
 /* Sparse triangular solves y = P^T L^-T L^-1 P b.
  * Replaces gko::solver::LowerTrs/UpperTrs + Permutation::apply as used by

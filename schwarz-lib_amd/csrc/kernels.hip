@@ -1630,7 +1630,10 @@ namespace {
 struct ProfState {
     bool on = false;
     std::vector<hipEvent_t> ev;
+    std::vector<int> kind;  // per event pair: 0 = the SpMV launch of a CG iteration, 1 = its update launch
     size_t used = 0;
+    double total[2] = {0.0, 0.0};
+    int64_t count[2] = {0, 0};
 } g_prof;
 }  // namespace
 
@@ -1644,6 +1647,7 @@ int schwz_profile_begin(int capacity)
         SCHWZ_HIP_TRY(hipEventCreate(&e));
         g_prof.ev.push_back(e);
     }
+    g_prof.kind.assign((size_t)capacity, 0);
     g_prof.used = 0;
     g_prof.on = true;
     return SCHWZ_OK;
@@ -1654,15 +1658,26 @@ int schwz_profile_end(double *h_total_ms, int64_t *h_launches)
     SCHWZ_REQUIRE(h_total_ms && h_launches, "schwz_profile_end: null output");
     g_prof.on = false;
     SCHWZ_HIP_TRY(hipDeviceSynchronize());
-    double total = 0.0;
+    g_prof.total[0] = g_prof.total[1] = 0.0;
+    g_prof.count[0] = g_prof.count[1] = 0;
     for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
         float ms = 0.f;
         SCHWZ_HIP_TRY(hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]));
-        total += ms;
+        const int k = g_prof.kind[i / 2] ? 1 : 0;
+        g_prof.total[k] += ms;
+        g_prof.count[k] += 1;
     }
-    *h_total_ms = total;
-    *h_launches = (int64_t)(g_prof.used / 2);
+    *h_total_ms = g_prof.total[0];
+    *h_launches = g_prof.count[0];
     g_prof.used = 0;
+    return SCHWZ_OK;
+}
+
+int schwz_profile_kind(int kind, double *h_total_ms, int64_t *h_launches)
+{
+    SCHWZ_REQUIRE(h_total_ms && h_launches && (kind == 0 || kind == 1), "schwz_profile_kind: bad arguments");
+    *h_total_ms = g_prof.total[kind];
+    *h_launches = g_prof.count[kind];
     return SCHWZ_OK;
 }
 
@@ -2032,6 +2047,7 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
             if (rc) return rc;
             if (prof) {
                 SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used + 1], st));
+                g_prof.kind[g_prof.used / 2] = 0;
                 g_prof.used += 2;
             }
             if (qfree) {
@@ -2050,7 +2066,14 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
                 u.dinv = s->dinv;
                 u.partials = part_vec;
                 u.it = it;
+                const bool prof2 = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
+                if (prof2) SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used], st));
                 if ((rc = launch_spmv(A, kSpmvCgUpdate, u, s->variant, st))) return rc;
+                if (prof2) {
+                    SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used + 1], st));
+                    g_prof.kind[g_prof.used / 2] = 1;
+                    g_prof.used += 2;
+                }
                 hipLaunchKernelGGL((cg_direction_kernel<1, false>), dim3(gv), dim3(kBlock), 0, st, n, s->p, s->r, s->diag,
                                    part_vec, gs, s->state, it, rtol);
                 continue;

@@ -31,7 +31,7 @@ SYMBOLS = [
     "schwz_csr_create", "schwz_csr_destroy", "schwz_csr_nnz", "schwz_csr_format", "schwz_csr_spmv",
     "schwz_pcg_create", "schwz_pcg_create_ex", "schwz_pcg_destroy", "schwz_pcg_solve",
     "schwz_gmres_create", "schwz_gmres_destroy", "schwz_gmres_solve",
-    "schwz_profile_begin", "schwz_profile_end", "schwz_stream_probe",
+    "schwz_profile_begin", "schwz_profile_end", "schwz_profile_kind", "schwz_stream_probe",
     "schwz_trs_create", "schwz_trs_destroy", "schwz_trs_solve",
     "schwz_problem_laplacian", "schwz_problem_from_csr", "schwz_problem_from_matrix_market",
     "schwz_problem_destroy", "schwz_problem_size", "schwz_problem_nnz", "schwz_problem_row",
@@ -116,6 +116,7 @@ _sig("schwz_gmres_solve", i32, [vp, vp, vp, dbl, i32, C.POINTER(C.c_int), C.POIN
 _sig("schwz_pcg_solve", i32, [vp, vp, vp, dbl, i32, C.POINTER(C.c_int), C.POINTER(dbl), vp])
 _sig("schwz_profile_begin", i32, [i32])
 _sig("schwz_profile_end", i32, [C.POINTER(dbl), C.POINTER(i64)])
+_sig("schwz_profile_kind", i32, [i32, C.POINTER(dbl), C.POINTER(i64)])
 _sig("schwz_stream_probe", i32, [i64, i32, vp, vp, vp])
 _sig("schwz_trs_create", i32, [i64] + [vp] * 7 + [pvp])
 _sig("schwz_trs_destroy", None, [vp])

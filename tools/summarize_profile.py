@@ -21,7 +21,8 @@ import shutil
 import sys
 from collections import defaultdict
 
-DOMINANT = ("spmv_pair_kernel<1,", "spmv_pattern_kernel<1,", "spmv_dict_kernel<1>", "spmv_tiled2_kernel<1>")  # first one present wins
+TRACKED = ("spmv_pair_kernel<6,", "spmv_pair_kernel<5,", "spmv_pair_kernel<1,", "spmv_pattern_kernel<1,",
+           "spmv_dict_kernel<1>", "spmv_tiled2_kernel<1>", "cg_update_kernel", "cg_direction_kernel")
 
 
 def read_counter(dirname, counter):
@@ -57,20 +58,18 @@ def main():
             entry["hbm_GBs"] = entry["hbm_bytes_per_launch"] / entry["avg_ns"]
         summary[name] = entry
     json.dump(summary, open(os.path.join(out, tag + "_summary.json"), "w"), indent=1, sort_keys=True)
-    dom, dom_name = [], None
-    for name in DOMINANT:
-        dom = [v for k, v in summary.items() if name in k]
-        if dom:
-            dom_name = name
-            break
-    if dom and "hbm_bytes_per_launch" in dom[0]:
-        tpath = os.path.join(out, "traffic.json")
-        tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
-        key = sys.argv[3] if len(sys.argv) > 3 else "256x256x256"
-        tj[key] = dict(kernel=dom_name, hbm_bytes_per_launch=dom[0]["hbm_bytes_per_launch"],
-                       avg_ns=dom[0]["avg_ns"], source=tag + "_summary.json",
-                       note="(2*FETCH_SIZE + WRITE_SIZE) KiB per launch, separate --pmc passes")
-        json.dump(tj, open(tpath, "w"), indent=1, sort_keys=True)
+    # HBM bytes per launch of the CG kernels, keyed by the name prefix bench.py looks up
+    tpath = os.path.join(out, "traffic.json")
+    key = sys.argv[3] if len(sys.argv) > 3 else "256x256x256"
+    ent = {}
+    for name in TRACKED:
+        hit = [v for k, v in summary.items() if name in k and "hbm_bytes_per_launch" in v]
+        if hit:
+            ent[name] = dict(hbm_bytes_per_launch=hit[0]["hbm_bytes_per_launch"], avg_ns=hit[0]["avg_ns"],
+                             source=tag + "_summary.json",
+                             note="(2*FETCH_SIZE + WRITE_SIZE) KiB per launch, separate --pmc passes")
+    if ent:
+        json.dump({key: ent}, open(tpath, "w"), indent=1, sort_keys=True)
     for k, v in sorted(summary.items(), key=lambda kv: -kv[1]["pct"])[:8]:
         print("%-60s calls %4d avg %9.1f us  hbm %s" % (
             k[:60], v["calls"], v["avg_ns"] / 1e3,
