@@ -30,6 +30,7 @@ def timeit(torch, fn, reps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--shape", default=None, help="nx,ny,nz instead of a cube")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--variants", default="0,7,6")
     ap.add_argument("--only-spmv", action="store_true")
@@ -37,7 +38,8 @@ def main():
     import torch
     import schwz_amd as S
     n = a.size
-    prob = S.Problem.laplacian(3, n, n, n)
+    shp = [int(t) for t in a.shape.split(",")] if a.shape else [n, n, n]
+    prob = S.Problem.laplacian(3, *shp)
     sd = S.Subdomain(prob, 1, 0, 2, S.partition_regular(prob.N, 1))
     rp, col, val = sd.local_matrix()
     A = S.Csr(rp, col, val)
