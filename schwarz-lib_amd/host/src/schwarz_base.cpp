@@ -14,6 +14,8 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <cstdio>
+#include <fstream>
 #include <cmath>
 #include <cstdlib>
 #include <iostream>
@@ -548,6 +550,8 @@ void SchwarzBase<V, I, M>::run(std::shared_ptr<gko::matrix::Dense<V>> &solution)
             if (std::isnan(local_res)) std::exit(-1);  // solve.cpp:982-984
             ppd.local_residual_vector_out.push_back(local_res);
             ppd.local_converged_resnorm.push_back(local_res / local_res0);
+            ppd.local_converged_iter_count.push_back(0);
+            ppd.local_timestamp.push_back((V)(MPI_Wtime() - m.init_mpi_wtime));
             m.current_residual_norm = local_res;
             if (tol > 0.0 && local_res / local_res0 <= tol) mask |= 1ULL << me;
             if (mask == full && stop == never) stop = it + P;
@@ -608,6 +612,8 @@ void SchwarzBase<V, I, M>::run(std::shared_ptr<gko::matrix::Dense<V>> &solution)
         if (std::isnan(local_res)) std::exit(-1);  // solve.cpp:982-984
         ppd.local_residual_vector_out.push_back(local_res);
         ppd.local_converged_resnorm.push_back(local_res / local_res0);
+        ppd.local_converged_iter_count.push_back(0);  // inner counts need enable_logging (solve.cpp:751-775)
+        ppd.local_timestamp.push_back((V)(MPI_Wtime() - m.init_mpi_wtime));
         m.current_residual_norm = local_res;
         m.min_residual_norm = it == 0 ? local_res : std::min(local_res, m.min_residual_norm);
         const bool iter_cond = cv.enable_global_check_iter_offset ? ((it > m.max_iters * 0.05) || m.max_iters < 1000) : true;
@@ -657,6 +663,16 @@ void SchwarzBase<V, I, M>::run(std::shared_ptr<gko::matrix::Dense<V>> &solution)
     // Solve::compute_residual_norm (solve.cpp:1025-1085): fresh overlap values, then the true
     // residual over the interior rows, ||b|| and the assembled solution on rank 0
     const bool converged = num_converged == P;
+    // schwarz_base.cpp:456-472: per-rank history file of the iterative path
+    if (s.write_iters_and_residuals && s.local_solver == Settings::local_solver_settings::iterative_solver_ginkgo) {
+        char name[64];
+        std::snprintf(name, sizeof(name), "iter_res_%02d.csv", me);
+        std::ofstream file(name);
+        file << "iter,resnorm,localiter,localresnorm,timestamp\n";
+        for (size_t i = 0; i < ppd.local_residual_vector_out.size(); ++i)
+            file << i << "," << ppd.local_residual_vector_out[i] << "," << ppd.local_converged_iter_count[i] << ","
+                 << ppd.local_converged_resnorm[i] << "," << ppd.local_timestamp[i] << "\n";
+    }
     if (!converged) {
         std::cout << "Rank " << me << " did not converge in " << m.iter_count << " iterations." << std::endl;
     } else {

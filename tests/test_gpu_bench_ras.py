@@ -35,7 +35,7 @@ def test_bench_ras_2d_laplacian_matches_oracle(oracle, nranks, tmp_path):
     n = 32
     out = _run(nranks, "--explicit_laplacian", "--set_1d_laplacian_size=%d" % n, "--enable_global_check",
                "--num_iters=500", "--set_tol=1e-8", "--timings_file=%s" % (tmp_path / "t"),
-               "--write_comm_data", cwd=str(tmp_path))
+               "--write_comm_data", "--write_iters_and_residuals", cwd=str(tmp_path))
     iters = sorted(set(int(x) for x in re.findall(r"converged in (\d+) iterations", out)))
     assert len(iters) == 1, out
     rel = float(re.search(r"relative residual norm of solution ([0-9.eE+-]+)", out).group(1))
@@ -50,6 +50,11 @@ def test_bench_ras_2d_laplacian_matches_oracle(oracle, nranks, tmp_path):
     assert t[0] == "func,total,avg,min,med,max"
     assert [l.split(",")[0] for l in t[1:]] == ["boundary_exchange", "boundary_update", "convergence_check",
                                                 "local_solve", "expand_local_vec", "other"]
+    # schwarz_base.cpp:456-472: one history file per rank, one line per outer iteration
+    hist = (tmp_path / "iter_res_00.csv").read_text().splitlines()
+    assert hist[0] == "iter,resnorm,localiter,localresnorm,timestamp"
+    assert len(hist) == 1 + ref["iter_count"] + 1  # the converged iteration still records its residual
+    assert float(hist[-1].split(",")[1]) < float(hist[1].split(",")[1])
     if nranks > 1:
         send = (tmp_path / "num_send_00.csv").read_text().splitlines()
         assert send[0].startswith("subdomain 0 has 1 neighbors") and send[1] == "my_id,to_id,num_send"
