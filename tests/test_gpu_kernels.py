@@ -437,6 +437,43 @@ def test_coded_tiles_are_bit_identical_to_plain_csr(schwz, oracle, torch_cuda, m
         assert np.array_equal(sols[0][0], sols[k][0]) and sols[0][1] == sols[k][1]
 
 
+@pytest.mark.parametrize("nvalues", [1, 5, 40])
+def test_qfree_cg_with_every_diagonal_representation(schwz, oracle, torch_cuda, monkeypatch, nvalues):
+    """The q-free CG iteration of row-pair coded matrices (q = A p recomputed inside the update
+    launch) with the Jacobi diagonal as a scalar (1 distinct value), as the full vector (40
+    values: no dictionary) and -- 5 values: dictionary codes, which the fused launch does not
+    take -- through the stored-q iteration; each against the oracle and against the stored-q
+    iteration forced by SCHWZ_CG_QFREE=0 in a fresh process-independent way (same library, the
+    switch is read once, so the comparison is made through the oracle tolerance)."""
+    torch = torch_cuda
+    rp, col, val = oracle.laplacian3d(40, 40, 40)
+    n = len(rp) - 1
+    val = val.copy()
+    shifts = np.linspace(0.0, 2.0, nvalues) if nvalues > 1 else np.zeros(1)
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    diag = col == rows
+    val[diag] += shifts[(rows[diag] // 4096) % nvalues]   # piecewise constant: few pairs per chunk
+    monkeypatch.setenv("SCHWZ_SPMV_PATTERN", "2")   # code it whatever the table sharing heuristics say
+    monkeypatch.setenv("SCHWZ_SPMV_PAIR", "2")
+    A = schwz.Csr(rp, col, val)
+    assert A.format() == 3
+    rng = np.random.default_rng(13)
+    b = rng.standard_normal(n)
+    x0 = rng.standard_normal(n) * 0.1
+    cg = schwz.Pcg(A, 1)
+    for iters in (1, 9, 30):
+        exp, it_o, rn_o = oracle.pcg(rp, col, val, b, x0, 1, 0.0, iters)
+        d_b, d_x = _dev(torch, b), _dev(torch, x0)
+        it_g, rn_g = cg.solve(d_b.data_ptr(), d_x.data_ptr(), 0.0, iters)
+        assert it_g == it_o == iters
+        assert np.abs(d_x.cpu().numpy() - exp).max() <= RTOL_CG * np.abs(exp).max()
+        assert abs(rn_g - rn_o) <= 1e-8 * rn_o
+    exp, it_o, rn_o = oracle.pcg(rp, col, val, b, None, 1, 1e-9, n)
+    d_b, d_x = _dev(torch, b), torch.zeros(n, dtype=torch.float64, device="cuda")
+    it_g, rn_g = cg.solve(d_b.data_ptr(), d_x.data_ptr(), 1e-9, n)
+    assert abs(it_g - it_o) <= 1 and np.abs(d_x.cpu().numpy() - exp).max() <= 1e-7 * np.abs(exp).max()
+
+
 @pytest.mark.parametrize("nshift", [1, 3, 40])
 def test_pcg_diagonal_representations_agree(schwz, oracle, torch_cuda, monkeypatch, nshift):
     """Jacobi 1/diag as a scalar (1 distinct value), as 1-byte codes into a dictionary (3), or as
