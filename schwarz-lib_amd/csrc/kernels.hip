@@ -2201,16 +2201,19 @@ int schwz_trs_create(int64_t n, const schwz_idx *l_rp, const schwz_idx *l_col, c
     // One workgroup handles the whole solve while the factor is small; otherwise wide levels get
     // a multi-workgroup launch each and runs of narrow levels share a one-workgroup launch.
     t->fused = n <= 8192;
-    auto plan = [](const std::vector<schwz_idx> &lvl, std::vector<schwz_trs::Seg> &out) {
+    // a level of >= wide_min rows gets a launch of its own (SCHWZ_TRS_WIDE overrides the threshold)
+    const char *wenv = std::getenv("SCHWZ_TRS_WIDE");
+    const int wide_min = (wenv && std::atoi(wenv) > 0) ? std::atoi(wenv) : 256;  // measured: 4096 -> 11.8, 1024 -> 5.4, 256 -> 5.1 ms per ILU-CG iteration at 128^3
+    auto plan = [wide_min](const std::vector<schwz_idx> &lvl, std::vector<schwz_trs::Seg> &out) {
         const int nl = (int)lvl.size() - 1;
         int l = 0;
         while (l < nl) {
-            if (lvl[(size_t)l + 1] - lvl[(size_t)l] >= 4 * kTrsBlock) {
+            if (lvl[(size_t)l + 1] - lvl[(size_t)l] >= wide_min) {
                 out.push_back({l, l + 1, true});
                 ++l;
             } else {
                 int e = l;
-                while (e < nl && lvl[(size_t)e + 1] - lvl[(size_t)e] < 4 * kTrsBlock) ++e;
+                while (e < nl && lvl[(size_t)e + 1] - lvl[(size_t)e] < wide_min) ++e;
                 out.push_back({l, e, false});
                 l = e;
             }
@@ -2257,6 +2260,8 @@ void schwz_trs_destroy(schwz_trs *t)
     void *ptrs[] = {t->l_rp, t->l_col, t->l_val, t->u_rp, t->u_col, t->u_val, t->perm,
                     t->l_order, t->l_lvl, t->u_order, t->u_lvl, t->w0, t->w1};
     for (void *p : ptrs) (void)hipFree(p);
+    for (auto &g : t->graphs) (void)hipGraphExecDestroy(g.exec);
+    if (t->capture_stream) (void)hipStreamDestroy(t->capture_stream);
     delete t;
 }
 
@@ -2271,6 +2276,31 @@ int schwz_trs_solve(schwz_trs *t, const double *d_b, double *d_y, schwz_stream s
                            t->u_lvl, t->u_nlvl, d_b, d_y, t->w0, t->w1);
         SCHWZ_HIP_TRY(hipGetLastError());
         return SCHWZ_OK;
+    }
+    // The level-by-level plan is a fixed sequence of launches for given (b, y): it is captured once
+    // into a hipGraph (on a private stream: the caller's may be the legacy default stream, which
+    // cannot capture) and replayed with one graph launch afterwards.  SCHWZ_TRS_GRAPH=0 disables.
+    static const bool graphs_on = [] {
+        const char *e = std::getenv("SCHWZ_TRS_GRAPH");
+        return !(e && e[0] == '0');
+    }();
+    hipStream_t user_stream = st;
+    bool capturing = false;
+    if (graphs_on && t->l_plan.size() + t->u_plan.size() > 8) {
+        for (const auto &g : t->graphs)
+            if (g.b == d_b && g.y == d_y) {
+                SCHWZ_HIP_TRY(hipGraphLaunch(g.exec, user_stream));
+                return SCHWZ_OK;
+            }
+        if (t->graphs.size() < 4) {
+            if (!t->capture_stream) SCHWZ_HIP_TRY(hipStreamCreateWithFlags(&t->capture_stream, hipStreamNonBlocking));
+            if (hipStreamBeginCapture(t->capture_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                capturing = true;
+                st = t->capture_stream;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
     }
     // w0 = P b ; L w1 = w0 ; U w0 = w1 ; y = P^T w0
     hipLaunchKernelGGL(trs_permute_in_kernel, dim3(grid_for(t->n)), dim3(kBlock), 0, st, t->n, t->perm, d_b, t->w0);
@@ -2295,6 +2325,20 @@ int schwz_trs_solve(schwz_trs *t, const double *d_b, double *d_y, schwz_stream s
         }
     }
     hipLaunchKernelGGL(trs_permute_out_kernel, dim3(grid_for(t->n)), dim3(kBlock), 0, st, t->n, t->perm, t->w0, d_y);
+    if (capturing) {
+        hipGraph_t graph = nullptr;
+        SCHWZ_HIP_TRY(hipStreamEndCapture(t->capture_stream, &graph));
+        hipGraphExec_t exec = nullptr;
+        const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) {
+            set_error(std::string("schwz_trs_solve: hipGraphInstantiate: ") + hipGetErrorString(e));
+            return SCHWZ_ERR_HIP;
+        }
+        t->graphs.push_back({d_b, d_y, exec});
+        SCHWZ_HIP_TRY(hipGraphLaunch(exec, user_stream));
+        return SCHWZ_OK;
+    }
     SCHWZ_HIP_TRY(hipGetLastError());
     return SCHWZ_OK;
 }

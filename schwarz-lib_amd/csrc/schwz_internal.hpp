@@ -232,6 +232,15 @@ struct schwz_trs {
     std::vector<Seg> l_plan, u_plan;
     std::vector<schwz_idx> h_l_lvl, h_u_lvl;
     bool fused = true;  // whole solve in the single-workgroup kernel
+    // multi-launch plan as hipGraphs, one per (b, y) pair it has been asked for: a sweep over a
+    // 256^3 subdomain is ~1500 tiny launches, replayed as ONE graph launch
+    struct Captured {
+        const double *b;
+        double *y;
+        hipGraphExec_t exec;
+    };
+    std::vector<Captured> graphs;
+    hipStream_t capture_stream = nullptr;
 };
 
 // host-side global problem (explicit CSR or analytic stencil)
