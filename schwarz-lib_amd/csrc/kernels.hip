@@ -113,10 +113,11 @@ __global__ __launch_bounds__(kBlock) void spmv_tiled_kernel(CsrView A, SpmvArgs 
 // wave keeps ~1.5 KiB outstanding instead of one 12-byte pair.  The tile window
 // starts at the even index below rp[r0]; the at most two foreign entries at the
 // window's ends are multiplied like the others and simply never summed (the
-// arrays carry two padding entries, see schwz_csr_create).
+// arrays carry four padding entries, see schwz_csr_create).
 // ---------------------------------------------------------------------------
 
 constexpr int kPairsPerLane = kTileNnz / (2 * kBlock);  // 4
+constexpr int kQuadsPerLane = kTileNnz / (4 * kBlock);  // 2
 
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void spmv_tiled2_kernel(CsrView A, SpmvArgs a)
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(kBlock) void spmv_tiled2_kernel(CsrView A, SpmvArgs
     // every SpMV variant rounds each product before it is added (no FMA contraction), so
     // that all variants -- and the sequential CPU oracle -- produce the same bits
 #pragma clang fp contract(off)
-    __shared__ double prod[kTileNnz + 2];
+    __shared__ __attribute__((aligned(16))) double prod[kTileNnz + 4];
     __shared__ double red[4];
     if (MODE == kSpmvDot || MODE == kSpmvResidInit) {
         if (a.stop_iter && a.it >= *a.stop_iter) return;
@@ -148,37 +149,45 @@ __global__ __launch_bounds__(kBlock) void spmv_tiled2_kernel(CsrView A, SpmvArgs
         double sum = 0.0, sum2 = 0.0;
         int row = r0 + tid;
         bool have_row = false;
-        if (cnt <= kTileNnz - 2) {
-            const int s2 = s & ~1;
+        if ((s & 3) + cnt <= kTileNnz) {
+            const int s2 = s & ~3;  // 16-byte aligned window of the column indices (32-byte of the values)
             // own row bounds first: independent of the streaming loads
             int b0 = 0, b1 = 0;
             if (row < r1) {
                 b0 = A.rp[row] - s2;
                 b1 = A.rp[row + 1] - s2;
             }
-            // no per-pair bounds branch: lanes past the tile re-read its last pair
-            // (their products land in LDS slots no row sums)
-            const int last = max((e - 1) & ~1, s2);
-            double2 v[kPairsPerLane];
-            int2 c[kPairsPerLane];
+            // Four consecutive entries per lane and trip: two 16-byte value loads and ONE 16-byte
+            // index load (the vector-memory pipe is priced per instruction).  No bounds branch: lanes
+            // past the tile re-read its last quad (their products land in LDS slots no row sums).
+            const int last = max((e - 1) & ~3, s2);
+            double2 v[2 * kQuadsPerLane];
+            int4 c[kQuadsPerLane];
 #pragma unroll
-            for (int k = 0; k < kPairsPerLane; ++k) {
-                const int idx = min(s2 + 2 * (tid + kBlock * k), last);
-                v[k] = *reinterpret_cast<const double2 *>(A.val + idx);
-                c[k] = *reinterpret_cast<const int2 *>(A.col + idx);
+            for (int k = 0; k < kQuadsPerLane; ++k) {
+                const int idx = min(s2 + 4 * (tid + kBlock * k), last);
+                v[2 * k] = *reinterpret_cast<const double2 *>(A.val + idx);
+                v[2 * k + 1] = *reinterpret_cast<const double2 *>(A.val + idx + 2);
+                c[k] = *reinterpret_cast<const int4 *>(A.col + idx);
             }
-            double xg[2 * kPairsPerLane];
+            double xg[4 * kQuadsPerLane];
 #pragma unroll
-            for (int k = 0; k < kPairsPerLane; ++k) {
-                xg[2 * k] = a.x[c[k].x];
-                xg[2 * k + 1] = a.x[c[k].y];
+            for (int k = 0; k < kQuadsPerLane; ++k) {
+                xg[4 * k] = a.x[c[k].x];
+                xg[4 * k + 1] = a.x[c[k].y];
+                xg[4 * k + 2] = a.x[c[k].z];
+                xg[4 * k + 3] = a.x[c[k].w];
             }
 #pragma unroll
-            for (int k = 0; k < kPairsPerLane; ++k) {
-                double2 pr;
-                pr.x = v[k].x * xg[2 * k];
-                pr.y = v[k].y * xg[2 * k + 1];
-                *reinterpret_cast<double2 *>(&prod[2 * (tid + kBlock * k)]) = pr;
+            for (int k = 0; k < kQuadsPerLane; ++k) {
+                double2 p0, p1;
+                p0.x = v[2 * k].x * xg[4 * k];
+                p0.y = v[2 * k].y * xg[4 * k + 1];
+                p1.x = v[2 * k + 1].x * xg[4 * k + 2];
+                p1.y = v[2 * k + 1].y * xg[4 * k + 3];
+                double2 *dst = reinterpret_cast<double2 *>(&prod[4 * (tid + kBlock * k)]);
+                dst[0] = p0;
+                dst[1] = p1;
             }
             lds_barrier();
             if (row < r1) {
@@ -189,16 +198,22 @@ __global__ __launch_bounds__(kBlock) void spmv_tiled2_kernel(CsrView A, SpmvArgs
             if (dual_t) {
                 // second vector, same matrix entries (still in registers)
 #pragma unroll
-                for (int k = 0; k < kPairsPerLane; ++k) {
-                    xg[2 * k] = a.x2[c[k].x];
-                    xg[2 * k + 1] = a.x2[c[k].y];
+                for (int k = 0; k < kQuadsPerLane; ++k) {
+                    xg[4 * k] = a.x2[c[k].x];
+                    xg[4 * k + 1] = a.x2[c[k].y];
+                    xg[4 * k + 2] = a.x2[c[k].z];
+                    xg[4 * k + 3] = a.x2[c[k].w];
                 }
 #pragma unroll
-                for (int k = 0; k < kPairsPerLane; ++k) {
-                    double2 pr;
-                    pr.x = v[k].x * xg[2 * k];
-                    pr.y = v[k].y * xg[2 * k + 1];
-                    *reinterpret_cast<double2 *>(&prod[2 * (tid + kBlock * k)]) = pr;
+                for (int k = 0; k < kQuadsPerLane; ++k) {
+                    double2 p0, p1;
+                    p0.x = v[2 * k].x * xg[4 * k];
+                    p0.y = v[2 * k].y * xg[4 * k + 1];
+                    p1.x = v[2 * k + 1].x * xg[4 * k + 2];
+                    p1.y = v[2 * k + 1].y * xg[4 * k + 3];
+                    double2 *dst = reinterpret_cast<double2 *>(&prod[4 * (tid + kBlock * k)]);
+                    dst[0] = p0;
+                    dst[1] = p1;
                 }
                 lds_barrier();
                 if (row < r1)
@@ -1521,8 +1536,8 @@ int schwz_csr_create(int64_t nrows, int64_t ncols, const schwz_idx *h_rp, const 
     }
     schwz_csr *A = new schwz_csr();
     int rc;
-    if ((rc = upload(h_rp, (size_t)nrows + 1, &A->d_rp)) || (rc = upload(h_col, (size_t)nnz, &A->d_col, 2)) ||
-        (rc = upload(h_val, (size_t)nnz, &A->d_val, 2)) || (rc = upload(tiles.data(), tiles.size(), &A->d_tile)) ||
+    if ((rc = upload(h_rp, (size_t)nrows + 1, &A->d_rp)) || (rc = upload(h_col, (size_t)nnz, &A->d_col, 4)) ||
+        (rc = upload(h_val, (size_t)nnz, &A->d_val, 4)) || (rc = upload(tiles.data(), tiles.size(), &A->d_tile)) ||
         (rc = upload(wtiles.data(), wtiles.size(), &A->d_wtile)) ||
         (!order.empty() && (rc = upload(order.data(), order.size(), &A->d_order)))) {
         schwz_csr_destroy(A);
