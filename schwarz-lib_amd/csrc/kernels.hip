@@ -1059,13 +1059,14 @@ __global__ __launch_bounds__(kBlock) void cg_direction_kernel(int64_t n, double 
         p[i] = z + beta * p[i];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        // other workgroups read rho[it&1] and stop_iter concurrently: the slot
-        // written here is the other one, and stop_iter only ever drops to it+1,
-        // which every reader of this launch compares as "not yet".
+        // other workgroups read rho[it&1] concurrently: the slot written here is the other one
         st->rho[(it + 1) & 1] = rho_new;
         st->rr = rr;
-        st->iters = it + 1;
-        if (sqrt(rr) <= rtol * st->r0) st->stop_iter = it + 1;
+        st->iters = st->iters + 1;
+        // 0, not it + 1: every later launch leaves at once whatever iteration index it carries (the
+        // recorded launches of a replayed hipGraph carry 0..15 again and again).  Workgroups of THIS
+        // launch that read the 0 early skip their part of p, which nobody will read any more.
+        if (sqrt(rr) <= rtol * st->r0) st->stop_iter = 0;
     }
 }
 
@@ -1919,6 +1920,8 @@ void schwz_pcg_destroy(schwz_pcg *s)
     (void)hipFree(s->z);
     (void)hipFree(s->d_blk_id);
     (void)hipFree(s->d_blk_inv);
+    for (auto &g : s->graphs) (void)hipGraphExecDestroy(g.exec);
+    if (s->capture_stream) (void)hipStreamDestroy(s->capture_stream);
     schwz_trs_destroy(s->ilu);
     schwz_csr_destroy(s->isai_l);
     schwz_csr_destroy(s->isai_u);
@@ -2044,78 +2047,117 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
         return !(e && e[0] == '0');
     }();
     const bool qfree = qfree_on && !general && A.pair_id && s->variant == 0 && s->diag.mode != 2;
+    // one CG iteration on stream `q`; `it` only enters through its parity (rho slot) and through
+    // "it >= stop_iter", and stop_iter is 0 once the tolerance test has fired: a recorded sequence
+    // of an even number of iterations can therefore be replayed as a hipGraph
+    auto launch_iteration = [&](int it, hipStream_t q, bool instrument) -> int {
+        SpmvArgs a;
+        a.x = s->p;
+        a.y = s->q;
+        a.partials = part_spmv;
+        a.stop_iter = &s->state->stop_iter;
+        a.it = it;
+        const bool prof = instrument && g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
+        if (prof) SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used], q));
+        int rc = launch_spmv(A, qfree ? kSpmvDotOnly : kSpmvDot, a, s->variant, q);
+        if (rc) return rc;
+        if (prof) {
+            SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used + 1], q));
+            g_prof.kind[g_prof.used / 2] = 0;
+            g_prof.used += 2;
+        }
+        if (qfree) {
+            // q = A p is never stored: the update pass recomputes (A p)_i row by row while it
+            // streams x and r (spmv_pair.hip, kSpmvCgUpdate): 16 B per row less HBM traffic, a
+            // third of the stores of these two launches
+            SpmvArgs u;
+            u.x = s->p;
+            u.cg_x = d_x;
+            u.cg_r = s->r;
+            u.cg_state = s->state;
+            u.pq_partials = part_spmv;
+            u.pq_nparts = gs;
+            u.diag_mode = s->diag.mode;
+            u.diag_uniform = s->diag.uniform;
+            u.dinv = s->dinv;
+            u.partials = part_vec;
+            u.it = it;
+            const bool prof2 = instrument && g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
+            if (prof2) SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used], q));
+            if ((rc = launch_spmv(A, kSpmvCgUpdate, u, s->variant, q))) return rc;
+            if (prof2) {
+                SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used + 1], q));
+                g_prof.kind[g_prof.used / 2] = 1;
+                g_prof.used += 2;
+            }
+            hipLaunchKernelGGL((cg_direction_kernel<1, false>), dim3(gv), dim3(kBlock), 0, q, n, s->p, s->r, s->diag,
+                               part_vec, gs, s->state, it, rtol);
+        } else if (!general) {
+            hipLaunchKernelGGL((cg_update_kernel<1, false>), dim3(gv), dim3(kBlock), 0, q, n, d_x, s->r, s->p, s->q,
+                               s->diag, part_spmv, gs, s->state, it, part_vec);
+            hipLaunchKernelGGL((cg_direction_kernel<1, false>), dim3(gv), dim3(kBlock), 0, q, n, s->p, s->r, s->diag,
+                               part_vec, gv, s->state, it, rtol);
+        } else {
+            // x, r update without a preconditioner; z = M^-1 r; rho' = r.z; p = z + beta p
+            const DiagView none;
+            const int gz = grid_for(n);
+            hipLaunchKernelGGL((cg_update_kernel<1, false>), dim3(gv), dim3(kBlock), 0, q, n, d_x, s->r, s->p, s->q,
+                               none, part_spmv, gs, s->state, it, part_vec);
+            if ((rc = pcg_apply_general(s, q))) return rc;
+            hipLaunchKernelGGL(dot_rz_kernel, dim3(gz), dim3(kBlock), 0, q, n, s->r, s->z, (double *)nullptr, s->state,
+                               it, part_vec);
+            hipLaunchKernelGGL((cg_direction_kernel<1, false>), dim3(gv), dim3(kBlock), 0, q, n, s->p, s->z, none,
+                               part_vec, gz, s->state, it, rtol);
+        }
+        return SCHWZ_OK;
+    };
+    // Small systems are bound by launches, not bytes (33 k rows: 3 launches of ~3 us work each):
+    // kGraphIters iterations are captured once per (x, rtol) into a hipGraph -- on a private stream,
+    // the caller's may be the legacy default stream -- and replayed.  SCHWZ_CG_GRAPH=0 disables,
+    // =2 uses graphs for every size.
+    static const int graph_mode = [] {
+        const char *e = std::getenv("SCHWZ_CG_GRAPH");
+        return e ? std::atoi(e) : 1;
+    }();
+    const bool graphable = graph_mode != 0 && !general && !g_prof.on && (graph_mode == 2 || n <= kGraphRows);
+    hipGraphExec_t replay = nullptr;
+    if (graphable && max_iters >= kGraphIters) {
+        for (const auto &g : s->graphs)
+            if (g.x == d_x && g.rtol == rtol && g.variant == s->variant && g.qfree == qfree) replay = g.exec;
+        if (!replay && s->graphs.size() < 4) {
+            if (!s->capture_stream) SCHWZ_HIP_TRY(hipStreamCreateWithFlags(&s->capture_stream, hipStreamNonBlocking));
+            if (hipStreamBeginCapture(s->capture_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                int rc = SCHWZ_OK;
+                for (int k = 0; k < kGraphIters && !rc; ++k) rc = launch_iteration(k, s->capture_stream, false);
+                hipGraph_t graph = nullptr;
+                const hipError_t e1 = hipStreamEndCapture(s->capture_stream, &graph);
+                if (rc) {
+                    if (graph) (void)hipGraphDestroy(graph);
+                    return rc;
+                }
+                if (e1 == hipSuccess && hipGraphInstantiate(&replay, graph, nullptr, nullptr, 0) == hipSuccess)
+                    s->graphs.push_back({d_x, rtol, s->variant, qfree, replay});
+                else
+                    replay = nullptr;
+                if (graph) (void)hipGraphDestroy(graph);
+            }
+            (void)hipGetLastError();
+        }
+    }
     int chunk = 16;
     int it = 0, pending = -1, bank = 0;
     bool stopped = false;
     while (it < max_iters && !stopped) {
         const int end = (poll && it + chunk < max_iters) ? it + chunk : max_iters;
-        for (; it < end; ++it) {
-            SpmvArgs a;
-            a.x = s->p;
-            a.y = s->q;
-            a.partials = part_spmv;
-            a.stop_iter = &s->state->stop_iter;
-            a.it = it;
-            const bool prof = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
-            if (prof) SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used], st));
-            int rc = launch_spmv(A, qfree ? kSpmvDotOnly : kSpmvDot, a, s->variant, st);
-            if (rc) return rc;
-            if (prof) {
-                SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used + 1], st));
-                g_prof.kind[g_prof.used / 2] = 0;
-                g_prof.used += 2;
-            }
-            if (qfree) {
-                // q = A p is never stored: the update pass recomputes (A p)_i row by row while it
-                // streams x and r (spmv_pair.hip, kSpmvCgUpdate): 16 B per row less HBM traffic, a
-                // third of the stores of these two launches
-                SpmvArgs u;
-                u.x = s->p;
-                u.cg_x = d_x;
-                u.cg_r = s->r;
-                u.cg_state = s->state;
-                u.pq_partials = part_spmv;
-                u.pq_nparts = gs;
-                u.diag_mode = s->diag.mode;
-                u.diag_uniform = s->diag.uniform;
-                u.dinv = s->dinv;
-                u.partials = part_vec;
-                u.it = it;
-                const bool prof2 = g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
-                if (prof2) SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used], st));
-                if ((rc = launch_spmv(A, kSpmvCgUpdate, u, s->variant, st))) return rc;
-                if (prof2) {
-                    SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used + 1], st));
-                    g_prof.kind[g_prof.used / 2] = 1;
-                    g_prof.used += 2;
-                }
-                hipLaunchKernelGGL((cg_direction_kernel<1, false>), dim3(gv), dim3(kBlock), 0, st, n, s->p, s->r, s->diag,
-                                   part_vec, gs, s->state, it, rtol);
+        while (it < end) {
+            if (replay && it % kGraphIters == 0 && end - it >= kGraphIters) {
+                SCHWZ_HIP_TRY(hipGraphLaunch(replay, st));
+                it += kGraphIters;
                 continue;
             }
-#define SCHWZ_LAUNCH_UPDATE(U, NT)                                                                        \
-    hipLaunchKernelGGL((cg_update_kernel<U, NT>), dim3(gv), dim3(kBlock), 0, st, n, d_x, s->r, s->p, s->q, \
-                       s->diag, part_spmv, gs, s->state, it, part_vec)
-#define SCHWZ_LAUNCH_DIRECTION(U, NT)                                                                        \
-    hipLaunchKernelGGL((cg_direction_kernel<U, NT>), dim3(gv), dim3(kBlock), 0, st, n, s->p, s->r, s->diag, \
-                       part_vec, gv, s->state, it, rtol)
-            if (!general) {
-                SCHWZ_LAUNCH_UPDATE(1, false);
-                SCHWZ_LAUNCH_DIRECTION(1, false);
-            } else {
-                // x, r update without a preconditioner; z = M^-1 r; rho' = r.z; p = z + beta p
-                const DiagView none;
-                const int gz = grid_for(n);
-                hipLaunchKernelGGL((cg_update_kernel<1, false>), dim3(gv), dim3(kBlock), 0, st, n, d_x, s->r, s->p, s->q,
-                                   none, part_spmv, gs, s->state, it, part_vec);
-                if ((rc = pcg_apply_general(s, st))) return rc;
-                hipLaunchKernelGGL(dot_rz_kernel, dim3(gz), dim3(kBlock), 0, st, n, s->r, s->z, (double *)nullptr,
-                                   s->state, it, part_vec);
-                hipLaunchKernelGGL((cg_direction_kernel<1, false>), dim3(gv), dim3(kBlock), 0, st, n, s->p, s->z, none,
-                                   part_vec, gz, s->state, it, rtol);
-            }
-#undef SCHWZ_LAUNCH_UPDATE
-#undef SCHWZ_LAUNCH_DIRECTION
+            int rc = launch_iteration(it, st, true);
+            if (rc) return rc;
+            ++it;
         }
         SCHWZ_HIP_TRY(hipGetLastError());
         if (poll && it < max_iters) {

@@ -40,6 +40,8 @@ constexpr int kTileNnz = 2048;   // products staged in LDS per tile (16 KiB fp64
 constexpr int kTileRows = 256;   // one lane per row in the reduction phase
 constexpr int kMaxGrid = 2048;   // 256 CUs x 8 workgroups, grid-stride beyond
 constexpr int kXcds = 8;
+constexpr int kGraphIters = 16;          // CG iterations per recorded hipGraph (even: rho slots repeat)
+constexpr int64_t kGraphRows = 1 << 21;  // systems up to this many rows replay their CG loop as graphs
 constexpr int kWaveTileNnz = 512;  // products staged per wave (4 KiB fp64)
 
 struct CsrView {
@@ -212,6 +214,16 @@ struct schwz_pcg {
     schwz::CgState *h_state = nullptr;  // pinned
     hipEvent_t ev[2] = {nullptr, nullptr};
     int variant = 0;
+    // recorded runs of kGraphIters iterations (launch-bound small systems), see pcg_iterate
+    struct Captured {
+        double *x;
+        double rtol;
+        int variant;
+        bool qfree;
+        hipGraphExec_t exec;
+    };
+    std::vector<Captured> graphs;
+    hipStream_t capture_stream = nullptr;
 };
 
 struct schwz_trs {
