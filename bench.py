@@ -275,6 +275,31 @@ def main():
                           "launches": launches.value, "avg_launch_ms": spmv_avg_ms},
         "roofline_csr_plain": csr_plain,
     }
+    # the box's own HBM ceilings (STREAM-style kernels of the library, 2 GiB), quoted beside the
+    # 8 TB/s spec the roofline fractions are priced against
+    if rank == 0:
+        try:
+            big = torch.empty(1 << 28, dtype=torch.float64, device="cuda")
+            dst = torch.empty_like(big)
+            stream = torch.cuda.current_stream().cuda_stream
+            meas = {}
+            for mode, name, factor in ((1, "read", 1), (0, "copy", 2)):
+                for _ in range(2):
+                    schwz.capi.check(schwz.capi.lib.schwz_stream_probe(big.numel(), mode, big.data_ptr(),
+                                                                       dst.data_ptr(), stream))
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    schwz.capi.check(schwz.capi.lib.schwz_stream_probe(big.numel(), mode, big.data_ptr(),
+                                                                       dst.data_ptr(), stream))
+                e1.record()
+                torch.cuda.synchronize()
+                meas[name] = factor * big.numel() * 8 / (e0.elapsed_time(e1) / 10) / 1e6
+            line["hbm_measured"] = {"read": meas["read"], "copy": meas["copy"], "unit": "GB/s",
+                                    "note": "STREAM-style double2 kernels over 2 GiB on this GPU"}
+            del big, dst
+        except Exception as exc:  # never let the side measurement break the bench line
+            line["hbm_measured"] = {"error": str(exc)}
     # time-to-residual(1e-6) at the authors' inexact setting (SURVEY 8d ii)
     if not a.no_ttr:
         del solver
