@@ -89,6 +89,8 @@ class TorchDistComm:
         self.local_ranks = [self.rank]
         self.is_root = self.rank == 0
         self.device = device if device is not None else torch.device("cpu")
+        # the GPU this rank's subdomain lives on (SolverRAS binds its backend to it)
+        self.device_index = self.device.index if self.device.type == "cuda" and self.device.index is not None else 0
         self.backend = dist.get_backend(group)
         self.host_group = group if self.backend == "gloo" else dist.new_group(backend="gloo")
         self.stage_through_host = self.backend == "gloo" and self.device.type != "cpu"
