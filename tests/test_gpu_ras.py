@@ -510,3 +510,43 @@ def test_ras_mixed_precision_halo(schwz, oracle, torch_cuda):
     assert out["converged"]
     full, m2, out2 = _run_gpu(schwz, P, dict(), dict(oned_laplacian_size=n, tolerance=1e-4, max_iters=400))
     assert 0 < np.abs(out["solution"] - out2["solution"]).max() < 1e-3 * np.abs(out2["solution"]).max()
+
+
+def test_torchdist_comm_on_the_nccl_backend_single_rank(schwz, oracle, torch_cuda, tmp_path):
+    """The product N > 1 host path -- TorchDistComm over the `nccl` (= RCCL) process group with its
+    gloo side group for host data -- brought up with the one rank a 1-GPU box allows: process
+    group creation, index handshake, norm all-gather, solution gather and barrier all run for
+    real (the peer-to-peer halo calls need a second GPU and are covered by the gloo tests and by
+    the driver's multi-GPU run).  Run in a subprocess: process groups are per process."""
+    import subprocess
+    import sys
+    script = tmp_path / "nccl_one_rank.py"
+    script.write_text(
+        "import os, sys, json\n"
+        "sys.path.insert(0, %r)\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29641', RANK='0', WORLD_SIZE='1')\n"
+        "import torch, torch.distributed as dist\n"
+        "import schwz_amd as S\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', device_id=torch.device('cuda', 0))\n"
+        "comm = S.TorchDistComm(device=torch.device('cuda', 0))\n"
+        "assert comm.backend == 'nccl' and not comm.stage_through_host\n"
+        "s = S.Settings(laplacian_dim=3, laplacian_shape=(20, 18, 16))\n"
+        "m = S.Metadata(tolerance=1e-8, max_iters=50, local_precond='block-jacobi', precond_max_block_size=1)\n"
+        "solver = S.SolverRAS(s, m, comm=comm, quiet=True)\n"
+        "solver.initialize()\n"
+        "out = solver.run()\n"
+        "comm.barrier()\n"
+        "print(json.dumps(dict(iters=out['iter_count'], conv=bool(out['converged']),\n"
+        "                      rel=out['residual_norm'] / out['rhs_norm'], n=int(out['solution'].size))))\n"
+        "dist.destroy_process_group()\n" % os.path.join(os.path.dirname(os.path.dirname(__file__)), "schwarz-lib_amd"))
+    p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    import json
+    got = json.loads(p.stdout.strip().splitlines()[-1])
+    rp, col, val = oracle.laplacian3d(20, 18, 16)
+    N = len(rp) - 1
+    ref = oracle.ras_run(rp, col, val, np.ones(N), 1, oracle.first_rows_regular(N, 1),
+                         oracle.make_settings(max_iters=50, tol=1e-8, precond=1))
+    assert got["conv"] and got["iters"] == ref["iter_count"] and got["n"] == N
+    assert abs(got["rel"] - ref["residual_norm"] / ref["rhs_norm"]) <= 1e-6 * got["rel"] + 1e-13
