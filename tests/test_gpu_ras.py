@@ -516,8 +516,9 @@ def test_torchdist_comm_on_the_nccl_backend_single_rank(schwz, oracle, torch_cud
     """The product N > 1 host path -- TorchDistComm over the `nccl` (= RCCL) process group with its
     gloo side group for host data -- brought up with the one rank a 1-GPU box allows: process
     group creation, index handshake, norm all-gather, solution gather and barrier all run for
-    real (the peer-to-peer halo calls need a second GPU and are covered by the gloo tests and by
-    the driver's multi-GPU run).  Run in a subprocess: process groups are per process."""
+    real, and the grouped device-buffer send/recv of the halo exchange is exercised from rank 0 to
+    itself on the compute stream and on the side stream of the overlapped mode (true peer-to-peer
+    needs a second GPU: gloo tests and the driver's multi-GPU run).  Run in a subprocess: process groups are per process."""
     import subprocess
     import sys
     script = tmp_path / "nccl_one_rank.py"
@@ -537,6 +538,15 @@ def test_torchdist_comm_on_the_nccl_backend_single_rank(schwz, oracle, torch_cud
         "solver.initialize()\n"
         "out = solver.run()\n"
         "comm.barrier()\n"
+        "# the grouped send/recv mechanics on device buffers, rank 0 to itself: on the compute\n"
+        "# stream and on the side stream of the overlapped mode\n"
+        "src = torch.arange(4096, dtype=torch.float64, device='cuda') * 0.5\n"
+        "for ov in (False, True):\n"
+        "    dst = torch.zeros_like(src)\n"
+        "    h = comm.start_exchange({(0, 0): src}, {(0, 0): dst}, overlap=ov)\n"
+        "    comm.finish_exchange(h)\n"
+        "    torch.cuda.synchronize()\n"
+        "    assert torch.equal(src, dst), ov\n"
         "print(json.dumps(dict(iters=out['iter_count'], conv=bool(out['converged']),\n"
         "                      rel=out['residual_norm'] / out['rhs_norm'], n=int(out['solution'].size))))\n"
         "dist.destroy_process_group()\n" % os.path.join(os.path.dirname(os.path.dirname(__file__)), "schwarz-lib_amd"))
