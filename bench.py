@@ -113,7 +113,9 @@ def main():
     import schwz_amd as schwz
     N = a.gpus
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if N > 1 or world > 1:
+    # SCHWZ_BENCH_FORCE_DIST=1: take the torch.distributed branch with a single rank as well
+    # (brings the nccl process group, the gloo side group and the slab workload up on a 1-GPU box)
+    if N > 1 or world > 1 or os.environ.get("SCHWZ_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         # SCHWZ_DIST_BACKEND=gloo: several ranks may share one GPU (halos staged through host);
@@ -315,8 +317,8 @@ def main():
         line["cpu_baseline"] = cpu_baseline(shape, a.inner, a.cpu_iters)
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if N > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
         comm.barrier()
         dist.destroy_process_group()
 
