@@ -269,3 +269,17 @@ def test_isai_of_ilu_factors_matches_oracle_and_inverts_on_the_pattern(schwz, or
         pat = T.copy()
         pat.data[:] = 1.0
         assert abs((W @ T).multiply(pat) - sp.identity(n)).max() <= 1e-13
+
+
+def test_local_solver_names_map_like_the_reference(schwz):
+    """settings.local_solver (bench_ras.cpp:120-135): iterative-ginkgo -> CG/GMRES, direct-ginkgo
+    and direct-cholmod -> own LL^T + HIP triangular solves; direct-umfpack, iterative-dealii and
+    unknown names are refused."""
+    from schwz_amd import solver as sv
+    code = lambda name: sv._local_solver_code(schwz.Settings(local_solver=name))
+    assert code("iterative-ginkgo") == schwz.capi.SOLVER_ITERATIVE
+    assert code("direct-ginkgo") == schwz.capi.SOLVER_DIRECT
+    assert code("direct-cholmod") == schwz.capi.SOLVER_DIRECT
+    for bad in ("direct-umfpack", "iterative-dealii", "nope"):
+        with pytest.raises(schwz.capi.NotImplementedSchwz):
+            code(bad)
