@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 typedef double vd2 __attribute__((ext_vector_type(2)));
@@ -171,10 +172,11 @@ static float run(const double *x, double *y, long n, int nx, long plane, int gri
     return ms / reps;
 }
 
-int main()
+int main(int argc, char **argv)
 {
-    const int nx = 256;
-    const long plane = 256L * 256, n = plane * 256;
+    // default: the 256^3 cube; `gather_probe 512 512 64` = the per-GPU slab of the multi-GPU runs
+    const int nx = argc > 3 ? atoi(argv[1]) : 256;
+    const long plane = (long)nx * (argc > 3 ? atoi(argv[2]) : 256), n = plane * (argc > 3 ? atoi(argv[3]) : 256);
     double *x, *y, *junk;
     hipMalloc(&x, n * 8);
     hipMalloc(&y, n * 8);
