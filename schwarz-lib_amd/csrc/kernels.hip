@@ -1827,19 +1827,9 @@ static int pcg_setup_general(schwz_pcg *s)
     return SCHWZ_OK;
 }
 
-int schwz_pcg_create_ex(const schwz_csr *A, int precond, int block_size, schwz_pcg **out)
+// everything of schwz_pcg_create_ex that can fail half way: the caller destroys `s` on error
+static int pcg_build(schwz_pcg *s, const schwz_csr *A, int precond)
 {
-    SCHWZ_REQUIRE(A && out, "schwz_pcg_create: null argument");
-    SCHWZ_REQUIRE(A->v.nrows == A->v.ncols, "schwz_pcg_create: matrix not square");
-    SCHWZ_REQUIRE(precond >= SCHWZ_PRECOND_NONE && precond <= SCHWZ_PRECOND_ISAI,
-                  "schwz_pcg_create: unknown preconditioner");
-    SCHWZ_REQUIRE(block_size >= 1 && block_size <= 32, "schwz_pcg_create: block size must be in 1..32");
-    if (precond == SCHWZ_PRECOND_BLOCK_JACOBI && block_size == 1) precond = SCHWZ_PRECOND_JACOBI;
-    schwz_pcg *s = new schwz_pcg();
-    s->A = A;
-    s->precond = precond;
-    s->block_size = block_size;
-    s->n = A->v.nrows;
     const size_t nb = (size_t)(s->n ? s->n : 1) * sizeof(double);
     SCHWZ_HIP_TRY(hipMalloc((void **)&s->r, nb));
     SCHWZ_HIP_TRY(hipMalloc((void **)&s->p, nb));
@@ -1901,10 +1891,28 @@ int schwz_pcg_create_ex(const schwz_csr *A, int precond, int block_size, schwz_p
     }
     if (precond == SCHWZ_PRECOND_BLOCK_JACOBI || precond == SCHWZ_PRECOND_ILU || precond == SCHWZ_PRECOND_ISAI) {
         int rc = pcg_setup_general(s);
-        if (rc) {
-            schwz_pcg_destroy(s);
-            return rc;
-        }
+        if (rc) return rc;
+    }
+    return SCHWZ_OK;
+}
+
+int schwz_pcg_create_ex(const schwz_csr *A, int precond, int block_size, schwz_pcg **out)
+{
+    SCHWZ_REQUIRE(A && out, "schwz_pcg_create: null argument");
+    SCHWZ_REQUIRE(A->v.nrows == A->v.ncols, "schwz_pcg_create: matrix not square");
+    SCHWZ_REQUIRE(precond >= SCHWZ_PRECOND_NONE && precond <= SCHWZ_PRECOND_ISAI,
+                  "schwz_pcg_create: unknown preconditioner");
+    SCHWZ_REQUIRE(block_size >= 1 && block_size <= 32, "schwz_pcg_create: block size must be in 1..32");
+    if (precond == SCHWZ_PRECOND_BLOCK_JACOBI && block_size == 1) precond = SCHWZ_PRECOND_JACOBI;
+    schwz_pcg *s = new schwz_pcg();
+    s->A = A;
+    s->precond = precond;
+    s->block_size = block_size;
+    s->n = A->v.nrows;
+    const int rc = pcg_build(s, A, precond);
+    if (rc) {
+        schwz_pcg_destroy(s);
+        return rc;
     }
     *out = s;
     return SCHWZ_OK;
