@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--slab", default="512,512,64",
                     help="N>1: per-GPU slab nx,ny,nz (grid = nx x ny x nz*N; default = configs[2] at N=8)")
     ap.add_argument("--spmv-variant", type=int, default=0)
+    ap.add_argument("--strong", default=None, metavar="NX,NY,NZ",
+                    help="strong scaling: this whole grid (e.g. 512,512,512 = configs[2]) on every N, z-slabs")
     ap.add_argument("--overlapped", action="store_true",
                     help="one-sided overlapped exchange with decentralised convergence (configs[4] flavour)")
     ap.add_argument("--mixed-halo", action="store_true", help="fp32 halo wire format (use_mixed_precision)")
@@ -131,14 +133,22 @@ def main():
         comm = schwz.TorchDistComm(device=torch.device("cuda", local_rank))
         comm.device_index = local_rank
         assert comm.size == N, "--gpus must equal the launched world size"
-        sx, sy, sz = [int(t) for t in a.slab.split(",")]
-        shape = (sx, sy, sz * N)
-        workload = "3D Poisson %dx%dx%d, %d z-slab subdomains (%.1fM rows/GPU), overlap 2" % (
-            sx, sy, sz * N, N, sx * sy * sz / 1e6)
+        if a.strong:
+            shape = tuple(int(t) for t in a.strong.split(","))
+            workload = "3D Poisson %dx%dx%d (fixed), %d z-slab subdomains, overlap 2" % (shape + (N,))
+        else:
+            sx, sy, sz = [int(t) for t in a.slab.split(",")]
+            shape = (sx, sy, sz * N)
+            workload = "3D Poisson %dx%dx%d, %d z-slab subdomains (%.1fM rows/GPU), overlap 2" % (
+                sx, sy, sz * N, N, sx * sy * sz / 1e6)
     else:
         comm = schwz.InProcessComm(1)
-        shape = (a.size, a.size, a.size)
-        workload = "3D Poisson %d^3, 1 subdomain on 1 MI355X (BASELINE configs[1])" % a.size
+        if a.strong:
+            shape = tuple(int(t) for t in a.strong.split(","))
+            workload = "3D Poisson %dx%dx%d (fixed), 1 subdomain on 1 MI355X" % shape
+        else:
+            shape = (a.size, a.size, a.size)
+            workload = "3D Poisson %d^3, 1 subdomain on 1 MI355X (BASELINE configs[1])" % a.size
     rank = comm.rank
 
     t_setup = time.perf_counter()
@@ -241,14 +251,16 @@ def main():
                      "algorithmic_bytes_per_launch": alg_spmv}
     line = {
         "metric": "RAS iterations/sec (3D Poisson; subdomain-iterations aggregated over GPUs)",
-        "value": N * iters_per_s,
-        "unit": "subdomain-iter/s",
+        # weak scaling: subdomain-iterations/s of the whole job; strong scaling (fixed grid): the job's
+        # outer iterations/s
+        "value": iters_per_s if a.strong else N * iters_per_s,
+        "unit": "outer-iter/s" if a.strong else "subdomain-iter/s",
         "n_gpus": N,
         "steps": a.steps,
         "warmup": a.warmup,
         "ms_per_step": 1e3 * elapsed / a.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if a.strong else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic (7-point Dirichlet Laplacian generated in place, rhs = 1, x0 = 0)",
