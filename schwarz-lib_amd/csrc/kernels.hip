@@ -2351,7 +2351,7 @@ int schwz_trs_solve(schwz_trs *t, const double *d_b, double *d_y, schwz_stream s
     }();
     hipStream_t user_stream = st;
     bool capturing = false;
-    if (graphs_on && t->l_plan.size() + t->u_plan.size() > 8) {
+    if (graphs_on && !t->graphs_failed && t->l_plan.size() + t->u_plan.size() > 8) {
         for (const auto &g : t->graphs)
             if (g.b == d_b && g.y == d_y) {
                 SCHWZ_HIP_TRY(hipGraphLaunch(g.exec, user_stream));
@@ -2392,13 +2392,18 @@ int schwz_trs_solve(schwz_trs *t, const double *d_b, double *d_y, schwz_stream s
     hipLaunchKernelGGL(trs_permute_out_kernel, dim3(grid_for(t->n)), dim3(kBlock), 0, st, t->n, t->perm, t->w0, d_y);
     if (capturing) {
         hipGraph_t graph = nullptr;
-        SCHWZ_HIP_TRY(hipStreamEndCapture(t->capture_stream, &graph));
+        if (hipStreamEndCapture(t->capture_stream, &graph) != hipSuccess || !graph) {
+            (void)hipGetLastError();
+            t->graphs_failed = true;
+            return schwz_trs_solve(t, d_b, d_y, stream);
+        }
         hipGraphExec_t exec = nullptr;
         const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
-        if (e != hipSuccess) {
-            set_error(std::string("schwz_trs_solve: hipGraphInstantiate: ") + hipGetErrorString(e));
-            return SCHWZ_ERR_HIP;
+        if (e != hipSuccess) {  // no graph on this system: launch by launch from now on
+            (void)hipGetLastError();
+            t->graphs_failed = true;
+            return schwz_trs_solve(t, d_b, d_y, stream);
         }
         t->graphs.push_back({d_b, d_y, exec});
         SCHWZ_HIP_TRY(hipGraphLaunch(exec, user_stream));

@@ -253,6 +253,7 @@ struct schwz_trs {
     };
     std::vector<Captured> graphs;
     hipStream_t capture_stream = nullptr;
+    bool graphs_failed = false;  // capture / instantiate refused once: launch by launch from then on
 };
 
 // host-side global problem (explicit CSR or analytic stencil)
