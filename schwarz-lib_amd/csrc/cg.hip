@@ -1,0 +1,859 @@
+// Device-resident preconditioned CG: the fused vector kernels, the preconditioner applications
+// (Jacobi, block-Jacobi, ILU(0) sweeps, ISAI products), the stored-q and the q-free iteration,
+// hipGraph replay for small systems, and the profiling hooks of bench.py's roofline leg.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cstdlib>
+#include <cstring>
+#include <unordered_map>
+
+#include "schwz_internal.hpp"
+#include "device_utils.hpp"
+
+namespace schwz {
+
+// ---------------------------------------------------------------------------
+// CG vector kernels.  One CG iteration = spmv_tiled_kernel<kSpmvDot> + these two.
+// Scalars live in CgState in HBM; nothing returns to the host inside the loop.
+// ---------------------------------------------------------------------------
+
+__global__ void cg_init_finalize_kernel(CgState *st, const double *partials, int nparts, double rtol,
+                                        double *norm_sq_out, int norm_bank)
+{
+    __shared__ double red[4];
+    const double rho = fold_partials(partials, nparts, red);
+    const double rr = fold_partials(partials + nparts, nparts, red);
+    if (norm_sq_out) {
+        const double n2 = fold_partials(partials + norm_bank * nparts, nparts, red);
+        if (threadIdx.x == 0) {
+            norm_sq_out[0] = n2;  // may be mapped host memory
+            __threadfence_system();
+        }
+    }
+    if (threadIdx.x == 0) {
+        st->rho[0] = rho;
+        st->rho[1] = 0.0;
+        st->rr = rr;
+        st->r0 = sqrt(rr);
+        st->iters = 0;
+        // loop-top test of iteration 0: ||r|| <= rtol*||r_initial||
+        st->stop_iter = (sqrt(rr) <= rtol * sqrt(rr)) ? 0 : INT_MAX;
+    }
+}
+
+typedef double vd2 __attribute__((ext_vector_type(2)));
+
+template <bool NT>
+__device__ __forceinline__ void store2(double *base, int64_t i, vd2 v)
+{
+    if (NT)
+        __builtin_nontemporal_store(v, reinterpret_cast<vd2 *>(base) + i);
+    else
+        reinterpret_cast<vd2 *>(base)[i] = v;
+}
+
+// 1/diag of rows 2i and 2i+1 in whichever representation the solver holds
+__device__ __forceinline__ vd2 diag_pair(const DiagView &dg, const vd2 *full2, const uint16_t *code2,
+                                         const double *ddict, int64_t i)
+{
+    vd2 d;
+    if (dg.mode == 1) {
+        d = full2[i];
+    } else if (dg.mode == 2) {
+        const unsigned c = code2[i];
+        d.x = ddict[c & 255u];
+        d.y = ddict[c >> 8];
+    } else {
+        d.x = d.y = dg.uniform;
+    }
+    return d;
+}
+
+__device__ __forceinline__ double diag_one(const DiagView &dg, const double *ddict, int64_t i)
+{
+    if (dg.mode == 1) return dg.full[i];
+    if (dg.mode == 2) return ddict[dg.code[i]];
+    return dg.uniform;
+}
+
+// x += alpha p ; r -= alpha q ; z = dinv r ; partials: r.z and r.r
+// U: 16-byte elements per lane in flight per trip; NT: non-temporal stores
+template <int U, bool NT>
+__global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, double *__restrict__ x,
+                                                           double *__restrict__ r,
+                                                           const double *__restrict__ p,
+                                                           const double *__restrict__ q,
+                                                           const DiagView dg,
+                                                           const double *pq_partials, int nparts_in,
+                                                           const CgState *st, int it,
+                                                           double *partials_out)
+{
+    __shared__ double red[4];
+    __shared__ double ddict[256];
+    if (it >= st->stop_iter) return;
+    if (dg.mode == 2) {
+        if (threadIdx.x < dg.ndict) ddict[threadIdx.x] = dg.dict[threadIdx.x];
+        __syncthreads();
+    }
+    const double *__restrict__ dinv = dg.mode == 1 ? dg.full : nullptr;
+    const uint16_t *dc2 = reinterpret_cast<const uint16_t *>(dg.code);
+    const double pq = fold_partials(pq_partials, nparts_in, red);
+    const double alpha = st->rho[it & 1] / pq;
+    double a0 = 0.0, a1 = 0.0;
+    const int64_t n2 = n >> 1;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const vd2 *x2 = reinterpret_cast<const vd2 *>(x);
+    const vd2 *r2 = reinterpret_cast<const vd2 *>(r);
+    const vd2 *p2 = reinterpret_cast<const vd2 *>(p);
+    const vd2 *q2 = reinterpret_cast<const vd2 *>(q);
+    const vd2 *d2 = reinterpret_cast<const vd2 *>(dinv);
+    for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < n2; i0 += stride * U) {
+        vd2 xv[U], rv[U], pv[U], qv[U], dv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i < n2) {
+                xv[u] = x2[i];
+                rv[u] = r2[i];
+                pv[u] = p2[i];
+                qv[u] = q2[i];
+                dv[u] = diag_pair(dg, d2, dc2, ddict, i);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i < n2) {
+                xv[u] += alpha * pv[u];
+                rv[u] -= alpha * qv[u];
+                store2<NT>(x, i, xv[u]);
+                store2<NT>(r, i, rv[u]);
+                vd2 z = rv[u];
+                if (dg.mode) z *= dv[u];
+                a0 += rv[u].x * z.x;
+                a0 += rv[u].y * z.y;
+                a1 += rv[u].x * rv[u].x;
+                a1 += rv[u].y * rv[u].y;
+            }
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
+        x[i] += alpha * p[i];
+        const double rv = r[i] - alpha * q[i];
+        r[i] = rv;
+        const double z = dg.mode ? diag_one(dg, ddict, i) * rv : rv;
+        a0 += rv * z;
+        a1 += rv * rv;
+    }
+    const double s0 = block_sum(a0, red);
+    const double s1 = block_sum(a1, red);
+    if (threadIdx.x == 0) {
+        partials_out[blockIdx.x] = s0;
+        partials_out[gridDim.x + blockIdx.x] = s1;
+    }
+}
+
+// beta = rho'/rho ; p = dinv r + beta p ; state update by workgroup 0
+template <int U, bool NT>
+__global__ __launch_bounds__(kBlock) void cg_direction_kernel(int64_t n, double *__restrict__ p,
+                                                              const double *__restrict__ r,
+                                                              const DiagView dg,
+                                                              const double *partials_in, int nparts,
+                                                              CgState *st, int it, double rtol)
+{
+    // with a general preconditioner `r` is already z = M^-1 r and dg.mode is 0
+    __shared__ double red[4];
+    __shared__ double ddict[256];
+    if (it >= st->stop_iter) return;
+    if (dg.mode == 2) {
+        if (threadIdx.x < dg.ndict) ddict[threadIdx.x] = dg.dict[threadIdx.x];
+        __syncthreads();
+    }
+    const double *__restrict__ dinv = dg.mode == 1 ? dg.full : nullptr;
+    const uint16_t *dc2 = reinterpret_cast<const uint16_t *>(dg.code);
+    const double rho_new = fold_partials(partials_in, nparts, red);
+    const double rr = fold_partials(partials_in + nparts, nparts, red);
+    const double beta = rho_new / st->rho[it & 1];
+    const int64_t n2 = n >> 1;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const vd2 *p2 = reinterpret_cast<const vd2 *>(p);
+    const vd2 *r2 = reinterpret_cast<const vd2 *>(r);
+    const vd2 *d2 = reinterpret_cast<const vd2 *>(dinv);
+    for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < n2; i0 += stride * U) {
+        vd2 pv[U], zv[U], dv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i < n2) {
+                pv[u] = p2[i];
+                zv[u] = r2[i];
+                dv[u] = diag_pair(dg, d2, dc2, ddict, i);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i < n2) {
+                if (dg.mode) zv[u] *= dv[u];
+                store2<NT>(p, i, zv[u] + beta * pv[u]);
+            }
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
+        const double z = dg.mode ? diag_one(dg, ddict, i) * r[i] : r[i];
+        p[i] = z + beta * p[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // other workgroups read rho[it&1] concurrently: the slot written here is the other one
+        st->rho[(it + 1) & 1] = rho_new;
+        st->rr = rr;
+        st->iters = st->iters + 1;
+        // 0, not it + 1: every later launch leaves at once whatever iteration index it carries (the
+        // recorded launches of a replayed hipGraph carry 0..15 again and again).  Workgroups of THIS
+        // launch that read the 0 early skip their part of p, which nobody will read any more.
+        if (sqrt(rr) <= rtol * st->r0) st->stop_iter = 0;
+    }
+}
+
+// Measured on MI355X (256^3): U = 2/4 and non-temporal stores change the PCG iteration time by
+// < 1 % (0.403 / 0.406 / 0.417 ms for U = 1 / 2 / 4): these kernels sit at the mixed
+// read+write HBM ceiling (~5.0-5.5 TB/s), so the plain shape is used.
+
+
+// dinv[i] = 1 / A[i][i] (1 when the row stores no diagonal): scalar Jacobi, i.e.
+// block-Jacobi with max_block_size 1
+__global__ void extract_dinv_kernel(CsrView A, double *__restrict__ dinv)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.nrows; i += stride) {
+        double d = 1.0;
+        for (int j = A.rp[i]; j < A.rp[i + 1]; ++j)
+            if (A.col[j] == i) d = A.val[j];
+        dinv[i] = 1.0 / d;
+    }
+}
+
+// ---- block-Jacobi apply and the vector pieces of the general preconditioned CG -------------
+
+// z[i] = sum_j inv[blk_id[i / bs]][i % bs][j] * r[(i / bs) * bs + j]
+__global__ __launch_bounds__(kBlock) void block_jacobi_apply_kernel(int64_t n, int bs,
+                                                                    const schwz_idx *__restrict__ blk_id,
+                                                                    const double *__restrict__ blk_inv,
+                                                                    const double *__restrict__ r,
+                                                                    double *__restrict__ z)
+{
+#pragma clang fp contract(off)
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const int64_t b = i / bs, r0 = b * bs;
+        const double *row = blk_inv + ((int64_t)blk_id[b] * bs + (i - r0)) * bs;
+        double s = 0.0;
+        for (int j = 0; j < bs && r0 + j < n; ++j) s += row[j] * r[r0 + j];
+        z[i] = s;
+    }
+}
+
+// partial sums of r.z and r.r (banks 0 and 1), optionally p := z
+__global__ __launch_bounds__(kBlock) void dot_rz_kernel(int64_t n, const double *__restrict__ r,
+                                                        const double *__restrict__ z, double *__restrict__ p_out,
+                                                        const CgState *st, int it, double *partials_out)
+{
+    __shared__ double red[4];
+    if (st && it >= st->stop_iter) return;
+    double a0 = 0.0, a1 = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const double rv = r[i], zv = z[i];
+        a0 += rv * zv;
+        a1 += rv * rv;
+        if (p_out) p_out[i] = zv;
+    }
+    const double s0 = block_sum(a0, red);
+    const double s1 = block_sum(a1, red);
+    if (threadIdx.x == 0) {
+        partials_out[blockIdx.x] = s0;
+        partials_out[gridDim.x + blockIdx.x] = s1;
+    }
+}
+
+}  // namespace schwz
+
+using namespace schwz;
+
+// ---- profiling hooks (bench.py roofline leg) ------------------------------------
+// HIP-event pairs around the SpMV and the update launch of every CG iteration, on the stream
+// they are launched on.
+
+namespace {
+struct ProfState {
+    bool on = false;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> kind;  // per event pair: 0 = the SpMV launch of a CG iteration, 1 = its update launch
+    size_t used = 0;
+    double total[2] = {0.0, 0.0};
+    int64_t count[2] = {0, 0};
+} g_prof;
+}  // namespace
+
+extern "C" {
+
+int schwz_profile_begin(int capacity)
+{
+    SCHWZ_REQUIRE(capacity > 0, "schwz_profile_begin: capacity must be positive");
+    while (g_prof.ev.size() < (size_t)2 * capacity) {
+        hipEvent_t e;
+        SCHWZ_HIP_TRY(hipEventCreate(&e));
+        g_prof.ev.push_back(e);
+    }
+    g_prof.kind.assign((size_t)capacity, 0);
+    g_prof.used = 0;
+    g_prof.on = true;
+    return SCHWZ_OK;
+}
+
+int schwz_profile_end(double *h_total_ms, int64_t *h_launches)
+{
+    SCHWZ_REQUIRE(h_total_ms && h_launches, "schwz_profile_end: null output");
+    g_prof.on = false;
+    SCHWZ_HIP_TRY(hipDeviceSynchronize());
+    g_prof.total[0] = g_prof.total[1] = 0.0;
+    g_prof.count[0] = g_prof.count[1] = 0;
+    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+        float ms = 0.f;
+        SCHWZ_HIP_TRY(hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]));
+        const int k = g_prof.kind[i / 2] ? 1 : 0;
+        g_prof.total[k] += ms;
+        g_prof.count[k] += 1;
+    }
+    *h_total_ms = g_prof.total[0];
+    *h_launches = g_prof.count[0];
+    g_prof.used = 0;
+    return SCHWZ_OK;
+}
+
+int schwz_profile_kind(int kind, double *h_total_ms, int64_t *h_launches)
+{
+    SCHWZ_REQUIRE(h_total_ms && h_launches && (kind == 0 || kind == 1), "schwz_profile_kind: bad arguments");
+    *h_total_ms = g_prof.total[kind];
+    *h_launches = g_prof.count[kind];
+    return SCHWZ_OK;
+}
+
+// ---- PCG --------------------------------------------------------------------
+
+int schwz_pcg_create(const schwz_csr *A, int precond, schwz_pcg **out)
+{
+    return schwz_pcg_create_ex(A, precond, 1, out);
+}
+
+// block-Jacobi / ILU(0) setup: the (setup-time) host copy of the matrix comes back from HBM
+static int pcg_setup_general(schwz_pcg *s)
+{
+    const CsrView &A = s->A->v;
+    const int64_t n = s->n;
+    std::vector<schwz_idx> rp((size_t)n + 1), col((size_t)A.nnz);
+    std::vector<double> val((size_t)A.nnz);
+    SCHWZ_HIP_TRY(hipMemcpy(rp.data(), A.rp, rp.size() * sizeof(schwz_idx), hipMemcpyDeviceToHost));
+    if (A.nnz) {
+        SCHWZ_HIP_TRY(hipMemcpy(col.data(), A.col, col.size() * sizeof(schwz_idx), hipMemcpyDeviceToHost));
+        SCHWZ_HIP_TRY(hipMemcpy(val.data(), A.val, val.size() * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    SCHWZ_HIP_TRY(hipMalloc((void **)&s->z, (size_t)(n ? n : 1) * sizeof(double)));
+    if (s->precond == SCHWZ_PRECOND_ILU || s->precond == SCHWZ_PRECOND_ISAI) {
+        schwz_idx *l_rp, *l_col, *u_rp, *u_col;
+        double *l_val, *u_val;
+        int rc = schwz_ilu0(n, rp.data(), col.data(), val.data(), &l_rp, &l_col, &l_val, &u_rp, &u_col, &u_val);
+        if (rc) return rc;
+        if (s->precond == SCHWZ_PRECOND_ISAI) {
+            // Ilu<LowerIsai, UpperIsai> (solve.cpp:616-638): z = W_U (W_L r), two CSR products on
+            // the patterns of L and U, stored like any other matrix of this library
+            double *wl = nullptr, *wu = nullptr;
+            rc = schwz_isai(n, l_rp, l_col, l_val, 1, &wl);
+            if (!rc) rc = schwz_isai(n, u_rp, u_col, u_val, 0, &wu);
+            if (!rc) rc = schwz_csr_create(n, n, l_rp, l_col, wl, &s->isai_l);
+            if (!rc) rc = schwz_csr_create(n, n, u_rp, u_col, wu, &s->isai_u);
+            if (!rc && hipMalloc((void **)&s->isai_tmp, (size_t)(n ? n : 1) * sizeof(double)) != hipSuccess) {
+                set_error("schwz_pcg_create: out of device memory (ISAI work vector)");
+                rc = SCHWZ_ERR_HIP;
+            }
+            schwz_free(wl);
+            schwz_free(wu);
+        } else {
+            rc = schwz_trs_create(n, l_rp, l_col, l_val, u_rp, u_col, u_val, nullptr, &s->ilu);
+        }
+        schwz_free(l_rp);
+        schwz_free(l_col);
+        schwz_free(l_val);
+        schwz_free(u_rp);
+        schwz_free(u_col);
+        schwz_free(u_val);
+        return rc;
+    }
+    // block-Jacobi: consecutive blocks of bs rows, inverted by Gauss-Jordan with partial
+    // pivoting; identical inverse blocks are stored once (a stencil matrix has a handful)
+    const int bs = s->block_size;
+    const int64_t nb = (n + bs - 1) / bs;
+    std::vector<schwz_idx> id((size_t)nb);
+    std::vector<double> uniq, blk((size_t)bs * bs), inv((size_t)bs * bs);
+    std::unordered_multimap<uint64_t, schwz_idx> seen;
+    for (int64_t b = 0; b < nb; ++b) {
+        const int64_t r0 = b * bs;
+        std::fill(blk.begin(), blk.end(), 0.0);
+        for (int i = 0; i < bs; ++i) {
+            if (r0 + i >= n) {
+                blk[(size_t)i * bs + i] = 1.0;
+                continue;
+            }
+            for (schwz_idx j = rp[(size_t)(r0 + i)]; j < rp[(size_t)(r0 + i) + 1]; ++j)
+                if (col[(size_t)j] >= r0 && col[(size_t)j] < r0 + bs)
+                    blk[(size_t)i * bs + (col[(size_t)j] - r0)] = val[(size_t)j];
+        }
+        uint64_t h = 1469598103934665603ull;
+        for (double v : blk) {
+            uint64_t bits;
+            std::memcpy(&bits, &v, 8);
+            h = (h ^ bits) * 1099511628211ull;
+        }
+        // invert (the copy in blk is destroyed)
+        std::vector<double> a = blk;
+        for (int i = 0; i < bs; ++i)
+            for (int j = 0; j < bs; ++j) inv[(size_t)i * bs + j] = i == j ? 1.0 : 0.0;
+        for (int c = 0; c < bs; ++c) {
+            int piv = c;
+            for (int r = c + 1; r < bs; ++r)
+                if (std::fabs(a[(size_t)r * bs + c]) > std::fabs(a[(size_t)piv * bs + c])) piv = r;
+            if (a[(size_t)piv * bs + c] == 0.0) {
+                set_error("block-Jacobi: singular diagonal block");
+                return SCHWZ_ERR_NOT_SPD;
+            }
+            if (piv != c)
+                for (int j = 0; j < bs; ++j) {
+                    std::swap(a[(size_t)c * bs + j], a[(size_t)piv * bs + j]);
+                    std::swap(inv[(size_t)c * bs + j], inv[(size_t)piv * bs + j]);
+                }
+            const double d = a[(size_t)c * bs + c];
+            for (int j = 0; j < bs; ++j) {
+                a[(size_t)c * bs + j] /= d;
+                inv[(size_t)c * bs + j] /= d;
+            }
+            for (int r = 0; r < bs; ++r) {
+                if (r == c) continue;
+                const double f = a[(size_t)r * bs + c];
+                if (f == 0.0) continue;
+                for (int j = 0; j < bs; ++j) {
+                    a[(size_t)r * bs + j] -= f * a[(size_t)c * bs + j];
+                    inv[(size_t)r * bs + j] -= f * inv[(size_t)c * bs + j];
+                }
+            }
+        }
+        schwz_idx found = -1;
+        auto range = seen.equal_range(h);
+        for (auto it = range.first; it != range.second; ++it)
+            if (std::memcmp(&uniq[(size_t)it->second * bs * bs], inv.data(), sizeof(double) * bs * bs) == 0) {
+                found = it->second;
+                break;
+            }
+        if (found < 0) {
+            found = (schwz_idx)(uniq.size() / ((size_t)bs * bs));
+            uniq.insert(uniq.end(), inv.begin(), inv.end());
+            seen.emplace(h, found);
+        }
+        id[(size_t)b] = found;
+    }
+    int rc;
+    void *d;
+    if ((rc = upload(id.data(), id.size(), &d))) return rc;
+    s->d_blk_id = (schwz_idx *)d;
+    if ((rc = upload(uniq.data(), uniq.size(), &d))) return rc;
+    s->d_blk_inv = (double *)d;
+    return SCHWZ_OK;
+}
+
+// everything of schwz_pcg_create_ex that can fail half way: the caller destroys `s` on error
+static int pcg_build(schwz_pcg *s, const schwz_csr *A, int precond)
+{
+    const size_t nb = (size_t)(s->n ? s->n : 1) * sizeof(double);
+    SCHWZ_HIP_TRY(hipMalloc((void **)&s->r, nb));
+    SCHWZ_HIP_TRY(hipMalloc((void **)&s->p, nb));
+    SCHWZ_HIP_TRY(hipMalloc((void **)&s->q, nb));
+    SCHWZ_HIP_TRY(hipMalloc((void **)&s->partials, sizeof(double) * 5 * kMaxGrid));
+    SCHWZ_HIP_TRY(hipMalloc((void **)&s->d_norm_sq, sizeof(double) * 2));
+    SCHWZ_HIP_TRY(hipMalloc((void **)&s->state, sizeof(CgState)));
+    SCHWZ_HIP_TRY(hipHostMalloc((void **)&s->h_state, 2 * sizeof(CgState), hipHostMallocDefault));
+    SCHWZ_HIP_TRY(hipEventCreateWithFlags(&s->ev[0], hipEventDisableTiming));
+    SCHWZ_HIP_TRY(hipEventCreateWithFlags(&s->ev[1], hipEventDisableTiming));
+    if (precond == SCHWZ_PRECOND_JACOBI) {
+        SCHWZ_HIP_TRY(hipMalloc((void **)&s->dinv, nb));
+        if (s->n) {
+            hipLaunchKernelGGL(extract_dinv_kernel, dim3(grid_for(s->n)), dim3(kBlock), 0, 0, A->v, s->dinv);
+            SCHWZ_HIP_TRY(hipGetLastError());
+            SCHWZ_HIP_TRY(hipDeviceSynchronize());
+        }
+        // compact representation for the per-iteration vector kernels (DiagView)
+        s->diag.mode = 1;
+        s->diag.full = s->dinv;
+        const char *env = std::getenv("SCHWZ_DIAG_DICT");
+        if (s->n && !(env && env[0] == '0')) {
+            std::vector<double> h((size_t)s->n);
+            SCHWZ_HIP_TRY(hipMemcpy(h.data(), s->dinv, (size_t)s->n * sizeof(double), hipMemcpyDeviceToHost));
+            std::vector<double> dict;
+            std::vector<uint8_t> code((size_t)s->n + 2, 0);
+            bool ok = true;
+            for (int64_t i = 0; i < s->n && ok; ++i) {
+                int c = -1;
+                for (size_t k = 0; k < dict.size(); ++k)
+                    if (std::memcmp(&dict[k], &h[(size_t)i], 8) == 0) {
+                        c = (int)k;
+                        break;
+                    }
+                if (c < 0) {
+                    if (dict.size() == 256) {
+                        ok = false;
+                        break;
+                    }
+                    c = (int)dict.size();
+                    dict.push_back(h[(size_t)i]);
+                }
+                code[(size_t)i] = (uint8_t)c;
+            }
+            if (ok && dict.size() == 1) {
+                s->diag.mode = 3;
+                s->diag.uniform = dict[0];
+            } else if (ok && dict.size() <= 16) {  // linear search above stays cheap
+                int rc;
+                if ((rc = upload(code.data(), code.size(), &s->d_dcode)) ||
+                    (rc = upload(dict.data(), dict.size(), &s->d_ddict)))
+                    return rc;
+                s->diag.mode = 2;
+                s->diag.code = (const uint8_t *)s->d_dcode;
+                s->diag.dict = (const double *)s->d_ddict;
+                s->diag.ndict = (int)dict.size();
+            }
+        }
+    }
+    if (precond == SCHWZ_PRECOND_BLOCK_JACOBI || precond == SCHWZ_PRECOND_ILU || precond == SCHWZ_PRECOND_ISAI) {
+        int rc = pcg_setup_general(s);
+        if (rc) return rc;
+    }
+    return SCHWZ_OK;
+}
+
+int schwz_pcg_create_ex(const schwz_csr *A, int precond, int block_size, schwz_pcg **out)
+{
+    SCHWZ_REQUIRE(A && out, "schwz_pcg_create: null argument");
+    SCHWZ_REQUIRE(A->v.nrows == A->v.ncols, "schwz_pcg_create: matrix not square");
+    SCHWZ_REQUIRE(precond >= SCHWZ_PRECOND_NONE && precond <= SCHWZ_PRECOND_ISAI,
+                  "schwz_pcg_create: unknown preconditioner");
+    SCHWZ_REQUIRE(block_size >= 1 && block_size <= 32, "schwz_pcg_create: block size must be in 1..32");
+    if (precond == SCHWZ_PRECOND_BLOCK_JACOBI && block_size == 1) precond = SCHWZ_PRECOND_JACOBI;
+    schwz_pcg *s = new schwz_pcg();
+    s->A = A;
+    s->precond = precond;
+    s->block_size = block_size;
+    s->n = A->v.nrows;
+    const int rc = pcg_build(s, A, precond);
+    if (rc) {
+        schwz_pcg_destroy(s);
+        return rc;
+    }
+    *out = s;
+    return SCHWZ_OK;
+}
+
+void schwz_pcg_destroy(schwz_pcg *s)
+{
+    if (!s) return;
+    (void)hipFree(s->r);
+    (void)hipFree(s->p);
+    (void)hipFree(s->q);
+    (void)hipFree(s->dinv);
+    (void)hipFree(s->z);
+    (void)hipFree(s->d_blk_id);
+    (void)hipFree(s->d_blk_inv);
+    for (auto &g : s->graphs) (void)hipGraphExecDestroy(g.exec);
+    if (s->capture_stream) (void)hipStreamDestroy(s->capture_stream);
+    schwz_trs_destroy(s->ilu);
+    schwz_csr_destroy(s->isai_l);
+    schwz_csr_destroy(s->isai_u);
+    (void)hipFree(s->isai_tmp);
+    (void)hipFree(s->d_dcode);
+    (void)hipFree(s->d_ddict);
+    (void)hipFree(s->partials);
+    (void)hipFree(s->d_norm_sq);
+    (void)hipFree(s->state);
+    (void)hipHostFree(s->h_state);
+    if (s->ev[0]) (void)hipEventDestroy(s->ev[0]);
+    if (s->ev[1]) (void)hipEventDestroy(s->ev[1]);
+    delete s;
+}
+
+}  // extern "C"
+
+namespace schwz {
+
+// z = M^-1 r for the preconditioners that are operators of their own
+__global__ __launch_bounds__(kBlock) void diag_scale_kernel(int64_t n, const double *__restrict__ dinv,
+                                                            const double *__restrict__ in, double *__restrict__ out)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) out[i] = dinv[i] * in[i];
+}
+
+// out = M^-1 in for whichever preconditioner the object holds (in != out)
+int precond_apply(schwz_pcg *s, const double *in, double *out, hipStream_t st)
+{
+    if (s->n == 0) return SCHWZ_OK;
+    if (s->precond == SCHWZ_PRECOND_ILU) return schwz_trs_solve(s->ilu, in, out, (schwz_stream)st);
+    if (s->precond == SCHWZ_PRECOND_ISAI) {
+        SpmvArgs a;
+        a.x = in;
+        a.y = s->isai_tmp;
+        int rc = launch_spmv(s->isai_l->v, kSpmvPlain, a, 0, st);
+        if (rc) return rc;
+        a.x = s->isai_tmp;
+        a.y = out;
+        return launch_spmv(s->isai_u->v, kSpmvPlain, a, 0, st);
+    }
+    if (s->precond == SCHWZ_PRECOND_BLOCK_JACOBI) {
+        hipLaunchKernelGGL(block_jacobi_apply_kernel, dim3(grid_for(s->n)), dim3(kBlock), 0, st, s->n, s->block_size,
+                           s->d_blk_id, s->d_blk_inv, in, out);
+    } else if (s->precond == SCHWZ_PRECOND_JACOBI) {
+        hipLaunchKernelGGL(diag_scale_kernel, dim3(grid_for(s->n)), dim3(kBlock), 0, st, s->n, s->dinv, in, out);
+    } else {
+        return launch_copy(s->n, in, out, st);
+    }
+    SCHWZ_HIP_TRY(hipGetLastError());
+    return SCHWZ_OK;
+}
+
+static int pcg_apply_general(schwz_pcg *s, hipStream_t st) { return precond_apply(s, s->r, s->z, st); }
+
+static bool pcg_is_general(const schwz_pcg *s)
+{
+    return s->precond == SCHWZ_PRECOND_BLOCK_JACOBI || s->precond == SCHWZ_PRECOND_ILU ||
+           s->precond == SCHWZ_PRECOND_ISAI;
+}
+
+// First half of a solve: r = b - A x, p = M^-1 r, rho, ||r||^2 -> CgState.  With
+// `fused` the same pass over the matrix also yields ||b - A x2||^2 over the rows
+// below row_limit in s->d_norm_sq[0] (x2 == nullptr: x2 is x).
+int pcg_begin(schwz_pcg *s, const double *d_b, double *d_x, double rtol, bool fused, const double *d_x2,
+              int64_t row_limit, hipStream_t st)
+{
+    const CsrView &A = s->A->v;
+    const int gs = spmv_grid(A, s->variant);
+    SpmvArgs a;
+    a.x = d_x;
+    a.x2 = d_x2;
+    a.b = d_b;
+    a.y = s->r;
+    a.p = s->p;
+    a.dinv = s->dinv;
+    a.partials = s->partials;
+    a.row_limit = row_limit;
+    // x2 == x over all rows: the check residual IS the start residual (rr bank)
+    const bool same = fused && d_x2 == nullptr && row_limit >= s->n;
+    if (pcg_is_general(s)) a.dinv = nullptr;  // p := r for now, z follows
+    int rc = launch_spmv(A, (fused && !same) ? kSpmvResidDual : kSpmvResidInit, a, s->variant, st);
+    if (rc) return rc;
+    if (pcg_is_general(s)) {
+        // the check-residual norm (bank 1 or 2 of the SpMV partials) first, then z = M^-1 r,
+        // p = z and rho = r.z, ||r||^2 from the vector-kernel partials
+        if (fused) {
+            if ((rc = launch_final_norm(s->partials + (same ? 1 : 2) * gs, gs, s->d_norm_sq, st))) return rc;
+        }
+        if ((rc = pcg_apply_general(s, st))) return rc;
+        const int gv = grid_for(s->n);
+        double *part_vec = s->partials + 3 * kMaxGrid;
+        hipLaunchKernelGGL(dot_rz_kernel, dim3(gv), dim3(kBlock), 0, st, s->n, s->r, s->z, s->p, nullptr, 0, part_vec);
+        hipLaunchKernelGGL(cg_init_finalize_kernel, dim3(1), dim3(kBlock), 0, st, s->state, part_vec, gv, rtol, nullptr,
+                           1);
+        SCHWZ_HIP_TRY(hipGetLastError());
+        return SCHWZ_OK;
+    }
+    hipLaunchKernelGGL(cg_init_finalize_kernel, dim3(1), dim3(kBlock), 0, st, s->state, s->partials, gs, rtol,
+                       fused ? s->d_norm_sq : nullptr, same ? 1 : 2);
+    SCHWZ_HIP_TRY(hipGetLastError());
+    return SCHWZ_OK;
+}
+
+// Second half: up to max_iters CG updates.  With a positive tolerance the host
+// looks at the state every `chunk` iterations, one chunk behind the launches, so
+// the queue never drains.
+int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream_t st)
+{
+    const CsrView &A = s->A->v;
+    const int64_t n = s->n;
+    const int gs = spmv_grid(A, s->variant);
+    const int gv = grid_for((n + 1) / 2);
+    double *part_spmv = s->partials;                // [3][gs]
+    double *part_vec = s->partials + 3 * kMaxGrid;  // [2][gv]
+    const bool poll = rtol > 0.0;
+    const bool general = pcg_is_general(s);
+    // SCHWZ_CG_QFREE=0 keeps the stored-q iteration for row-pair coded matrices too (A/B runs)
+    static const bool qfree_on = [] {
+        const char *e = std::getenv("SCHWZ_CG_QFREE");
+        return !(e && e[0] == '0');
+    }();
+    const bool qfree = qfree_on && !general && A.pair_id && s->variant == 0 && s->diag.mode != 2;
+    // one CG iteration on stream `q`; `it` only enters through its parity (rho slot) and through
+    // "it >= stop_iter", and stop_iter is 0 once the tolerance test has fired: a recorded sequence
+    // of an even number of iterations can therefore be replayed as a hipGraph
+    auto launch_iteration = [&](int it, hipStream_t q, bool instrument) -> int {
+        SpmvArgs a;
+        a.x = s->p;
+        a.y = s->q;
+        a.partials = part_spmv;
+        a.stop_iter = &s->state->stop_iter;
+        a.it = it;
+        const bool prof = instrument && g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
+        if (prof) SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used], q));
+        int rc = launch_spmv(A, qfree ? kSpmvDotOnly : kSpmvDot, a, s->variant, q);
+        if (rc) return rc;
+        if (prof) {
+            SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used + 1], q));
+            g_prof.kind[g_prof.used / 2] = 0;
+            g_prof.used += 2;
+        }
+        if (qfree) {
+            // q = A p is never stored: the update pass recomputes (A p)_i row by row while it
+            // streams x and r (spmv_pair.hip, kSpmvCgUpdate): 16 B per row less HBM traffic, a
+            // third of the stores of these two launches
+            SpmvArgs u;
+            u.x = s->p;
+            u.cg_x = d_x;
+            u.cg_r = s->r;
+            u.cg_state = s->state;
+            u.pq_partials = part_spmv;
+            u.pq_nparts = gs;
+            u.diag_mode = s->diag.mode;
+            u.diag_uniform = s->diag.uniform;
+            u.dinv = s->dinv;
+            u.partials = part_vec;
+            u.it = it;
+            const bool prof2 = instrument && g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
+            if (prof2) SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used], q));
+            if ((rc = launch_spmv(A, kSpmvCgUpdate, u, s->variant, q))) return rc;
+            if (prof2) {
+                SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used + 1], q));
+                g_prof.kind[g_prof.used / 2] = 1;
+                g_prof.used += 2;
+            }
+            hipLaunchKernelGGL((cg_direction_kernel<1, false>), dim3(gv), dim3(kBlock), 0, q, n, s->p, s->r, s->diag,
+                               part_vec, gs, s->state, it, rtol);
+        } else if (!general) {
+            hipLaunchKernelGGL((cg_update_kernel<1, false>), dim3(gv), dim3(kBlock), 0, q, n, d_x, s->r, s->p, s->q,
+                               s->diag, part_spmv, gs, s->state, it, part_vec);
+            hipLaunchKernelGGL((cg_direction_kernel<1, false>), dim3(gv), dim3(kBlock), 0, q, n, s->p, s->r, s->diag,
+                               part_vec, gv, s->state, it, rtol);
+        } else {
+            // x, r update without a preconditioner; z = M^-1 r; rho' = r.z; p = z + beta p
+            const DiagView none;
+            const int gz = grid_for(n);
+            hipLaunchKernelGGL((cg_update_kernel<1, false>), dim3(gv), dim3(kBlock), 0, q, n, d_x, s->r, s->p, s->q,
+                               none, part_spmv, gs, s->state, it, part_vec);
+            if ((rc = pcg_apply_general(s, q))) return rc;
+            hipLaunchKernelGGL(dot_rz_kernel, dim3(gz), dim3(kBlock), 0, q, n, s->r, s->z, (double *)nullptr, s->state,
+                               it, part_vec);
+            hipLaunchKernelGGL((cg_direction_kernel<1, false>), dim3(gv), dim3(kBlock), 0, q, n, s->p, s->z, none,
+                               part_vec, gz, s->state, it, rtol);
+        }
+        return SCHWZ_OK;
+    };
+    // Small systems are bound by launches, not bytes (33 k rows: 3 launches of ~3 us work each):
+    // kGraphIters iterations are captured once per (x, rtol) into a hipGraph -- on a private stream,
+    // the caller's may be the legacy default stream -- and replayed.  SCHWZ_CG_GRAPH=0 disables,
+    // =2 uses graphs for every size.
+    static const int graph_mode = [] {
+        const char *e = std::getenv("SCHWZ_CG_GRAPH");
+        return e ? std::atoi(e) : 1;
+    }();
+    const bool graphable = graph_mode != 0 && !general && !g_prof.on && (graph_mode == 2 || n <= kGraphRows);
+    hipGraphExec_t replay = nullptr;
+    if (graphable && max_iters >= kGraphIters) {
+        for (const auto &g : s->graphs)
+            if (g.x == d_x && g.rtol == rtol && g.variant == s->variant && g.qfree == qfree) replay = g.exec;
+        if (!replay && s->graphs.size() < 4) {
+            if (!s->capture_stream) SCHWZ_HIP_TRY(hipStreamCreateWithFlags(&s->capture_stream, hipStreamNonBlocking));
+            if (hipStreamBeginCapture(s->capture_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                int rc = SCHWZ_OK;
+                for (int k = 0; k < kGraphIters && !rc; ++k) rc = launch_iteration(k, s->capture_stream, false);
+                hipGraph_t graph = nullptr;
+                const hipError_t e1 = hipStreamEndCapture(s->capture_stream, &graph);
+                if (rc) {
+                    if (graph) (void)hipGraphDestroy(graph);
+                    return rc;
+                }
+                if (e1 == hipSuccess && hipGraphInstantiate(&replay, graph, nullptr, nullptr, 0) == hipSuccess)
+                    s->graphs.push_back({d_x, rtol, s->variant, qfree, replay});
+                else
+                    replay = nullptr;
+                if (graph) (void)hipGraphDestroy(graph);
+            }
+            (void)hipGetLastError();
+        }
+    }
+    int chunk = 16;
+    int it = 0, pending = -1, bank = 0;
+    bool stopped = false;
+    while (it < max_iters && !stopped) {
+        const int end = (poll && it + chunk < max_iters) ? it + chunk : max_iters;
+        while (it < end) {
+            if (replay && it % kGraphIters == 0 && end - it >= kGraphIters) {
+                SCHWZ_HIP_TRY(hipGraphLaunch(replay, st));
+                it += kGraphIters;
+                continue;
+            }
+            int rc = launch_iteration(it, st, true);
+            if (rc) return rc;
+            ++it;
+        }
+        SCHWZ_HIP_TRY(hipGetLastError());
+        if (poll && it < max_iters) {
+            if (pending >= 0) {
+                SCHWZ_HIP_TRY(hipEventSynchronize(s->ev[pending]));
+                if (s->h_state[pending].stop_iter != INT_MAX) stopped = true;
+            }
+            SCHWZ_HIP_TRY(hipMemcpyAsync(&s->h_state[bank], s->state, sizeof(CgState), hipMemcpyDeviceToHost, st));
+            SCHWZ_HIP_TRY(hipEventRecord(s->ev[bank], st));
+            pending = bank;
+            bank ^= 1;
+            if (chunk < 64) chunk *= 2;
+        }
+    }
+    return SCHWZ_OK;
+}
+
+}  // namespace schwz
+
+extern "C" {
+
+int schwz_pcg_solve(schwz_pcg *s, const double *d_b, double *d_x, double rtol, int max_iters,
+                    int *h_iters, double *h_resnorm, schwz_stream stream)
+{
+    SCHWZ_REQUIRE(s && d_b && d_x, "schwz_pcg_solve: null argument");
+    SCHWZ_REQUIRE(max_iters >= 0, "schwz_pcg_solve: negative max_iters");
+    SCHWZ_REQUIRE((reinterpret_cast<uintptr_t>(d_x) & 15) == 0, "schwz_pcg_solve: x must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (s->n == 0) {
+        if (h_iters) *h_iters = 0;
+        if (h_resnorm) *h_resnorm = 0.0;
+        return SCHWZ_OK;
+    }
+    int rc = pcg_begin(s, d_b, d_x, rtol, false, nullptr, 0, st);
+    if (rc) return rc;
+    if ((rc = pcg_iterate(s, d_x, rtol, max_iters, st))) return rc;
+    if (h_iters || h_resnorm) {
+        SCHWZ_HIP_TRY(hipMemcpyAsync(&s->h_state[0], s->state, sizeof(CgState), hipMemcpyDeviceToHost, st));
+        SCHWZ_HIP_TRY(hipStreamSynchronize(st));
+        if (h_iters) *h_iters = s->h_state[0].iters;
+        if (h_resnorm) *h_resnorm = sqrt(s->h_state[0].rr);
+    }
+    return SCHWZ_OK;
+}
+
+}  // extern "C"

@@ -6,7 +6,7 @@
 // rotations, the same restatement as oracle/schwz_oracle.c::schwz_or_gmres, which scipy's GMRES
 // reproduces iteration for iteration.
 //
-// Device resident like the CG (kernels.hip): all scalars -- the Hessenberg column, the rotations,
+// Device resident like the CG (cg.hip): all scalars -- the Hessenberg column, the rotations,
 // the rotated right-hand side, the stop decision -- live in HBM; every vector kernel folds the
 // per-workgroup partial sums of the launch before it in a fixed order (bit-reproducible, no
 // atomics), and once the tolerance test has fired the remaining launches of the cycle return at

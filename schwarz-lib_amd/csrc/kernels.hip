@@ -1,9 +1,12 @@
-// HIP kernels for gfx950 (MI355X): CSR SpMV with LDS-staged products, fused CG
-// vector kernels, gather/scatter, level-scheduled triangular solves.
+// libschwz_hip.so, general part: gather / scatter (the four reference ops and the fp32 wire
+// variants), the interface (boundary) update, copies and STREAM-style probes, and the C ABI of the
+// device CSR matrix (upload, tiling, XCD deal, the lossless codings of spmv_pair.hip / spmv_dict.hip).
+// The SpMV kernels live in spmv_csr.hip / spmv_dict.hip / spmv_pair.hip, the solvers in cg.hip /
+// gmres.hip / trs.hip, the per-subdomain RAS steps in subdomain.hip.
 //
-// Everything here is HBM-bandwidth bound fp64 / int32 streaming work; there is no
-// dense contraction, so MFMA is deliberately unused (BASELINE.json north_star).
-// Wavefronts are 64 lanes; workgroups are 256 threads (4 waves).
+// Everything is HBM-bandwidth bound fp64 / int32 streaming work; there is no dense contraction, so
+// MFMA is deliberately unused (BASELINE.json north_star).  Wavefronts are 64 lanes; workgroups are
+// 256 threads (4 waves).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -15,1064 +18,6 @@
 #include "device_utils.hpp"
 
 namespace schwz {
-
-// ---------------------------------------------------------------------------
-// CSR SpMV, tiled: each workgroup owns a run of consecutive rows whose nonzeros
-// (<= kTileNnz) are read with unit stride, multiplied with the gathered x and
-// staged in LDS; one lane per row then sums its LDS segment.  Tiles are dealt to
-// workgroups so that each XCD (blockIdx % 8) sweeps one contiguous eighth of the
-// matrix: the x entries a tile shares with its neighbours (i+-1, i+-nx, i+-nx*ny
-// for the Poisson stencils) stay in that XCD's 4 MiB L2.
-// ---------------------------------------------------------------------------
-
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void spmv_tiled_kernel(CsrView A, SpmvArgs a)
-{
-    // every SpMV variant rounds each product before it is added (no FMA contraction), so
-    // that all variants -- and the sequential CPU oracle -- produce the same bits
-#pragma clang fp contract(off)
-    __shared__ double prod[kTileNnz];
-    __shared__ double red[4];
-    if (MODE == kSpmvDot || MODE == kSpmvResidInit) {
-        if (a.stop_iter && a.it >= *a.stop_iter) return;
-    }
-    const int tid = threadIdx.x;
-    const int xcd = blockIdx.x % kXcds;
-    const int slot = blockIdx.x / kXcds;
-    const int per_xcd = gridDim.x / kXcds;
-    const int chunk = (A.ntiles + kXcds - 1) / kXcds;
-    double acc0 = 0.0, acc1 = 0.0;
-
-    for (int t = slot; t < chunk; t += per_xcd) {
-        const int tile = xcd * chunk + t;
-        if (tile >= A.ntiles) break;
-        const int r0 = A.tile_row[tile], r1 = A.tile_row[tile + 1];
-        const int s = A.rp[r0], e = A.rp[r1];
-        const int cnt = e - s;
-        double sum = 0.0;
-        int row = r0 + tid;
-        bool have_row = false;
-        if (cnt <= kTileNnz) {
-            for (int i = tid; i < cnt; i += kBlock)
-                prod[i] = A.val[s + i] * a.x[A.col[s + i]];
-            __syncthreads();
-            if (row < r1) {
-                have_row = true;
-                const int b0 = A.rp[row] - s, b1 = A.rp[row + 1] - s;
-                for (int j = b0; j < b1; ++j) sum += prod[j];
-            }
-            __syncthreads();
-        } else {
-            // a single row longer than a tile: the whole workgroup reduces it
-            double part = 0.0;
-            for (int i = tid; i < cnt; i += kBlock) part += __dmul_rn(A.val[s + i], a.x[A.col[s + i]]);
-            part = block_sum(part, red);
-            row = r0;
-            if (tid == 0) {
-                have_row = true;
-                sum = part;
-            }
-        }
-        if (have_row) {
-            if (MODE == kSpmvPlain) {
-                a.y[row] = (a.beta == 0.0) ? a.alpha * sum : a.alpha * sum + a.beta * a.y[row];
-            } else if (MODE == kSpmvDot) {
-                a.y[row] = sum;
-                acc0 += a.x[row] * sum;
-            } else if (MODE == kSpmvResidInit) {
-                const double r = a.b[row] - sum;
-                const double z = a.dinv ? a.dinv[row] * r : r;
-                a.y[row] = r;
-                a.p[row] = z;
-                acc0 += r * z;
-                acc1 += r * r;
-            } else {  // kSpmvResidNorm
-                if (row < a.row_limit) {
-                    const double r = a.b[row] - sum;
-                    acc1 += r * r;
-                }
-            }
-        }
-    }
-    if (MODE != kSpmvPlain) {
-        const double s0 = block_sum(acc0, red);
-        const double s1 = block_sum(acc1, red);
-        if (tid == 0) {
-            a.partials[blockIdx.x] = s0;
-            a.partials[gridDim.x + blockIdx.x] = s1;
-        }
-    }
-}
-
-
-// ---------------------------------------------------------------------------
-// Default (variant 0) tiled SpMV: the same tile table as the first version
-// (spmv_tiled_kernel, kept as variant 2 for A/B runs), but the streaming phase is
-// issued as 16-byte loads (double2 values, int2 columns) and all of a lane's
-// loads are in flight before the first use (8 nonzeros per lane per tile), so a
-// wave keeps ~1.5 KiB outstanding instead of one 12-byte pair.  The tile window
-// starts at the even index below rp[r0]; the at most two foreign entries at the
-// window's ends are multiplied like the others and simply never summed (the
-// arrays carry four padding entries, see schwz_csr_create).
-// ---------------------------------------------------------------------------
-
-constexpr int kPairsPerLane = kTileNnz / (2 * kBlock);  // 4
-constexpr int kQuadsPerLane = kTileNnz / (4 * kBlock);  // 2
-
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void spmv_tiled2_kernel(CsrView A, SpmvArgs a)
-{
-    // every SpMV variant rounds each product before it is added (no FMA contraction), so
-    // that all variants -- and the sequential CPU oracle -- produce the same bits
-#pragma clang fp contract(off)
-    __shared__ __attribute__((aligned(16))) double prod[kTileNnz + 4];
-    __shared__ double red[4];
-    if (MODE == kSpmvDot || MODE == kSpmvResidInit) {
-        if (a.stop_iter && a.it >= *a.stop_iter) return;
-    }
-    const int tid = threadIdx.x;
-    const int xcd = blockIdx.x % kXcds;
-    const int slot = blockIdx.x / kXcds;
-    const int per_xcd = gridDim.x / kXcds;
-    const int chunk = xcd_slots(A);
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
-    const bool dual = (MODE == kSpmvResidDual) && a.x2 != nullptr;
-
-    for (int t = slot; t < chunk; t += per_xcd) {
-        const int tile = xcd_tile(A, xcd, t);
-        if (tile < 0) continue;
-        const int tl = A.tile_order ? A.tile_order[tile] : tile;
-        const int r0 = A.tile_row[tl], r1 = A.tile_row[tl + 1];
-        const int s = A.rp[r0], e = A.rp[r1];
-        const int cnt = e - s;
-        const bool dual_t = dual && (!A.tile_dual || A.tile_dual[tl]);
-        double sum = 0.0, sum2 = 0.0;
-        int row = r0 + tid;
-        bool have_row = false;
-        if ((s & 3) + cnt <= kTileNnz) {
-            const int s2 = s & ~3;  // 16-byte aligned window of the column indices (32-byte of the values)
-            // own row bounds first: independent of the streaming loads
-            int b0 = 0, b1 = 0;
-            if (row < r1) {
-                b0 = A.rp[row] - s2;
-                b1 = A.rp[row + 1] - s2;
-            }
-            // Four consecutive entries per lane and trip: two 16-byte value loads and ONE 16-byte
-            // index load (the vector-memory pipe is priced per instruction).  No bounds branch: lanes
-            // past the tile re-read its last quad (their products land in LDS slots no row sums).
-            const int last = max((e - 1) & ~3, s2);
-            double2 v[2 * kQuadsPerLane];
-            int4 c[kQuadsPerLane];
-#pragma unroll
-            for (int k = 0; k < kQuadsPerLane; ++k) {
-                const int idx = min(s2 + 4 * (tid + kBlock * k), last);
-                v[2 * k] = *reinterpret_cast<const double2 *>(A.val + idx);
-                v[2 * k + 1] = *reinterpret_cast<const double2 *>(A.val + idx + 2);
-                c[k] = *reinterpret_cast<const int4 *>(A.col + idx);
-            }
-            double xg[4 * kQuadsPerLane];
-#pragma unroll
-            for (int k = 0; k < kQuadsPerLane; ++k) {
-                xg[4 * k] = a.x[c[k].x];
-                xg[4 * k + 1] = a.x[c[k].y];
-                xg[4 * k + 2] = a.x[c[k].z];
-                xg[4 * k + 3] = a.x[c[k].w];
-            }
-#pragma unroll
-            for (int k = 0; k < kQuadsPerLane; ++k) {
-                double2 p0, p1;
-                p0.x = v[2 * k].x * xg[4 * k];
-                p0.y = v[2 * k].y * xg[4 * k + 1];
-                p1.x = v[2 * k + 1].x * xg[4 * k + 2];
-                p1.y = v[2 * k + 1].y * xg[4 * k + 3];
-                double2 *dst = reinterpret_cast<double2 *>(&prod[4 * (tid + kBlock * k)]);
-                dst[0] = p0;
-                dst[1] = p1;
-            }
-            lds_barrier();
-            if (row < r1) {
-                have_row = true;
-                for (int j = b0; j < b1; ++j) sum += prod[j];
-            }
-            lds_barrier();
-            if (dual_t) {
-                // second vector, same matrix entries (still in registers)
-#pragma unroll
-                for (int k = 0; k < kQuadsPerLane; ++k) {
-                    xg[4 * k] = a.x2[c[k].x];
-                    xg[4 * k + 1] = a.x2[c[k].y];
-                    xg[4 * k + 2] = a.x2[c[k].z];
-                    xg[4 * k + 3] = a.x2[c[k].w];
-                }
-#pragma unroll
-                for (int k = 0; k < kQuadsPerLane; ++k) {
-                    double2 p0, p1;
-                    p0.x = v[2 * k].x * xg[4 * k];
-                    p0.y = v[2 * k].y * xg[4 * k + 1];
-                    p1.x = v[2 * k + 1].x * xg[4 * k + 2];
-                    p1.y = v[2 * k + 1].y * xg[4 * k + 3];
-                    double2 *dst = reinterpret_cast<double2 *>(&prod[4 * (tid + kBlock * k)]);
-                    dst[0] = p0;
-                    dst[1] = p1;
-                }
-                lds_barrier();
-                if (row < r1)
-                    for (int j = b0; j < b1; ++j) sum2 += prod[j];
-                lds_barrier();
-            }
-        } else if (r1 - r0 > 1) {
-            // tile that fits kTileNnz but not the aligned window: plain staging
-            for (int i = tid; i < cnt; i += kBlock) prod[i] = A.val[s + i] * a.x[A.col[s + i]];
-            lds_barrier();
-            const int b0 = row < r1 ? A.rp[row] - s : 0, b1 = row < r1 ? A.rp[row + 1] - s : 0;
-            if (row < r1) {
-                have_row = true;
-                for (int j = b0; j < b1; ++j) sum += prod[j];
-            }
-            lds_barrier();
-            if (dual_t) {
-                for (int i = tid; i < cnt; i += kBlock) prod[i] = A.val[s + i] * a.x2[A.col[s + i]];
-                lds_barrier();
-                for (int j = b0; j < b1; ++j) sum2 += prod[j];
-                lds_barrier();
-            }
-        } else {
-            // a single long row: the whole workgroup reduces it
-            double part = 0.0, part2 = 0.0;
-            for (int i = tid; i < cnt; i += kBlock) {
-                part += __dmul_rn(A.val[s + i], a.x[A.col[s + i]]);
-                if (dual_t) part2 += __dmul_rn(A.val[s + i], a.x2[A.col[s + i]]);
-            }
-            part = block_sum(part, red);
-            if (dual_t) part2 = block_sum(part2, red);
-            row = r0;
-            if (tid == 0) {
-                have_row = true;
-                sum = part;
-                sum2 = part2;
-            }
-        }
-        if (have_row) {
-            if (MODE == kSpmvPlain) {
-                a.y[row] = (a.beta == 0.0) ? a.alpha * sum : a.alpha * sum + a.beta * a.y[row];
-            } else if (MODE == kSpmvDot) {
-                a.y[row] = sum;
-                acc0 += a.x[row] * sum;
-            } else if (MODE == kSpmvResidInit || MODE == kSpmvResidDual) {
-                const double bb = a.b[row];
-                const double r = bb - sum;
-                const double z = a.dinv ? a.dinv[row] * r : r;
-                a.y[row] = r;
-                a.p[row] = z;
-                acc0 += r * z;
-                acc1 += r * r;
-                if (MODE == kSpmvResidDual && row < a.row_limit) {
-                    const double r2 = dual_t ? bb - sum2 : r;
-                    acc2 += r2 * r2;
-                }
-            } else {  // kSpmvResidNorm
-                if (row < a.row_limit) {
-                    const double r = a.b[row] - sum;
-                    acc1 += r * r;
-                }
-            }
-        }
-    }
-    if (MODE != kSpmvPlain) {
-        const double s0 = block_sum(acc0, red);
-        const double s1 = block_sum(acc1, red);
-        if (tid == 0) {
-            a.partials[blockIdx.x] = s0;
-            a.partials[gridDim.x + blockIdx.x] = s1;
-        }
-        if (MODE == kSpmvResidDual) {
-            const double s2v = block_sum(acc2, red);
-            if (tid == 0) a.partials[2 * gridDim.x + blockIdx.x] = s2v;
-        }
-    }
-}
-
-
-// ---------------------------------------------------------------------------
-// Software-pipelined tiled SpMV (variant 4; measured no faster than variant 0).  Same tiles and arithmetic
-// as spmv_tiled2_kernel, but a workgroup's tile loop is a two-stage pipeline:
-// as soon as the products of tile t are in LDS, the 16-byte loads of tile t+1 are
-// issued into the SAME registers, so they fly during the barrier / row-sum / store
-// phase of tile t; the tile descriptors (row range, nonzero range) are fetched one
-// tile ahead as well.  Each workgroup thus always has ~24 KiB of matrix stream in
-// flight instead of stalling through a load -> gather -> LDS -> barrier chain.
-// ---------------------------------------------------------------------------
-
-struct TileDesc {
-    int r0, r1, s, e;
-    bool valid, regular;
-};
-
-__device__ __forceinline__ TileDesc tile_desc(const CsrView &A, int xcd, int chunk, int t)
-{
-    TileDesc d;
-    d.r0 = d.r1 = d.s = d.e = 0;
-    d.regular = false;
-    const int tile = t < chunk ? xcd_tile(A, xcd, t) : -1;
-    d.valid = tile >= 0;
-    if (d.valid) {
-        const int tl = A.tile_order ? A.tile_order[tile] : tile;
-        d.r0 = A.tile_row[tl];
-        d.r1 = A.tile_row[tl + 1];
-        d.s = A.rp[d.r0];
-        d.e = A.rp[d.r1];
-        d.regular = (d.e - d.s) <= kTileNnz - 2;
-    }
-    return d;
-}
-
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void spmv_pipe_kernel(CsrView A, SpmvArgs a)
-{
-    // every SpMV variant rounds each product before it is added (no FMA contraction), so
-    // that all variants -- and the sequential CPU oracle -- produce the same bits
-#pragma clang fp contract(off)
-    __shared__ double prod[kTileNnz + 2];
-    __shared__ double red[4];
-    if (MODE == kSpmvDot || MODE == kSpmvResidInit) {
-        if (a.stop_iter && a.it >= *a.stop_iter) return;
-    }
-    const int tid = threadIdx.x;
-    const int xcd = blockIdx.x % kXcds;
-    const int slot = blockIdx.x / kXcds;
-    const int per_xcd = gridDim.x / kXcds;
-    const int chunk = xcd_slots(A);
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
-    const bool dual = (MODE == kSpmvResidDual) && a.x2 != nullptr;
-
-    double2 v[kPairsPerLane];
-    int2 c[kPairsPerLane];
-    // No per-pair bounds branch: a lane whose pair lies past the tile re-reads the
-    // tile's last pair instead (its product lands in an LDS slot no row sums), so
-    // all loads of a phase issue back to back and one wait covers them.
-#define SCHWZ_ISSUE_LOADS(D)                                                     \
-    {                                                                            \
-        const int s2_ = (D).s & ~1;                                              \
-        const int last_ = max(((D).e - 1) & ~1, s2_);                            \
-        _Pragma("unroll") for (int k = 0; k < kPairsPerLane; ++k)                \
-        {                                                                        \
-            const int idx = min(s2_ + 2 * (tid + kBlock * k), last_);            \
-            v[k] = *reinterpret_cast<const double2 *>(A.val + idx);              \
-            c[k] = *reinterpret_cast<const int2 *>(A.col + idx);                 \
-        }                                                                        \
-    }
-#define SCHWZ_PRODUCTS(XV, D)                                                    \
-    {                                                                            \
-        double xg[2 * kPairsPerLane];                                            \
-        _Pragma("unroll") for (int k = 0; k < kPairsPerLane; ++k)                \
-        {                                                                        \
-            xg[2 * k] = (XV)[c[k].x];                                            \
-            xg[2 * k + 1] = (XV)[c[k].y];                                        \
-        }                                                                        \
-        _Pragma("unroll") for (int k = 0; k < kPairsPerLane; ++k)                \
-        {                                                                        \
-            double2 pr;                                                          \
-            pr.x = v[k].x * xg[2 * k];                                           \
-            pr.y = v[k].y * xg[2 * k + 1];                                       \
-            *reinterpret_cast<double2 *>(&prod[2 * (tid + kBlock * k)]) = pr;    \
-        }                                                                        \
-    }
-
-    // past-the-end slots only occur in the last run of the block-cyclic deal
-    int t = slot;
-    while (t < chunk && xcd_tile(A, xcd, t) < 0) t += per_xcd;
-    TileDesc cur = tile_desc(A, xcd, chunk, t);
-    if (cur.valid && cur.regular) SCHWZ_ISSUE_LOADS(cur)
-    while (cur.valid) {
-        t += per_xcd;
-        while (t < chunk && xcd_tile(A, xcd, t) < 0) t += per_xcd;
-        const TileDesc nxt = tile_desc(A, xcd, chunk, t);
-        const int r0 = cur.r0, r1 = cur.r1, s = cur.s, e = cur.e;
-        const int cnt = e - s;
-        double sum = 0.0, sum2 = 0.0;
-        int row = r0 + tid;
-        bool have_row = false;
-        if (cur.regular) {
-            const int s2 = s & ~1;
-            int b0 = 0, b1 = 0;
-            if (row < r1) {
-                b0 = A.rp[row] - s2;
-                b1 = A.rp[row + 1] - s2;
-            }
-            SCHWZ_PRODUCTS(a.x, cur)
-            if (!dual && nxt.valid && nxt.regular) SCHWZ_ISSUE_LOADS(nxt)
-            lds_barrier();
-            if (row < r1) {
-                have_row = true;
-                for (int j = b0; j < b1; ++j) sum += prod[j];
-            }
-            lds_barrier();
-            if (dual) {
-                SCHWZ_PRODUCTS(a.x2, cur)
-                if (nxt.valid && nxt.regular) SCHWZ_ISSUE_LOADS(nxt)
-                lds_barrier();
-                if (row < r1)
-                    for (int j = b0; j < b1; ++j) sum2 += prod[j];
-                lds_barrier();
-            }
-        } else {
-            if (r1 - r0 > 1) {
-                // fits kTileNnz but not the aligned window: plain staging
-                for (int i = tid; i < cnt; i += kBlock) prod[i] = A.val[s + i] * a.x[A.col[s + i]];
-                lds_barrier();
-                const int b0 = row < r1 ? A.rp[row] - s : 0, b1 = row < r1 ? A.rp[row + 1] - s : 0;
-                if (row < r1) {
-                    have_row = true;
-                    for (int j = b0; j < b1; ++j) sum += prod[j];
-                }
-                lds_barrier();
-                if (dual) {
-                    for (int i = tid; i < cnt; i += kBlock) prod[i] = A.val[s + i] * a.x2[A.col[s + i]];
-                    lds_barrier();
-                    for (int j = b0; j < b1; ++j) sum2 += prod[j];
-                    lds_barrier();
-                }
-            } else {
-                // a single long row: the whole workgroup reduces it
-                double part = 0.0, part2 = 0.0;
-                for (int i = tid; i < cnt; i += kBlock) {
-                    part += __dmul_rn(A.val[s + i], a.x[A.col[s + i]]);
-                    if (dual) part2 += __dmul_rn(A.val[s + i], a.x2[A.col[s + i]]);
-                }
-                part = block_sum(part, red);
-                if (dual) part2 = block_sum(part2, red);
-                row = r0;
-                if (tid == 0) {
-                    have_row = true;
-                    sum = part;
-                    sum2 = part2;
-                }
-            }
-            if (nxt.valid && nxt.regular) SCHWZ_ISSUE_LOADS(nxt)
-        }
-        if (have_row) {
-            if (MODE == kSpmvPlain) {
-                a.y[row] = (a.beta == 0.0) ? a.alpha * sum : a.alpha * sum + a.beta * a.y[row];
-            } else if (MODE == kSpmvDot) {
-                a.y[row] = sum;
-                acc0 += a.x[row] * sum;
-            } else if (MODE == kSpmvResidInit || MODE == kSpmvResidDual) {
-                const double bb = a.b[row];
-                const double r = bb - sum;
-                const double z = a.dinv ? a.dinv[row] * r : r;
-                a.y[row] = r;
-                a.p[row] = z;
-                acc0 += r * z;
-                acc1 += r * r;
-                if (MODE == kSpmvResidDual && row < a.row_limit) {
-                    const double r2 = dual ? bb - sum2 : r;
-                    acc2 += r2 * r2;
-                }
-            } else {  // kSpmvResidNorm
-                if (row < a.row_limit) {
-                    const double r = a.b[row] - sum;
-                    acc1 += r * r;
-                }
-            }
-        }
-        cur = nxt;
-    }
-#undef SCHWZ_ISSUE_LOADS
-#undef SCHWZ_PRODUCTS
-    if (MODE != kSpmvPlain) {
-        const double s0 = block_sum(acc0, red);
-        const double s1 = block_sum(acc1, red);
-        if (tid == 0) {
-            a.partials[blockIdx.x] = s0;
-            a.partials[gridDim.x + blockIdx.x] = s1;
-        }
-        if (MODE == kSpmvResidDual) {
-            const double s2v = block_sum(acc2, red);
-            if (tid == 0) a.partials[2 * gridDim.x + blockIdx.x] = s2v;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Ablation build of the tiled kernel (plain mode only, WRONG results on purpose):
-// used by tools/spmv_probe.py --variants 10.. to price the pieces of a tile.
-//   bit 0: no x gather (x := 1)      bit 1: no LDS staging / barriers / row sums
-//   bit 2: no y store                bit 3: no column-index stream
-// ---------------------------------------------------------------------------
-template <int WHAT>
-__global__ __launch_bounds__(kBlock) void spmv_ablate_kernel(CsrView A, SpmvArgs a)
-{
-    __shared__ double prod[kTileNnz + 2];
-    const int tid = threadIdx.x;
-    const int xcd = blockIdx.x % kXcds;
-    const int slot = blockIdx.x / kXcds;
-    const int per_xcd = gridDim.x / kXcds;
-    const int chunk = xcd_slots(A);
-    double keep = 0.0;
-    for (int t = slot; t < chunk; t += per_xcd) {
-        const int tile = xcd_tile(A, xcd, t);
-        if (tile < 0) continue;
-        const int r0 = A.tile_row[tile], r1 = A.tile_row[tile + 1];
-        const int s = A.rp[r0], e = A.rp[r1];
-        if (e - s > kTileNnz - 2) continue;
-        const int row = r0 + tid;
-        const int s2 = (WHAT & 32) ? s : (s & ~1);
-        int b0 = 0, b1 = 0;
-        if (row < r1) {
-            b0 = A.rp[row] - s2;
-            b1 = A.rp[row + 1] - s2;
-        }
-        double sum = 0.0;
-        if (WHAT & 32) {
-            // consecutive lanes take consecutive entries (8-byte / 4-byte loads)
-            const int last = max(e - 1, s);
-            double v[2 * kPairsPerLane];
-            int c[2 * kPairsPerLane];
-#pragma unroll
-            for (int k = 0; k < 2 * kPairsPerLane; ++k) {
-                const int idx = min(s + tid + kBlock * k, last);
-                v[k] = A.val[idx];
-                c[k] = A.col[idx];
-            }
-            double xg[2 * kPairsPerLane];
-#pragma unroll
-            for (int k = 0; k < 2 * kPairsPerLane; ++k) xg[k] = a.x[c[k]];
-#pragma unroll
-            for (int k = 0; k < 2 * kPairsPerLane; ++k) prod[tid + kBlock * k] = v[k] * xg[k];
-            lds_barrier();
-            if (row < r1)
-                for (int j = b0; j < b1; ++j) sum += prod[j];
-            lds_barrier();
-        } else {
-            const int last = max((e - 1) & ~1, s2);
-            double2 v[kPairsPerLane];
-            int2 c[kPairsPerLane];
-#pragma unroll
-            for (int k = 0; k < kPairsPerLane; ++k) {
-                const int idx = min(s2 + 2 * (tid + kBlock * k), last);
-                v[k] = *reinterpret_cast<const double2 *>(A.val + idx);
-                if (WHAT & 8) {
-                    c[k].x = idx & 1023;
-                    c[k].y = (idx + 1) & 1023;
-                } else {
-                    c[k] = *reinterpret_cast<const int2 *>(A.col + idx);
-                }
-            }
-            double xg[2 * kPairsPerLane];
-#pragma unroll
-            for (int k = 0; k < kPairsPerLane; ++k) {
-                if (WHAT & 1) {
-                    xg[2 * k] = 1.0 + c[k].x;
-                    xg[2 * k + 1] = 1.0 + c[k].y;
-                } else {
-                    xg[2 * k] = a.x[c[k].x];
-                    xg[2 * k + 1] = a.x[c[k].y];
-                }
-            }
-            if (WHAT & 2) {
-#pragma unroll
-                for (int k = 0; k < kPairsPerLane; ++k) sum += v[k].x * xg[2 * k] + v[k].y * xg[2 * k + 1];
-                sum += b0 + b1;
-            } else {
-#pragma unroll
-                for (int k = 0; k < kPairsPerLane; ++k) {
-                    double2 pr;
-                    pr.x = v[k].x * xg[2 * k];
-                    pr.y = v[k].y * xg[2 * k + 1];
-                    *reinterpret_cast<double2 *>(&prod[2 * (tid + kBlock * k)]) = pr;
-                }
-                lds_barrier();
-                if (row < r1)
-                    for (int j = b0; j < b1; ++j) sum += prod[j];
-                lds_barrier();
-            }
-        }
-        if (WHAT & 4) {
-            keep += sum;
-        } else if (WHAT & 16) {
-            if (row < r1) __builtin_nontemporal_store(sum, &a.y[row]);
-        } else if (row < r1) {
-            a.y[row] = sum;
-        }
-    }
-    if ((WHAT & 4) && keep == 123.456) a.y[0] = keep;
-}
-
-// ---------------------------------------------------------------------------
-// Wave-tiled SpMV: the same idea with a WAVE as the unit of work.  Each 64-lane
-// wave owns tiles of <= 64 consecutive rows / <= 510 nonzeros, stages the
-// products in its private 4 KiB LDS slice and sums one row per lane.  There is no
-// workgroup barrier in the loop (LDS operations of one wave complete in order),
-// so the four waves of a workgroup -- and the 32 of a CU -- drift apart and keep
-// loads in flight while others are in their LDS phase.
-// NT: matrix entries are read once per SpMV; loading them non-temporally keeps
-// them from evicting the x planes that neighbouring tiles re-read from L2.
-// ---------------------------------------------------------------------------
-
-typedef double v2d __attribute__((ext_vector_type(2)));
-typedef int v2i __attribute__((ext_vector_type(2)));
-
-template <typename T, bool NT>
-__device__ __forceinline__ T stream_load(const T *p)
-{
-    if (NT) return __builtin_nontemporal_load(p);
-    return *p;
-}
-
-__device__ __forceinline__ void wave_lds_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-constexpr int kWavePairs = kWaveTileNnz / 128;  // 16-byte pairs per lane per tile (4)
-
-template <int MODE, bool NT>
-__global__ __launch_bounds__(kBlock) void spmv_wave_kernel(CsrView A, SpmvArgs a)
-{
-    // every SpMV variant rounds each product before it is added (no FMA contraction), so
-    // that all variants -- and the sequential CPU oracle -- produce the same bits
-#pragma clang fp contract(off)
-    __shared__ double prod_all[kBlock / 64][kWaveTileNnz + 2];
-    __shared__ double red[4];
-    if (MODE == kSpmvDot || MODE == kSpmvResidInit) {
-        if (a.stop_iter && a.it >= *a.stop_iter) return;
-    }
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    double *prod = prod_all[wave];
-    const int xcd = blockIdx.x % kXcds;
-    const int slot = (blockIdx.x / kXcds) * (kBlock / 64) + wave;
-    const int per_xcd = (gridDim.x / kXcds) * (kBlock / 64);
-    const int chunk = (A.nwtiles + kXcds - 1) / kXcds;
-    double acc0 = 0.0, acc1 = 0.0;
-
-    for (int t = slot; t < chunk; t += per_xcd) {
-        const int tile = xcd * chunk + t;
-        if (tile >= A.nwtiles) break;
-        const int r0 = A.wtile_row[tile], r1 = A.wtile_row[tile + 1];
-        const int s = A.rp[r0], e = A.rp[r1];
-        const int cnt = e - s;
-        double sum = 0.0;
-        int row = r0 + lane;
-        bool have_row = false;
-        if (cnt <= kWaveTileNnz - 2) {
-            const int s2 = s & ~1;
-            int b0 = 0, b1 = 0;
-            if (row < r1) {
-                b0 = A.rp[row] - s2;
-                b1 = A.rp[row + 1] - s2;
-            }
-            v2d v[kWavePairs];
-            v2i c[kWavePairs];
-#pragma unroll
-            for (int k = 0; k < kWavePairs; ++k) {
-                const int idx = s2 + 2 * (lane + 64 * k);
-                if (idx < e) {
-                    v[k] = stream_load<v2d, NT>(reinterpret_cast<const v2d *>(A.val + idx));
-                    c[k] = stream_load<v2i, NT>(reinterpret_cast<const v2i *>(A.col + idx));
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < kWavePairs; ++k) {
-                const int idx = s2 + 2 * (lane + 64 * k);
-                if (idx < e) {
-                    v2d pr;
-                    pr.x = v[k].x * a.x[c[k].x];
-                    pr.y = v[k].y * a.x[c[k].y];
-                    *reinterpret_cast<v2d *>(&prod[2 * (lane + 64 * k)]) = pr;
-                }
-            }
-            wave_lds_sync();
-            if (row < r1) {
-                have_row = true;
-                for (int j = b0; j < b1; ++j) sum += prod[j];
-            }
-            wave_lds_sync();
-        } else {
-            // a single row longer than a wave tile: the wave reduces it
-            double part = 0.0;
-            for (int i = lane; i < cnt; i += 64) part += __dmul_rn(A.val[s + i], a.x[A.col[s + i]]);
-            part = wave_sum(part);
-            row = r0;
-            if (lane == 0) {
-                have_row = true;
-                sum = part;
-            }
-        }
-        if (have_row) {
-            if (MODE == kSpmvPlain) {
-                a.y[row] = (a.beta == 0.0) ? a.alpha * sum : a.alpha * sum + a.beta * a.y[row];
-            } else if (MODE == kSpmvDot) {
-                a.y[row] = sum;
-                acc0 += a.x[row] * sum;
-            } else if (MODE == kSpmvResidInit) {
-                const double r = a.b[row] - sum;
-                const double z = a.dinv ? a.dinv[row] * r : r;
-                a.y[row] = r;
-                a.p[row] = z;
-                acc0 += r * z;
-                acc1 += r * r;
-            } else {  // kSpmvResidNorm
-                if (row < a.row_limit) {
-                    const double r = a.b[row] - sum;
-                    acc1 += r * r;
-                }
-            }
-        }
-    }
-    if (MODE != kSpmvPlain) {
-        const double s0 = block_sum(acc0, red);
-        const double s1 = block_sum(acc1, red);
-        if (threadIdx.x == 0) {
-            a.partials[blockIdx.x] = s0;
-            a.partials[gridDim.x + blockIdx.x] = s1;
-        }
-    }
-}
-
-// Baseline for A/B runs: one row per lane, no staging (what a direct port of a
-// row-parallel CPU loop would do).  Only the plain mode.
-__global__ __launch_bounds__(kBlock) void spmv_rowlane_kernel(CsrView A, SpmvArgs a)
-{
-    // every SpMV variant rounds each product before it is added (no FMA contraction), so
-    // that all variants -- and the sequential CPU oracle -- produce the same bits
-#pragma clang fp contract(off)
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < A.nrows; row += stride) {
-        double sum = 0.0;
-        for (int j = A.rp[row]; j < A.rp[row + 1]; ++j) sum += A.val[j] * a.x[A.col[j]];
-        a.y[row] = (a.beta == 0.0) ? a.alpha * sum : a.alpha * sum + a.beta * a.y[row];
-    }
-}
-
-int spmv_grid(const CsrView &A, int variant)
-{
-    // wave variants: four wave tiles per workgroup
-    const int units = (variant == 3 || variant == 5) ? (A.nwtiles + 3) / 4 : A.ntiles;
-    static const int cap = [] {  // SCHWZ_SPMV_GRID: smaller grids for occupancy experiments
-        const char *e = std::getenv("SCHWZ_SPMV_GRID");
-        const int v = e ? std::atoi(e) : 0;
-        return (v >= kXcds && v < kMaxGrid) ? v : kMaxGrid;
-    }();
-    int g = units < cap ? units : cap;
-    g = ((g + kXcds - 1) / kXcds) * kXcds;
-    return g < kXcds ? kXcds : g;
-}
-
-int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipStream_t s)
-{
-    if (A.nrows == 0) return SCHWZ_OK;
-    if (mode == kSpmvResidDual && variant != 0 && variant != 4 && variant != 6 && variant != 7 && variant != 8) {
-        set_error("launch_spmv: the fused dual-residual mode exists for variants 0, 4 and 6 only");
-        return SCHWZ_ERR_INVALID;
-    }
-    const int grid = spmv_grid(A, variant);
-#define SCHWZ_LAUNCH_WAVE(NTV)                                                                          \
-    switch (mode) {                                                                                    \
-    case kSpmvPlain:                                                                                   \
-        hipLaunchKernelGGL((spmv_wave_kernel<kSpmvPlain, NTV>), dim3(wgrid), dim3(kBlock), 0, s, A, a); \
-        break;                                                                                         \
-    case kSpmvDot:                                                                                     \
-        hipLaunchKernelGGL((spmv_wave_kernel<kSpmvDot, NTV>), dim3(wgrid), dim3(kBlock), 0, s, A, a);   \
-        break;                                                                                         \
-    case kSpmvResidInit:                                                                               \
-        hipLaunchKernelGGL((spmv_wave_kernel<kSpmvResidInit, NTV>), dim3(wgrid), dim3(kBlock), 0, s, A, a); \
-        break;                                                                                         \
-    default:                                                                                           \
-        hipLaunchKernelGGL((spmv_wave_kernel<kSpmvResidNorm, NTV>), dim3(wgrid), dim3(kBlock), 0, s, A, a); \
-        break;                                                                                         \
-    }
-    if (variant == 0 && A.pair_id) return launch_spmv_pair(A, mode, a, grid, s);
-    if (mode == kSpmvDotOnly || mode == kSpmvCgUpdate) {
-        set_error("launch_spmv: the q-free CG modes exist for row-pair coded matrices only");
-        return SCHWZ_ERR_INVALID;
-    }
-    if ((variant == 0 || variant == 8) && A.pat_id) return launch_spmv_pattern(A, mode, a, grid, s);
-    if ((variant == 0 || variant == 7) && A.code) return launch_spmv_dict(A, mode, a, grid, s);
-    if (variant >= 10 && variant < 74 && mode == kSpmvPlain) {
-        switch (variant - 10) {
-#define SCHWZ_ABL(W) \
-    case W: hipLaunchKernelGGL(spmv_ablate_kernel<W>, dim3(grid), dim3(kBlock), 0, s, A, a); break;
-            SCHWZ_ABL(0) SCHWZ_ABL(1) SCHWZ_ABL(2) SCHWZ_ABL(3) SCHWZ_ABL(4) SCHWZ_ABL(5) SCHWZ_ABL(6) SCHWZ_ABL(7)
-            SCHWZ_ABL(8) SCHWZ_ABL(9) SCHWZ_ABL(10) SCHWZ_ABL(11) SCHWZ_ABL(12) SCHWZ_ABL(13) SCHWZ_ABL(14) SCHWZ_ABL(15)
-            SCHWZ_ABL(16) SCHWZ_ABL(32) SCHWZ_ABL(48) SCHWZ_ABL(36)
-#undef SCHWZ_ABL
-        }
-    } else if (variant == 3 || variant == 5) {
-        const int wgrid = spmv_grid(A, variant);
-        if (variant == 3) {
-            SCHWZ_LAUNCH_WAVE(false)
-        } else {
-            SCHWZ_LAUNCH_WAVE(true)
-        }
-    } else if (variant == 1 && mode == kSpmvPlain) {
-        hipLaunchKernelGGL(spmv_rowlane_kernel, dim3(kMaxGrid), dim3(kBlock), 0, s, A, a);
-    } else if (variant == 4) {
-        switch (mode) {
-        case kSpmvPlain:
-            hipLaunchKernelGGL(spmv_pipe_kernel<kSpmvPlain>, dim3(grid), dim3(kBlock), 0, s, A, a);
-            break;
-        case kSpmvDot:
-            hipLaunchKernelGGL(spmv_pipe_kernel<kSpmvDot>, dim3(grid), dim3(kBlock), 0, s, A, a);
-            break;
-        case kSpmvResidInit:
-            hipLaunchKernelGGL(spmv_pipe_kernel<kSpmvResidInit>, dim3(grid), dim3(kBlock), 0, s, A, a);
-            break;
-        case kSpmvResidDual:
-            hipLaunchKernelGGL(spmv_pipe_kernel<kSpmvResidDual>, dim3(grid), dim3(kBlock), 0, s, A, a);
-            break;
-        default:
-            hipLaunchKernelGGL(spmv_pipe_kernel<kSpmvResidNorm>, dim3(grid), dim3(kBlock), 0, s, A, a);
-            break;
-        }
-    } else if (variant != 2) {
-        switch (mode) {
-        case kSpmvPlain:
-            hipLaunchKernelGGL(spmv_tiled2_kernel<kSpmvPlain>, dim3(grid), dim3(kBlock), 0, s, A, a);
-            break;
-        case kSpmvDot:
-            hipLaunchKernelGGL(spmv_tiled2_kernel<kSpmvDot>, dim3(grid), dim3(kBlock), 0, s, A, a);
-            break;
-        case kSpmvResidInit:
-            hipLaunchKernelGGL(spmv_tiled2_kernel<kSpmvResidInit>, dim3(grid), dim3(kBlock), 0, s, A, a);
-            break;
-        case kSpmvResidDual:
-            hipLaunchKernelGGL(spmv_tiled2_kernel<kSpmvResidDual>, dim3(grid), dim3(kBlock), 0, s, A, a);
-            break;
-        default:
-            hipLaunchKernelGGL(spmv_tiled2_kernel<kSpmvResidNorm>, dim3(grid), dim3(kBlock), 0, s, A, a);
-            break;
-        }
-    } else {
-        switch (mode) {
-        case kSpmvPlain:
-            hipLaunchKernelGGL(spmv_tiled_kernel<kSpmvPlain>, dim3(grid), dim3(kBlock), 0, s, A, a);
-            break;
-        case kSpmvDot:
-            hipLaunchKernelGGL(spmv_tiled_kernel<kSpmvDot>, dim3(grid), dim3(kBlock), 0, s, A, a);
-            break;
-        case kSpmvResidInit:
-            hipLaunchKernelGGL(spmv_tiled_kernel<kSpmvResidInit>, dim3(grid), dim3(kBlock), 0, s, A, a);
-            break;
-        default:
-            hipLaunchKernelGGL(spmv_tiled_kernel<kSpmvResidNorm>, dim3(grid), dim3(kBlock), 0, s, A, a);
-            break;
-        }
-    }
-    SCHWZ_HIP_TRY(hipGetLastError());
-    return SCHWZ_OK;
-}
-
-// ---------------------------------------------------------------------------
-// CG vector kernels.  One CG iteration = spmv_tiled_kernel<kSpmvDot> + these two.
-// Scalars live in CgState in HBM; nothing returns to the host inside the loop.
-// ---------------------------------------------------------------------------
-
-__global__ void cg_init_finalize_kernel(CgState *st, const double *partials, int nparts, double rtol,
-                                        double *norm_sq_out, int norm_bank)
-{
-    __shared__ double red[4];
-    const double rho = fold_partials(partials, nparts, red);
-    const double rr = fold_partials(partials + nparts, nparts, red);
-    if (norm_sq_out) {
-        const double n2 = fold_partials(partials + norm_bank * nparts, nparts, red);
-        if (threadIdx.x == 0) {
-            norm_sq_out[0] = n2;  // may be mapped host memory
-            __threadfence_system();
-        }
-    }
-    if (threadIdx.x == 0) {
-        st->rho[0] = rho;
-        st->rho[1] = 0.0;
-        st->rr = rr;
-        st->r0 = sqrt(rr);
-        st->iters = 0;
-        // loop-top test of iteration 0: ||r|| <= rtol*||r_initial||
-        st->stop_iter = (sqrt(rr) <= rtol * sqrt(rr)) ? 0 : INT_MAX;
-    }
-}
-
-typedef double vd2 __attribute__((ext_vector_type(2)));
-
-template <bool NT>
-__device__ __forceinline__ void store2(double *base, int64_t i, vd2 v)
-{
-    if (NT)
-        __builtin_nontemporal_store(v, reinterpret_cast<vd2 *>(base) + i);
-    else
-        reinterpret_cast<vd2 *>(base)[i] = v;
-}
-
-// 1/diag of rows 2i and 2i+1 in whichever representation the solver holds
-__device__ __forceinline__ vd2 diag_pair(const DiagView &dg, const vd2 *full2, const uint16_t *code2,
-                                         const double *ddict, int64_t i)
-{
-    vd2 d;
-    if (dg.mode == 1) {
-        d = full2[i];
-    } else if (dg.mode == 2) {
-        const unsigned c = code2[i];
-        d.x = ddict[c & 255u];
-        d.y = ddict[c >> 8];
-    } else {
-        d.x = d.y = dg.uniform;
-    }
-    return d;
-}
-
-__device__ __forceinline__ double diag_one(const DiagView &dg, const double *ddict, int64_t i)
-{
-    if (dg.mode == 1) return dg.full[i];
-    if (dg.mode == 2) return ddict[dg.code[i]];
-    return dg.uniform;
-}
-
-// x += alpha p ; r -= alpha q ; z = dinv r ; partials: r.z and r.r
-// U: 16-byte elements per lane in flight per trip; NT: non-temporal stores
-template <int U, bool NT>
-__global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, double *__restrict__ x,
-                                                           double *__restrict__ r,
-                                                           const double *__restrict__ p,
-                                                           const double *__restrict__ q,
-                                                           const DiagView dg,
-                                                           const double *pq_partials, int nparts_in,
-                                                           const CgState *st, int it,
-                                                           double *partials_out)
-{
-    __shared__ double red[4];
-    __shared__ double ddict[256];
-    if (it >= st->stop_iter) return;
-    if (dg.mode == 2) {
-        if (threadIdx.x < dg.ndict) ddict[threadIdx.x] = dg.dict[threadIdx.x];
-        __syncthreads();
-    }
-    const double *__restrict__ dinv = dg.mode == 1 ? dg.full : nullptr;
-    const uint16_t *dc2 = reinterpret_cast<const uint16_t *>(dg.code);
-    const double pq = fold_partials(pq_partials, nparts_in, red);
-    const double alpha = st->rho[it & 1] / pq;
-    double a0 = 0.0, a1 = 0.0;
-    const int64_t n2 = n >> 1;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    const vd2 *x2 = reinterpret_cast<const vd2 *>(x);
-    const vd2 *r2 = reinterpret_cast<const vd2 *>(r);
-    const vd2 *p2 = reinterpret_cast<const vd2 *>(p);
-    const vd2 *q2 = reinterpret_cast<const vd2 *>(q);
-    const vd2 *d2 = reinterpret_cast<const vd2 *>(dinv);
-    for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < n2; i0 += stride * U) {
-        vd2 xv[U], rv[U], pv[U], qv[U], dv[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t i = i0 + u * stride;
-            if (i < n2) {
-                xv[u] = x2[i];
-                rv[u] = r2[i];
-                pv[u] = p2[i];
-                qv[u] = q2[i];
-                dv[u] = diag_pair(dg, d2, dc2, ddict, i);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t i = i0 + u * stride;
-            if (i < n2) {
-                xv[u] += alpha * pv[u];
-                rv[u] -= alpha * qv[u];
-                store2<NT>(x, i, xv[u]);
-                store2<NT>(r, i, rv[u]);
-                vd2 z = rv[u];
-                if (dg.mode) z *= dv[u];
-                a0 += rv[u].x * z.x;
-                a0 += rv[u].y * z.y;
-                a1 += rv[u].x * rv[u].x;
-                a1 += rv[u].y * rv[u].y;
-            }
-        }
-    }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-        const int64_t i = n - 1;
-        x[i] += alpha * p[i];
-        const double rv = r[i] - alpha * q[i];
-        r[i] = rv;
-        const double z = dg.mode ? diag_one(dg, ddict, i) * rv : rv;
-        a0 += rv * z;
-        a1 += rv * rv;
-    }
-    const double s0 = block_sum(a0, red);
-    const double s1 = block_sum(a1, red);
-    if (threadIdx.x == 0) {
-        partials_out[blockIdx.x] = s0;
-        partials_out[gridDim.x + blockIdx.x] = s1;
-    }
-}
-
-// beta = rho'/rho ; p = dinv r + beta p ; state update by workgroup 0
-template <int U, bool NT>
-__global__ __launch_bounds__(kBlock) void cg_direction_kernel(int64_t n, double *__restrict__ p,
-                                                              const double *__restrict__ r,
-                                                              const DiagView dg,
-                                                              const double *partials_in, int nparts,
-                                                              CgState *st, int it, double rtol)
-{
-    // with a general preconditioner `r` is already z = M^-1 r and dg.mode is 0
-    __shared__ double red[4];
-    __shared__ double ddict[256];
-    if (it >= st->stop_iter) return;
-    if (dg.mode == 2) {
-        if (threadIdx.x < dg.ndict) ddict[threadIdx.x] = dg.dict[threadIdx.x];
-        __syncthreads();
-    }
-    const double *__restrict__ dinv = dg.mode == 1 ? dg.full : nullptr;
-    const uint16_t *dc2 = reinterpret_cast<const uint16_t *>(dg.code);
-    const double rho_new = fold_partials(partials_in, nparts, red);
-    const double rr = fold_partials(partials_in + nparts, nparts, red);
-    const double beta = rho_new / st->rho[it & 1];
-    const int64_t n2 = n >> 1;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    const vd2 *p2 = reinterpret_cast<const vd2 *>(p);
-    const vd2 *r2 = reinterpret_cast<const vd2 *>(r);
-    const vd2 *d2 = reinterpret_cast<const vd2 *>(dinv);
-    for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < n2; i0 += stride * U) {
-        vd2 pv[U], zv[U], dv[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t i = i0 + u * stride;
-            if (i < n2) {
-                pv[u] = p2[i];
-                zv[u] = r2[i];
-                dv[u] = diag_pair(dg, d2, dc2, ddict, i);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t i = i0 + u * stride;
-            if (i < n2) {
-                if (dg.mode) zv[u] *= dv[u];
-                store2<NT>(p, i, zv[u] + beta * pv[u]);
-            }
-        }
-    }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-        const int64_t i = n - 1;
-        const double z = dg.mode ? diag_one(dg, ddict, i) * r[i] : r[i];
-        p[i] = z + beta * p[i];
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        // other workgroups read rho[it&1] concurrently: the slot written here is the other one
-        st->rho[(it + 1) & 1] = rho_new;
-        st->rr = rr;
-        st->iters = st->iters + 1;
-        // 0, not it + 1: every later launch leaves at once whatever iteration index it carries (the
-        // recorded launches of a replayed hipGraph carry 0..15 again and again).  Workgroups of THIS
-        // launch that read the 0 early skip their part of p, which nobody will read any more.
-        if (sqrt(rr) <= rtol * st->r0) st->stop_iter = 0;
-    }
-}
-
-// Measured on MI355X (256^3): U = 2/4 and non-temporal stores change the PCG iteration time by
-// < 1 % (0.403 / 0.406 / 0.417 ms for U = 1 / 2 / 4): these kernels sit at the mixed
-// read+write HBM ceiling (~5.0-5.5 TB/s), so the plain shape is used.
 
 // ---------------------------------------------------------------------------
 // gather / scatter with the four reference ops
@@ -1124,12 +69,6 @@ __global__ void scatter_f32_kernel(int64_t n, const schwz_idx *__restrict__ idx,
         into[idx[i]] = (double)from[i];
 }
 
-static int grid_for(int64_t n)
-{
-    int64_t g = (n + kBlock - 1) / kBlock;
-    if (g > kMaxGrid) g = kMaxGrid;
-    return g < 1 ? 1 : (int)g;
-}
 
 // b~[row] = b[row] - sum_j A_Gamma[row][j] x~[col_j] for the overlap rows only
 // (rows < local_size have no interface entries; their b~ is set once at upload).
@@ -1147,18 +86,6 @@ __global__ void interface_update_kernel(int64_t nrows, int64_t row0, const schwz
     }
 }
 
-// dinv[i] = 1 / A[i][i] (1 when the row stores no diagonal): scalar Jacobi, i.e.
-// block-Jacobi with max_block_size 1
-__global__ void extract_dinv_kernel(CsrView A, double *__restrict__ dinv)
-{
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.nrows; i += stride) {
-        double d = 1.0;
-        for (int j = A.rp[i]; j < A.rp[i + 1]; ++j)
-            if (A.col[j] == i) d = A.val[j];
-        dinv[i] = 1.0 / d;
-    }
-}
 
 // STREAM-style probes: the measured copy / read ceiling quoted next to the 8 TB/s
 // spec figure in DESIGN.md.
@@ -1201,174 +128,6 @@ __global__ void final_norm_kernel(const double *partials, int nparts, double *ou
     if (threadIdx.x == 0) {
         out[0] = s;  // may be mapped host memory
         __threadfence_system();
-    }
-}
-
-// ---------------------------------------------------------------------------
-// level-scheduled sparse triangular solves in ONE workgroup: rows of a level are
-// independent; levels are separated by a workgroup barrier.  Used for the
-// direct local solve, whose factors are small (BASELINE config 4: ~500 rows).
-// ---------------------------------------------------------------------------
-
-constexpr int kTrsBlock = 1024;
-
-// out[i] = in[perm[i]]   (gko Permutation row_permute)
-// L t = out ; U out = t ; y[perm[i]] = out[i]
-__global__ __launch_bounds__(kTrsBlock) void trs_solve_kernel(
-    int64_t n, const schwz_idx *__restrict__ perm, const schwz_idx *__restrict__ l_rp,
-    const schwz_idx *__restrict__ l_col, const double *__restrict__ l_val,
-    const schwz_idx *__restrict__ l_order, const schwz_idx *__restrict__ l_lvl, int l_nlvl,
-    const schwz_idx *__restrict__ u_rp, const schwz_idx *__restrict__ u_col,
-    const double *__restrict__ u_val, const schwz_idx *__restrict__ u_order,
-    const schwz_idx *__restrict__ u_lvl, int u_nlvl, const double *__restrict__ b,
-    double *__restrict__ y, double *w0, double *w1)
-{
-    const int tid = threadIdx.x;
-    for (int64_t i = tid; i < n; i += kTrsBlock) w0[i] = b[perm[i]];
-    __threadfence_block();
-    __syncthreads();
-    for (int lv = 0; lv < l_nlvl; ++lv) {
-        for (int k = l_lvl[lv] + tid; k < l_lvl[lv + 1]; k += kTrsBlock) {
-            const int row = l_order[k];
-            const int e = l_rp[row + 1] - 1;
-            double s = w0[row];
-            for (int j = l_rp[row]; j < e; ++j) s -= l_val[j] * w1[l_col[j]];
-            w1[row] = s / l_val[e];
-        }
-        __threadfence_block();
-        __syncthreads();
-    }
-    for (int lv = 0; lv < u_nlvl; ++lv) {
-        for (int k = u_lvl[lv] + tid; k < u_lvl[lv + 1]; k += kTrsBlock) {
-            const int row = u_order[k];
-            const int s0 = u_rp[row];
-            double s = w1[row];
-            for (int j = s0 + 1; j < u_rp[row + 1]; ++j) s -= u_val[j] * w0[u_col[j]];
-            w0[row] = s / u_val[s0];
-        }
-        __threadfence_block();
-        __syncthreads();
-    }
-    for (int64_t i = tid; i < n; i += kTrsBlock) y[perm[i]] = w0[i];
-}
-
-// ---- the same solves level by level, for factors that do not fit one workgroup ----------------
-
-// w[i] = b[perm[i]] (perm == nullptr: identity)
-__global__ void trs_permute_in_kernel(int64_t n, const schwz_idx *__restrict__ perm, const double *__restrict__ b,
-                                      double *__restrict__ w)
-{
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        w[i] = perm ? b[perm[i]] : b[i];
-}
-
-// y[perm[i]] = w[i]
-__global__ void trs_permute_out_kernel(int64_t n, const schwz_idx *__restrict__ perm, const double *__restrict__ w,
-                                       double *__restrict__ y)
-{
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        if (perm)
-            y[perm[i]] = w[i];
-        else
-            y[i] = w[i];
-    }
-}
-
-// rows order[k0:k1) of one level: out[row] = (rhs[row] - sum_{deps} val * out[col]) / diag.
-// LOWER: diagonal is the row's last entry; else (upper) its first.  All dependencies belong to
-// earlier levels, i.e. to earlier launches.
-template <bool LOWER>
-__global__ __launch_bounds__(kBlock) void trs_level_kernel(int k0, int k1, const schwz_idx *__restrict__ order,
-                                                           const schwz_idx *__restrict__ rp,
-                                                           const schwz_idx *__restrict__ col,
-                                                           const double *__restrict__ val,
-                                                           const double *__restrict__ rhs, double *out)
-{
-#pragma clang fp contract(off)
-    const int k = k0 + blockIdx.x * kBlock + threadIdx.x;
-    if (k >= k1) return;
-    const int row = order[k];
-    const int s0 = rp[row], e = rp[row + 1];
-    double s = rhs[row];
-    if (LOWER) {
-        for (int j = s0; j < e - 1; ++j) s -= val[j] * out[col[j]];
-        out[row] = s / val[e - 1];
-    } else {
-        for (int j = s0 + 1; j < e; ++j) s -= val[j] * out[col[j]];
-        out[row] = s / val[s0];
-    }
-}
-
-// a run of narrow levels [lv0, lv1) in one workgroup
-template <bool LOWER>
-__global__ __launch_bounds__(kTrsBlock) void trs_narrow_kernel(int lv0, int lv1, const schwz_idx *__restrict__ lvl,
-                                                               const schwz_idx *__restrict__ order,
-                                                               const schwz_idx *__restrict__ rp,
-                                                               const schwz_idx *__restrict__ col,
-                                                               const double *__restrict__ val,
-                                                               const double *__restrict__ rhs, double *out)
-{
-#pragma clang fp contract(off)
-    for (int lv = lv0; lv < lv1; ++lv) {
-        for (int k = lvl[lv] + (int)threadIdx.x; k < lvl[lv + 1]; k += kTrsBlock) {
-            const int row = order[k];
-            const int s0 = rp[row], e = rp[row + 1];
-            double s = rhs[row];
-            if (LOWER) {
-                for (int j = s0; j < e - 1; ++j) s -= val[j] * out[col[j]];
-                out[row] = s / val[e - 1];
-            } else {
-                for (int j = s0 + 1; j < e; ++j) s -= val[j] * out[col[j]];
-                out[row] = s / val[s0];
-            }
-        }
-        __threadfence_block();
-        __syncthreads();
-    }
-}
-
-// ---- block-Jacobi apply and the vector pieces of the general preconditioned CG -------------
-
-// z[i] = sum_j inv[blk_id[i / bs]][i % bs][j] * r[(i / bs) * bs + j]
-__global__ __launch_bounds__(kBlock) void block_jacobi_apply_kernel(int64_t n, int bs,
-                                                                    const schwz_idx *__restrict__ blk_id,
-                                                                    const double *__restrict__ blk_inv,
-                                                                    const double *__restrict__ r,
-                                                                    double *__restrict__ z)
-{
-#pragma clang fp contract(off)
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        const int64_t b = i / bs, r0 = b * bs;
-        const double *row = blk_inv + ((int64_t)blk_id[b] * bs + (i - r0)) * bs;
-        double s = 0.0;
-        for (int j = 0; j < bs && r0 + j < n; ++j) s += row[j] * r[r0 + j];
-        z[i] = s;
-    }
-}
-
-// partial sums of r.z and r.r (banks 0 and 1), optionally p := z
-__global__ __launch_bounds__(kBlock) void dot_rz_kernel(int64_t n, const double *__restrict__ r,
-                                                        const double *__restrict__ z, double *__restrict__ p_out,
-                                                        const CgState *st, int it, double *partials_out)
-{
-    __shared__ double red[4];
-    if (st && it >= st->stop_iter) return;
-    double a0 = 0.0, a1 = 0.0;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        const double rv = r[i], zv = z[i];
-        a0 += rv * zv;
-        a1 += rv * rv;
-        if (p_out) p_out[i] = zv;
-    }
-    const double s0 = block_sum(a0, red);
-    const double s1 = block_sum(a1, red);
-    if (threadIdx.x == 0) {
-        partials_out[blockIdx.x] = s0;
-        partials_out[gridDim.x + blockIdx.x] = s1;
     }
 }
 
@@ -1436,16 +195,6 @@ int schwz_scatter(int64_t n, const schwz_idx *d_idx, const double *d_from, doubl
 
 }  // extern "C"
 
-// `pad` extra zeroed elements follow the data (the 16-byte SpMV loads may touch them)
-template <typename T>
-static int upload(const T *h, size_t count, void **d, size_t pad = 0)
-{
-    *d = nullptr;
-    SCHWZ_HIP_TRY(hipMalloc(d, (count + pad ? count + pad : 1) * sizeof(T)));
-    if (count) SCHWZ_HIP_TRY(hipMemcpy(*d, h, count * sizeof(T), hipMemcpyHostToDevice));
-    if (pad) SCHWZ_HIP_TRY(hipMemset((char *)*d + count * sizeof(T), 0, pad * sizeof(T)));
-    return SCHWZ_OK;
-}
 
 extern "C" {
 
@@ -1637,782 +386,6 @@ int schwz_stream_probe(int64_t n, int mode, const double *d_src, double *d_dst, 
     return SCHWZ_OK;
 }
 
-// ---- profiling hooks (bench.py roofline leg) ------------------------------------
-// HIP-event pairs around every launch of the dominant kernel (the CSR SpMV of the
-// PCG iteration) on the stream it is launched on.
-}  // extern "C"
-
-namespace {
-struct ProfState {
-    bool on = false;
-    std::vector<hipEvent_t> ev;
-    std::vector<int> kind;  // per event pair: 0 = the SpMV launch of a CG iteration, 1 = its update launch
-    size_t used = 0;
-    double total[2] = {0.0, 0.0};
-    int64_t count[2] = {0, 0};
-} g_prof;
-}  // namespace
-
-extern "C" {
-
-int schwz_profile_begin(int capacity)
-{
-    SCHWZ_REQUIRE(capacity > 0, "schwz_profile_begin: capacity must be positive");
-    while (g_prof.ev.size() < (size_t)2 * capacity) {
-        hipEvent_t e;
-        SCHWZ_HIP_TRY(hipEventCreate(&e));
-        g_prof.ev.push_back(e);
-    }
-    g_prof.kind.assign((size_t)capacity, 0);
-    g_prof.used = 0;
-    g_prof.on = true;
-    return SCHWZ_OK;
-}
-
-int schwz_profile_end(double *h_total_ms, int64_t *h_launches)
-{
-    SCHWZ_REQUIRE(h_total_ms && h_launches, "schwz_profile_end: null output");
-    g_prof.on = false;
-    SCHWZ_HIP_TRY(hipDeviceSynchronize());
-    g_prof.total[0] = g_prof.total[1] = 0.0;
-    g_prof.count[0] = g_prof.count[1] = 0;
-    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
-        float ms = 0.f;
-        SCHWZ_HIP_TRY(hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]));
-        const int k = g_prof.kind[i / 2] ? 1 : 0;
-        g_prof.total[k] += ms;
-        g_prof.count[k] += 1;
-    }
-    *h_total_ms = g_prof.total[0];
-    *h_launches = g_prof.count[0];
-    g_prof.used = 0;
-    return SCHWZ_OK;
-}
-
-int schwz_profile_kind(int kind, double *h_total_ms, int64_t *h_launches)
-{
-    SCHWZ_REQUIRE(h_total_ms && h_launches && (kind == 0 || kind == 1), "schwz_profile_kind: bad arguments");
-    *h_total_ms = g_prof.total[kind];
-    *h_launches = g_prof.count[kind];
-    return SCHWZ_OK;
-}
-
-// ---- PCG --------------------------------------------------------------------
-
-int schwz_pcg_create(const schwz_csr *A, int precond, schwz_pcg **out)
-{
-    return schwz_pcg_create_ex(A, precond, 1, out);
-}
-
-// block-Jacobi / ILU(0) setup: the (setup-time) host copy of the matrix comes back from HBM
-static int pcg_setup_general(schwz_pcg *s)
-{
-    const CsrView &A = s->A->v;
-    const int64_t n = s->n;
-    std::vector<schwz_idx> rp((size_t)n + 1), col((size_t)A.nnz);
-    std::vector<double> val((size_t)A.nnz);
-    SCHWZ_HIP_TRY(hipMemcpy(rp.data(), A.rp, rp.size() * sizeof(schwz_idx), hipMemcpyDeviceToHost));
-    if (A.nnz) {
-        SCHWZ_HIP_TRY(hipMemcpy(col.data(), A.col, col.size() * sizeof(schwz_idx), hipMemcpyDeviceToHost));
-        SCHWZ_HIP_TRY(hipMemcpy(val.data(), A.val, val.size() * sizeof(double), hipMemcpyDeviceToHost));
-    }
-    SCHWZ_HIP_TRY(hipMalloc((void **)&s->z, (size_t)(n ? n : 1) * sizeof(double)));
-    if (s->precond == SCHWZ_PRECOND_ILU || s->precond == SCHWZ_PRECOND_ISAI) {
-        schwz_idx *l_rp, *l_col, *u_rp, *u_col;
-        double *l_val, *u_val;
-        int rc = schwz_ilu0(n, rp.data(), col.data(), val.data(), &l_rp, &l_col, &l_val, &u_rp, &u_col, &u_val);
-        if (rc) return rc;
-        if (s->precond == SCHWZ_PRECOND_ISAI) {
-            // Ilu<LowerIsai, UpperIsai> (solve.cpp:616-638): z = W_U (W_L r), two CSR products on
-            // the patterns of L and U, stored like any other matrix of this library
-            double *wl = nullptr, *wu = nullptr;
-            rc = schwz_isai(n, l_rp, l_col, l_val, 1, &wl);
-            if (!rc) rc = schwz_isai(n, u_rp, u_col, u_val, 0, &wu);
-            if (!rc) rc = schwz_csr_create(n, n, l_rp, l_col, wl, &s->isai_l);
-            if (!rc) rc = schwz_csr_create(n, n, u_rp, u_col, wu, &s->isai_u);
-            if (!rc && hipMalloc((void **)&s->isai_tmp, (size_t)(n ? n : 1) * sizeof(double)) != hipSuccess) {
-                set_error("schwz_pcg_create: out of device memory (ISAI work vector)");
-                rc = SCHWZ_ERR_HIP;
-            }
-            schwz_free(wl);
-            schwz_free(wu);
-        } else {
-            rc = schwz_trs_create(n, l_rp, l_col, l_val, u_rp, u_col, u_val, nullptr, &s->ilu);
-        }
-        schwz_free(l_rp);
-        schwz_free(l_col);
-        schwz_free(l_val);
-        schwz_free(u_rp);
-        schwz_free(u_col);
-        schwz_free(u_val);
-        return rc;
-    }
-    // block-Jacobi: consecutive blocks of bs rows, inverted by Gauss-Jordan with partial
-    // pivoting; identical inverse blocks are stored once (a stencil matrix has a handful)
-    const int bs = s->block_size;
-    const int64_t nb = (n + bs - 1) / bs;
-    std::vector<schwz_idx> id((size_t)nb);
-    std::vector<double> uniq, blk((size_t)bs * bs), inv((size_t)bs * bs);
-    std::unordered_multimap<uint64_t, schwz_idx> seen;
-    for (int64_t b = 0; b < nb; ++b) {
-        const int64_t r0 = b * bs;
-        std::fill(blk.begin(), blk.end(), 0.0);
-        for (int i = 0; i < bs; ++i) {
-            if (r0 + i >= n) {
-                blk[(size_t)i * bs + i] = 1.0;
-                continue;
-            }
-            for (schwz_idx j = rp[(size_t)(r0 + i)]; j < rp[(size_t)(r0 + i) + 1]; ++j)
-                if (col[(size_t)j] >= r0 && col[(size_t)j] < r0 + bs)
-                    blk[(size_t)i * bs + (col[(size_t)j] - r0)] = val[(size_t)j];
-        }
-        uint64_t h = 1469598103934665603ull;
-        for (double v : blk) {
-            uint64_t bits;
-            std::memcpy(&bits, &v, 8);
-            h = (h ^ bits) * 1099511628211ull;
-        }
-        // invert (the copy in blk is destroyed)
-        std::vector<double> a = blk;
-        for (int i = 0; i < bs; ++i)
-            for (int j = 0; j < bs; ++j) inv[(size_t)i * bs + j] = i == j ? 1.0 : 0.0;
-        for (int c = 0; c < bs; ++c) {
-            int piv = c;
-            for (int r = c + 1; r < bs; ++r)
-                if (std::fabs(a[(size_t)r * bs + c]) > std::fabs(a[(size_t)piv * bs + c])) piv = r;
-            if (a[(size_t)piv * bs + c] == 0.0) {
-                set_error("block-Jacobi: singular diagonal block");
-                return SCHWZ_ERR_NOT_SPD;
-            }
-            if (piv != c)
-                for (int j = 0; j < bs; ++j) {
-                    std::swap(a[(size_t)c * bs + j], a[(size_t)piv * bs + j]);
-                    std::swap(inv[(size_t)c * bs + j], inv[(size_t)piv * bs + j]);
-                }
-            const double d = a[(size_t)c * bs + c];
-            for (int j = 0; j < bs; ++j) {
-                a[(size_t)c * bs + j] /= d;
-                inv[(size_t)c * bs + j] /= d;
-            }
-            for (int r = 0; r < bs; ++r) {
-                if (r == c) continue;
-                const double f = a[(size_t)r * bs + c];
-                if (f == 0.0) continue;
-                for (int j = 0; j < bs; ++j) {
-                    a[(size_t)r * bs + j] -= f * a[(size_t)c * bs + j];
-                    inv[(size_t)r * bs + j] -= f * inv[(size_t)c * bs + j];
-                }
-            }
-        }
-        schwz_idx found = -1;
-        auto range = seen.equal_range(h);
-        for (auto it = range.first; it != range.second; ++it)
-            if (std::memcmp(&uniq[(size_t)it->second * bs * bs], inv.data(), sizeof(double) * bs * bs) == 0) {
-                found = it->second;
-                break;
-            }
-        if (found < 0) {
-            found = (schwz_idx)(uniq.size() / ((size_t)bs * bs));
-            uniq.insert(uniq.end(), inv.begin(), inv.end());
-            seen.emplace(h, found);
-        }
-        id[(size_t)b] = found;
-    }
-    int rc;
-    void *d;
-    if ((rc = upload(id.data(), id.size(), &d))) return rc;
-    s->d_blk_id = (schwz_idx *)d;
-    if ((rc = upload(uniq.data(), uniq.size(), &d))) return rc;
-    s->d_blk_inv = (double *)d;
-    return SCHWZ_OK;
-}
-
-// everything of schwz_pcg_create_ex that can fail half way: the caller destroys `s` on error
-static int pcg_build(schwz_pcg *s, const schwz_csr *A, int precond)
-{
-    const size_t nb = (size_t)(s->n ? s->n : 1) * sizeof(double);
-    SCHWZ_HIP_TRY(hipMalloc((void **)&s->r, nb));
-    SCHWZ_HIP_TRY(hipMalloc((void **)&s->p, nb));
-    SCHWZ_HIP_TRY(hipMalloc((void **)&s->q, nb));
-    SCHWZ_HIP_TRY(hipMalloc((void **)&s->partials, sizeof(double) * 5 * kMaxGrid));
-    SCHWZ_HIP_TRY(hipMalloc((void **)&s->d_norm_sq, sizeof(double) * 2));
-    SCHWZ_HIP_TRY(hipMalloc((void **)&s->state, sizeof(CgState)));
-    SCHWZ_HIP_TRY(hipHostMalloc((void **)&s->h_state, 2 * sizeof(CgState), hipHostMallocDefault));
-    SCHWZ_HIP_TRY(hipEventCreateWithFlags(&s->ev[0], hipEventDisableTiming));
-    SCHWZ_HIP_TRY(hipEventCreateWithFlags(&s->ev[1], hipEventDisableTiming));
-    if (precond == SCHWZ_PRECOND_JACOBI) {
-        SCHWZ_HIP_TRY(hipMalloc((void **)&s->dinv, nb));
-        if (s->n) {
-            hipLaunchKernelGGL(extract_dinv_kernel, dim3(grid_for(s->n)), dim3(kBlock), 0, 0, A->v, s->dinv);
-            SCHWZ_HIP_TRY(hipGetLastError());
-            SCHWZ_HIP_TRY(hipDeviceSynchronize());
-        }
-        // compact representation for the per-iteration vector kernels (DiagView)
-        s->diag.mode = 1;
-        s->diag.full = s->dinv;
-        const char *env = std::getenv("SCHWZ_DIAG_DICT");
-        if (s->n && !(env && env[0] == '0')) {
-            std::vector<double> h((size_t)s->n);
-            SCHWZ_HIP_TRY(hipMemcpy(h.data(), s->dinv, (size_t)s->n * sizeof(double), hipMemcpyDeviceToHost));
-            std::vector<double> dict;
-            std::vector<uint8_t> code((size_t)s->n + 2, 0);
-            bool ok = true;
-            for (int64_t i = 0; i < s->n && ok; ++i) {
-                int c = -1;
-                for (size_t k = 0; k < dict.size(); ++k)
-                    if (std::memcmp(&dict[k], &h[(size_t)i], 8) == 0) {
-                        c = (int)k;
-                        break;
-                    }
-                if (c < 0) {
-                    if (dict.size() == 256) {
-                        ok = false;
-                        break;
-                    }
-                    c = (int)dict.size();
-                    dict.push_back(h[(size_t)i]);
-                }
-                code[(size_t)i] = (uint8_t)c;
-            }
-            if (ok && dict.size() == 1) {
-                s->diag.mode = 3;
-                s->diag.uniform = dict[0];
-            } else if (ok && dict.size() <= 16) {  // linear search above stays cheap
-                int rc;
-                if ((rc = upload(code.data(), code.size(), &s->d_dcode)) ||
-                    (rc = upload(dict.data(), dict.size(), &s->d_ddict)))
-                    return rc;
-                s->diag.mode = 2;
-                s->diag.code = (const uint8_t *)s->d_dcode;
-                s->diag.dict = (const double *)s->d_ddict;
-                s->diag.ndict = (int)dict.size();
-            }
-        }
-    }
-    if (precond == SCHWZ_PRECOND_BLOCK_JACOBI || precond == SCHWZ_PRECOND_ILU || precond == SCHWZ_PRECOND_ISAI) {
-        int rc = pcg_setup_general(s);
-        if (rc) return rc;
-    }
-    return SCHWZ_OK;
-}
-
-int schwz_pcg_create_ex(const schwz_csr *A, int precond, int block_size, schwz_pcg **out)
-{
-    SCHWZ_REQUIRE(A && out, "schwz_pcg_create: null argument");
-    SCHWZ_REQUIRE(A->v.nrows == A->v.ncols, "schwz_pcg_create: matrix not square");
-    SCHWZ_REQUIRE(precond >= SCHWZ_PRECOND_NONE && precond <= SCHWZ_PRECOND_ISAI,
-                  "schwz_pcg_create: unknown preconditioner");
-    SCHWZ_REQUIRE(block_size >= 1 && block_size <= 32, "schwz_pcg_create: block size must be in 1..32");
-    if (precond == SCHWZ_PRECOND_BLOCK_JACOBI && block_size == 1) precond = SCHWZ_PRECOND_JACOBI;
-    schwz_pcg *s = new schwz_pcg();
-    s->A = A;
-    s->precond = precond;
-    s->block_size = block_size;
-    s->n = A->v.nrows;
-    const int rc = pcg_build(s, A, precond);
-    if (rc) {
-        schwz_pcg_destroy(s);
-        return rc;
-    }
-    *out = s;
-    return SCHWZ_OK;
-}
-
-void schwz_pcg_destroy(schwz_pcg *s)
-{
-    if (!s) return;
-    (void)hipFree(s->r);
-    (void)hipFree(s->p);
-    (void)hipFree(s->q);
-    (void)hipFree(s->dinv);
-    (void)hipFree(s->z);
-    (void)hipFree(s->d_blk_id);
-    (void)hipFree(s->d_blk_inv);
-    for (auto &g : s->graphs) (void)hipGraphExecDestroy(g.exec);
-    if (s->capture_stream) (void)hipStreamDestroy(s->capture_stream);
-    schwz_trs_destroy(s->ilu);
-    schwz_csr_destroy(s->isai_l);
-    schwz_csr_destroy(s->isai_u);
-    (void)hipFree(s->isai_tmp);
-    (void)hipFree(s->d_dcode);
-    (void)hipFree(s->d_ddict);
-    (void)hipFree(s->partials);
-    (void)hipFree(s->d_norm_sq);
-    (void)hipFree(s->state);
-    (void)hipHostFree(s->h_state);
-    if (s->ev[0]) (void)hipEventDestroy(s->ev[0]);
-    if (s->ev[1]) (void)hipEventDestroy(s->ev[1]);
-    delete s;
-}
-
-}  // extern "C"
-
-namespace schwz {
-
-// z = M^-1 r for the preconditioners that are operators of their own
-__global__ __launch_bounds__(kBlock) void diag_scale_kernel(int64_t n, const double *__restrict__ dinv,
-                                                            const double *__restrict__ in, double *__restrict__ out)
-{
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) out[i] = dinv[i] * in[i];
-}
-
-// out = M^-1 in for whichever preconditioner the object holds (in != out)
-int precond_apply(schwz_pcg *s, const double *in, double *out, hipStream_t st)
-{
-    if (s->n == 0) return SCHWZ_OK;
-    if (s->precond == SCHWZ_PRECOND_ILU) return schwz_trs_solve(s->ilu, in, out, (schwz_stream)st);
-    if (s->precond == SCHWZ_PRECOND_ISAI) {
-        SpmvArgs a;
-        a.x = in;
-        a.y = s->isai_tmp;
-        int rc = launch_spmv(s->isai_l->v, kSpmvPlain, a, 0, st);
-        if (rc) return rc;
-        a.x = s->isai_tmp;
-        a.y = out;
-        return launch_spmv(s->isai_u->v, kSpmvPlain, a, 0, st);
-    }
-    if (s->precond == SCHWZ_PRECOND_BLOCK_JACOBI) {
-        hipLaunchKernelGGL(block_jacobi_apply_kernel, dim3(grid_for(s->n)), dim3(kBlock), 0, st, s->n, s->block_size,
-                           s->d_blk_id, s->d_blk_inv, in, out);
-    } else if (s->precond == SCHWZ_PRECOND_JACOBI) {
-        hipLaunchKernelGGL(diag_scale_kernel, dim3(grid_for(s->n)), dim3(kBlock), 0, st, s->n, s->dinv, in, out);
-    } else {
-        hipLaunchKernelGGL(copy_kernel, dim3(grid_for(s->n)), dim3(kBlock), 0, st, s->n, in, out);
-    }
-    SCHWZ_HIP_TRY(hipGetLastError());
-    return SCHWZ_OK;
-}
-
-static int pcg_apply_general(schwz_pcg *s, hipStream_t st) { return precond_apply(s, s->r, s->z, st); }
-
-static bool pcg_is_general(const schwz_pcg *s)
-{
-    return s->precond == SCHWZ_PRECOND_BLOCK_JACOBI || s->precond == SCHWZ_PRECOND_ILU ||
-           s->precond == SCHWZ_PRECOND_ISAI;
-}
-
-// First half of a solve: r = b - A x, p = M^-1 r, rho, ||r||^2 -> CgState.  With
-// `fused` the same pass over the matrix also yields ||b - A x2||^2 over the rows
-// below row_limit in s->d_norm_sq[0] (x2 == nullptr: x2 is x).
-int pcg_begin(schwz_pcg *s, const double *d_b, double *d_x, double rtol, bool fused, const double *d_x2,
-              int64_t row_limit, hipStream_t st)
-{
-    const CsrView &A = s->A->v;
-    const int gs = spmv_grid(A, s->variant);
-    SpmvArgs a;
-    a.x = d_x;
-    a.x2 = d_x2;
-    a.b = d_b;
-    a.y = s->r;
-    a.p = s->p;
-    a.dinv = s->dinv;
-    a.partials = s->partials;
-    a.row_limit = row_limit;
-    // x2 == x over all rows: the check residual IS the start residual (rr bank)
-    const bool same = fused && d_x2 == nullptr && row_limit >= s->n;
-    if (pcg_is_general(s)) a.dinv = nullptr;  // p := r for now, z follows
-    int rc = launch_spmv(A, (fused && !same) ? kSpmvResidDual : kSpmvResidInit, a, s->variant, st);
-    if (rc) return rc;
-    if (pcg_is_general(s)) {
-        // the check-residual norm (bank 1 or 2 of the SpMV partials) first, then z = M^-1 r,
-        // p = z and rho = r.z, ||r||^2 from the vector-kernel partials
-        if (fused) {
-            hipLaunchKernelGGL(final_norm_kernel, dim3(1), dim3(kBlock), 0, st, s->partials + (same ? 1 : 2) * gs, gs,
-                               s->d_norm_sq);
-        }
-        if ((rc = pcg_apply_general(s, st))) return rc;
-        const int gv = grid_for(s->n);
-        double *part_vec = s->partials + 3 * kMaxGrid;
-        hipLaunchKernelGGL(dot_rz_kernel, dim3(gv), dim3(kBlock), 0, st, s->n, s->r, s->z, s->p, nullptr, 0, part_vec);
-        hipLaunchKernelGGL(cg_init_finalize_kernel, dim3(1), dim3(kBlock), 0, st, s->state, part_vec, gv, rtol, nullptr,
-                           1);
-        SCHWZ_HIP_TRY(hipGetLastError());
-        return SCHWZ_OK;
-    }
-    hipLaunchKernelGGL(cg_init_finalize_kernel, dim3(1), dim3(kBlock), 0, st, s->state, s->partials, gs, rtol,
-                       fused ? s->d_norm_sq : nullptr, same ? 1 : 2);
-    SCHWZ_HIP_TRY(hipGetLastError());
-    return SCHWZ_OK;
-}
-
-// Second half: up to max_iters CG updates.  With a positive tolerance the host
-// looks at the state every `chunk` iterations, one chunk behind the launches, so
-// the queue never drains.
-int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream_t st)
-{
-    const CsrView &A = s->A->v;
-    const int64_t n = s->n;
-    const int gs = spmv_grid(A, s->variant);
-    const int gv = grid_for((n + 1) / 2);
-    double *part_spmv = s->partials;                // [3][gs]
-    double *part_vec = s->partials + 3 * kMaxGrid;  // [2][gv]
-    const bool poll = rtol > 0.0;
-    const bool general = pcg_is_general(s);
-    // SCHWZ_CG_QFREE=0 keeps the stored-q iteration for row-pair coded matrices too (A/B runs)
-    static const bool qfree_on = [] {
-        const char *e = std::getenv("SCHWZ_CG_QFREE");
-        return !(e && e[0] == '0');
-    }();
-    const bool qfree = qfree_on && !general && A.pair_id && s->variant == 0 && s->diag.mode != 2;
-    // one CG iteration on stream `q`; `it` only enters through its parity (rho slot) and through
-    // "it >= stop_iter", and stop_iter is 0 once the tolerance test has fired: a recorded sequence
-    // of an even number of iterations can therefore be replayed as a hipGraph
-    auto launch_iteration = [&](int it, hipStream_t q, bool instrument) -> int {
-        SpmvArgs a;
-        a.x = s->p;
-        a.y = s->q;
-        a.partials = part_spmv;
-        a.stop_iter = &s->state->stop_iter;
-        a.it = it;
-        const bool prof = instrument && g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
-        if (prof) SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used], q));
-        int rc = launch_spmv(A, qfree ? kSpmvDotOnly : kSpmvDot, a, s->variant, q);
-        if (rc) return rc;
-        if (prof) {
-            SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used + 1], q));
-            g_prof.kind[g_prof.used / 2] = 0;
-            g_prof.used += 2;
-        }
-        if (qfree) {
-            // q = A p is never stored: the update pass recomputes (A p)_i row by row while it
-            // streams x and r (spmv_pair.hip, kSpmvCgUpdate): 16 B per row less HBM traffic, a
-            // third of the stores of these two launches
-            SpmvArgs u;
-            u.x = s->p;
-            u.cg_x = d_x;
-            u.cg_r = s->r;
-            u.cg_state = s->state;
-            u.pq_partials = part_spmv;
-            u.pq_nparts = gs;
-            u.diag_mode = s->diag.mode;
-            u.diag_uniform = s->diag.uniform;
-            u.dinv = s->dinv;
-            u.partials = part_vec;
-            u.it = it;
-            const bool prof2 = instrument && g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
-            if (prof2) SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used], q));
-            if ((rc = launch_spmv(A, kSpmvCgUpdate, u, s->variant, q))) return rc;
-            if (prof2) {
-                SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used + 1], q));
-                g_prof.kind[g_prof.used / 2] = 1;
-                g_prof.used += 2;
-            }
-            hipLaunchKernelGGL((cg_direction_kernel<1, false>), dim3(gv), dim3(kBlock), 0, q, n, s->p, s->r, s->diag,
-                               part_vec, gs, s->state, it, rtol);
-        } else if (!general) {
-            hipLaunchKernelGGL((cg_update_kernel<1, false>), dim3(gv), dim3(kBlock), 0, q, n, d_x, s->r, s->p, s->q,
-                               s->diag, part_spmv, gs, s->state, it, part_vec);
-            hipLaunchKernelGGL((cg_direction_kernel<1, false>), dim3(gv), dim3(kBlock), 0, q, n, s->p, s->r, s->diag,
-                               part_vec, gv, s->state, it, rtol);
-        } else {
-            // x, r update without a preconditioner; z = M^-1 r; rho' = r.z; p = z + beta p
-            const DiagView none;
-            const int gz = grid_for(n);
-            hipLaunchKernelGGL((cg_update_kernel<1, false>), dim3(gv), dim3(kBlock), 0, q, n, d_x, s->r, s->p, s->q,
-                               none, part_spmv, gs, s->state, it, part_vec);
-            if ((rc = pcg_apply_general(s, q))) return rc;
-            hipLaunchKernelGGL(dot_rz_kernel, dim3(gz), dim3(kBlock), 0, q, n, s->r, s->z, (double *)nullptr, s->state,
-                               it, part_vec);
-            hipLaunchKernelGGL((cg_direction_kernel<1, false>), dim3(gv), dim3(kBlock), 0, q, n, s->p, s->z, none,
-                               part_vec, gz, s->state, it, rtol);
-        }
-        return SCHWZ_OK;
-    };
-    // Small systems are bound by launches, not bytes (33 k rows: 3 launches of ~3 us work each):
-    // kGraphIters iterations are captured once per (x, rtol) into a hipGraph -- on a private stream,
-    // the caller's may be the legacy default stream -- and replayed.  SCHWZ_CG_GRAPH=0 disables,
-    // =2 uses graphs for every size.
-    static const int graph_mode = [] {
-        const char *e = std::getenv("SCHWZ_CG_GRAPH");
-        return e ? std::atoi(e) : 1;
-    }();
-    const bool graphable = graph_mode != 0 && !general && !g_prof.on && (graph_mode == 2 || n <= kGraphRows);
-    hipGraphExec_t replay = nullptr;
-    if (graphable && max_iters >= kGraphIters) {
-        for (const auto &g : s->graphs)
-            if (g.x == d_x && g.rtol == rtol && g.variant == s->variant && g.qfree == qfree) replay = g.exec;
-        if (!replay && s->graphs.size() < 4) {
-            if (!s->capture_stream) SCHWZ_HIP_TRY(hipStreamCreateWithFlags(&s->capture_stream, hipStreamNonBlocking));
-            if (hipStreamBeginCapture(s->capture_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                int rc = SCHWZ_OK;
-                for (int k = 0; k < kGraphIters && !rc; ++k) rc = launch_iteration(k, s->capture_stream, false);
-                hipGraph_t graph = nullptr;
-                const hipError_t e1 = hipStreamEndCapture(s->capture_stream, &graph);
-                if (rc) {
-                    if (graph) (void)hipGraphDestroy(graph);
-                    return rc;
-                }
-                if (e1 == hipSuccess && hipGraphInstantiate(&replay, graph, nullptr, nullptr, 0) == hipSuccess)
-                    s->graphs.push_back({d_x, rtol, s->variant, qfree, replay});
-                else
-                    replay = nullptr;
-                if (graph) (void)hipGraphDestroy(graph);
-            }
-            (void)hipGetLastError();
-        }
-    }
-    int chunk = 16;
-    int it = 0, pending = -1, bank = 0;
-    bool stopped = false;
-    while (it < max_iters && !stopped) {
-        const int end = (poll && it + chunk < max_iters) ? it + chunk : max_iters;
-        while (it < end) {
-            if (replay && it % kGraphIters == 0 && end - it >= kGraphIters) {
-                SCHWZ_HIP_TRY(hipGraphLaunch(replay, st));
-                it += kGraphIters;
-                continue;
-            }
-            int rc = launch_iteration(it, st, true);
-            if (rc) return rc;
-            ++it;
-        }
-        SCHWZ_HIP_TRY(hipGetLastError());
-        if (poll && it < max_iters) {
-            if (pending >= 0) {
-                SCHWZ_HIP_TRY(hipEventSynchronize(s->ev[pending]));
-                if (s->h_state[pending].stop_iter != INT_MAX) stopped = true;
-            }
-            SCHWZ_HIP_TRY(hipMemcpyAsync(&s->h_state[bank], s->state, sizeof(CgState), hipMemcpyDeviceToHost, st));
-            SCHWZ_HIP_TRY(hipEventRecord(s->ev[bank], st));
-            pending = bank;
-            bank ^= 1;
-            if (chunk < 64) chunk *= 2;
-        }
-    }
-    return SCHWZ_OK;
-}
-
-}  // namespace schwz
-
-extern "C" {
-
-int schwz_pcg_solve(schwz_pcg *s, const double *d_b, double *d_x, double rtol, int max_iters,
-                    int *h_iters, double *h_resnorm, schwz_stream stream)
-{
-    SCHWZ_REQUIRE(s && d_b && d_x, "schwz_pcg_solve: null argument");
-    SCHWZ_REQUIRE(max_iters >= 0, "schwz_pcg_solve: negative max_iters");
-    SCHWZ_REQUIRE((reinterpret_cast<uintptr_t>(d_x) & 15) == 0, "schwz_pcg_solve: x must be 16-byte aligned");
-    hipStream_t st = (hipStream_t)stream;
-    if (s->n == 0) {
-        if (h_iters) *h_iters = 0;
-        if (h_resnorm) *h_resnorm = 0.0;
-        return SCHWZ_OK;
-    }
-    int rc = pcg_begin(s, d_b, d_x, rtol, false, nullptr, 0, st);
-    if (rc) return rc;
-    if ((rc = pcg_iterate(s, d_x, rtol, max_iters, st))) return rc;
-    if (h_iters || h_resnorm) {
-        SCHWZ_HIP_TRY(hipMemcpyAsync(&s->h_state[0], s->state, sizeof(CgState), hipMemcpyDeviceToHost, st));
-        SCHWZ_HIP_TRY(hipStreamSynchronize(st));
-        if (h_iters) *h_iters = s->h_state[0].iters;
-        if (h_resnorm) *h_resnorm = sqrt(s->h_state[0].rr);
-    }
-    return SCHWZ_OK;
-}
-
-// ---- triangular solves --------------------------------------------------------
-
-// levels of a triangular CSR: lower => forward dependencies on columns < row
-static void level_schedule(int64_t n, const schwz_idx *rp, const schwz_idx *col, bool lower,
-                           std::vector<schwz_idx> &order, std::vector<schwz_idx> &lvl_ptr)
-{
-    std::vector<schwz_idx> level((size_t)n, 0);
-    schwz_idx nl = 0;
-    if (lower) {
-        for (int64_t i = 0; i < n; ++i) {
-            schwz_idx l = 0;
-            for (schwz_idx j = rp[i]; j < rp[i + 1]; ++j)
-                if (col[j] < i && level[col[j]] + 1 > l) l = level[col[j]] + 1;
-            level[i] = l;
-            if (l + 1 > nl) nl = l + 1;
-        }
-    } else {
-        for (int64_t i = n - 1; i >= 0; --i) {
-            schwz_idx l = 0;
-            for (schwz_idx j = rp[i]; j < rp[i + 1]; ++j)
-                if (col[j] > i && level[col[j]] + 1 > l) l = level[col[j]] + 1;
-            level[i] = l;
-            if (l + 1 > nl) nl = l + 1;
-        }
-    }
-    lvl_ptr.assign((size_t)nl + 1, 0);
-    for (int64_t i = 0; i < n; ++i) lvl_ptr[level[i] + 1]++;
-    for (schwz_idx l = 0; l < nl; ++l) lvl_ptr[l + 1] += lvl_ptr[l];
-    order.resize((size_t)n);
-    std::vector<schwz_idx> fill(lvl_ptr.begin(), lvl_ptr.end() - 1);
-    for (int64_t i = 0; i < n; ++i) order[fill[level[i]]++] = (schwz_idx)i;
-}
-
-int schwz_trs_create(int64_t n, const schwz_idx *l_rp, const schwz_idx *l_col, const double *l_val,
-                     const schwz_idx *u_rp, const schwz_idx *u_col, const double *u_val,
-                     const schwz_idx *perm, schwz_trs **out)
-{
-    SCHWZ_REQUIRE(out && n >= 0 && l_rp && u_rp, "schwz_trs_create: bad arguments");
-    for (int64_t i = 0; i < n; ++i) {
-        SCHWZ_REQUIRE(l_rp[i + 1] > l_rp[i] && l_col[l_rp[i + 1] - 1] == i,
-                      "schwz_trs_create: L must hold its diagonal last in each row");
-        SCHWZ_REQUIRE(u_rp[i + 1] > u_rp[i] && u_col[u_rp[i]] == i,
-                      "schwz_trs_create: U must hold its diagonal first in each row");
-        SCHWZ_REQUIRE(!perm || (perm[i] >= 0 && perm[i] < n), "schwz_trs_create: permutation out of range");
-    }
-    schwz_trs *t = new schwz_trs();
-    t->n = n;
-    std::vector<schwz_idx> lo, ll, uo, ul;
-    level_schedule(n, l_rp, l_col, true, lo, ll);
-    level_schedule(n, u_rp, u_col, false, uo, ul);
-    t->l_nlvl = (int)ll.size() - 1;
-    t->u_nlvl = (int)ul.size() - 1;
-    // One workgroup handles the whole solve while the factor is small; otherwise wide levels get
-    // a multi-workgroup launch each and runs of narrow levels share a one-workgroup launch.
-    t->fused = n <= 8192;
-    // a level of >= wide_min rows gets a launch of its own (SCHWZ_TRS_WIDE overrides the threshold)
-    const char *wenv = std::getenv("SCHWZ_TRS_WIDE");
-    const int wide_min = (wenv && std::atoi(wenv) > 0) ? std::atoi(wenv) : 256;  // measured: 4096 -> 11.8, 1024 -> 5.4, 256 -> 5.1 ms per ILU-CG iteration at 128^3
-    auto plan = [wide_min](const std::vector<schwz_idx> &lvl, std::vector<schwz_trs::Seg> &out) {
-        const int nl = (int)lvl.size() - 1;
-        int l = 0;
-        while (l < nl) {
-            if (lvl[(size_t)l + 1] - lvl[(size_t)l] >= wide_min) {
-                out.push_back({l, l + 1, true});
-                ++l;
-            } else {
-                int e = l;
-                while (e < nl && lvl[(size_t)e + 1] - lvl[(size_t)e] < wide_min) ++e;
-                out.push_back({l, e, false});
-                l = e;
-            }
-        }
-    };
-    plan(ll, t->l_plan);
-    plan(ul, t->u_plan);
-    t->h_l_lvl = ll;
-    t->h_u_lvl = ul;
-    int rc = 0;
-    void *d;
-#define UP(dst, src, cnt, T)                        \
-    if (!rc) {                                      \
-        rc = upload<T>((src), (size_t)(cnt), &d);   \
-        dst = (decltype(dst))d;                     \
-    }
-    UP(t->l_rp, l_rp, n + 1, schwz_idx)
-    UP(t->l_col, l_col, l_rp[n], schwz_idx)
-    UP(t->l_val, l_val, l_rp[n], double)
-    UP(t->u_rp, u_rp, n + 1, schwz_idx)
-    UP(t->u_col, u_col, u_rp[n], schwz_idx)
-    UP(t->u_val, u_val, u_rp[n], double)
-    if (perm) {
-        UP(t->perm, perm, n, schwz_idx)
-    }
-    UP(t->l_order, lo.data(), lo.size(), schwz_idx)
-    UP(t->l_lvl, ll.data(), ll.size(), schwz_idx)
-    UP(t->u_order, uo.data(), uo.size(), schwz_idx)
-    UP(t->u_lvl, ul.data(), ul.size(), schwz_idx)
-#undef UP
-    if (rc) {
-        schwz_trs_destroy(t);
-        return rc;
-    }
-    SCHWZ_HIP_TRY(hipMalloc((void **)&t->w0, sizeof(double) * (size_t)(n ? n : 1)));
-    SCHWZ_HIP_TRY(hipMalloc((void **)&t->w1, sizeof(double) * (size_t)(n ? n : 1)));
-    *out = t;
-    return SCHWZ_OK;
-}
-
-void schwz_trs_destroy(schwz_trs *t)
-{
-    if (!t) return;
-    void *ptrs[] = {t->l_rp, t->l_col, t->l_val, t->u_rp, t->u_col, t->u_val, t->perm,
-                    t->l_order, t->l_lvl, t->u_order, t->u_lvl, t->w0, t->w1};
-    for (void *p : ptrs) (void)hipFree(p);
-    for (auto &g : t->graphs) (void)hipGraphExecDestroy(g.exec);
-    if (t->capture_stream) (void)hipStreamDestroy(t->capture_stream);
-    delete t;
-}
-
-int schwz_trs_solve(schwz_trs *t, const double *d_b, double *d_y, schwz_stream stream)
-{
-    SCHWZ_REQUIRE(t && d_b && d_y, "schwz_trs_solve: null argument");
-    if (t->n == 0) return SCHWZ_OK;
-    hipStream_t st = (hipStream_t)stream;
-    if (t->fused && t->perm) {
-        hipLaunchKernelGGL(trs_solve_kernel, dim3(1), dim3(kTrsBlock), 0, st, t->n, t->perm, t->l_rp, t->l_col,
-                           t->l_val, t->l_order, t->l_lvl, t->l_nlvl, t->u_rp, t->u_col, t->u_val, t->u_order,
-                           t->u_lvl, t->u_nlvl, d_b, d_y, t->w0, t->w1);
-        SCHWZ_HIP_TRY(hipGetLastError());
-        return SCHWZ_OK;
-    }
-    // The level-by-level plan is a fixed sequence of launches for given (b, y): it is captured once
-    // into a hipGraph (on a private stream: the caller's may be the legacy default stream, which
-    // cannot capture) and replayed with one graph launch afterwards.  SCHWZ_TRS_GRAPH=0 disables.
-    static const bool graphs_on = [] {
-        const char *e = std::getenv("SCHWZ_TRS_GRAPH");
-        return !(e && e[0] == '0');
-    }();
-    hipStream_t user_stream = st;
-    bool capturing = false;
-    if (graphs_on && !t->graphs_failed && t->l_plan.size() + t->u_plan.size() > 8) {
-        for (const auto &g : t->graphs)
-            if (g.b == d_b && g.y == d_y) {
-                SCHWZ_HIP_TRY(hipGraphLaunch(g.exec, user_stream));
-                return SCHWZ_OK;
-            }
-        if (t->graphs.size() < 4) {
-            if (!t->capture_stream) SCHWZ_HIP_TRY(hipStreamCreateWithFlags(&t->capture_stream, hipStreamNonBlocking));
-            if (hipStreamBeginCapture(t->capture_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                capturing = true;
-                st = t->capture_stream;
-            } else {
-                (void)hipGetLastError();
-            }
-        }
-    }
-    // w0 = P b ; L w1 = w0 ; U w0 = w1 ; y = P^T w0
-    hipLaunchKernelGGL(trs_permute_in_kernel, dim3(grid_for(t->n)), dim3(kBlock), 0, st, t->n, t->perm, d_b, t->w0);
-    for (const auto &sg : t->l_plan) {
-        if (sg.wide) {
-            const int k0 = t->h_l_lvl[(size_t)sg.lvl0], k1 = t->h_l_lvl[(size_t)sg.lvl1];
-            hipLaunchKernelGGL((trs_level_kernel<true>), dim3((k1 - k0 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, k0,
-                               k1, t->l_order, t->l_rp, t->l_col, t->l_val, t->w0, t->w1);
-        } else {
-            hipLaunchKernelGGL((trs_narrow_kernel<true>), dim3(1), dim3(kTrsBlock), 0, st, sg.lvl0, sg.lvl1, t->l_lvl,
-                               t->l_order, t->l_rp, t->l_col, t->l_val, t->w0, t->w1);
-        }
-    }
-    for (const auto &sg : t->u_plan) {
-        if (sg.wide) {
-            const int k0 = t->h_u_lvl[(size_t)sg.lvl0], k1 = t->h_u_lvl[(size_t)sg.lvl1];
-            hipLaunchKernelGGL((trs_level_kernel<false>), dim3((k1 - k0 + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
-                               k0, k1, t->u_order, t->u_rp, t->u_col, t->u_val, t->w1, t->w0);
-        } else {
-            hipLaunchKernelGGL((trs_narrow_kernel<false>), dim3(1), dim3(kTrsBlock), 0, st, sg.lvl0, sg.lvl1, t->u_lvl,
-                               t->u_order, t->u_rp, t->u_col, t->u_val, t->w1, t->w0);
-        }
-    }
-    hipLaunchKernelGGL(trs_permute_out_kernel, dim3(grid_for(t->n)), dim3(kBlock), 0, st, t->n, t->perm, t->w0, d_y);
-    if (capturing) {
-        hipGraph_t graph = nullptr;
-        if (hipStreamEndCapture(t->capture_stream, &graph) != hipSuccess || !graph) {
-            (void)hipGetLastError();
-            t->graphs_failed = true;
-            return schwz_trs_solve(t, d_b, d_y, stream);
-        }
-        hipGraphExec_t exec = nullptr;
-        const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        if (e != hipSuccess) {  // no graph on this system: launch by launch from now on
-            (void)hipGetLastError();
-            t->graphs_failed = true;
-            return schwz_trs_solve(t, d_b, d_y, stream);
-        }
-        t->graphs.push_back({d_b, d_y, exec});
-        SCHWZ_HIP_TRY(hipGraphLaunch(exec, user_stream));
-        return SCHWZ_OK;
-    }
-    SCHWZ_HIP_TRY(hipGetLastError());
-    return SCHWZ_OK;
-}
-
 }  // extern "C"
 
 // ===========================================================================
@@ -2484,3 +457,4 @@ int launch_final_norm(const double *partials, int nparts, double *out, hipStream
 }
 
 }  // namespace schwz
+

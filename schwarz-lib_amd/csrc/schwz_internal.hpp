@@ -125,6 +125,22 @@ struct SpmvArgs {
     double diag_uniform = 1.0;
 };
 
+// launch grid of the streaming vector kernels: one lane per element up to kMaxGrid workgroups
+inline int grid_for(int64_t n)
+{
+    int64_t g = (n + kBlock - 1) / kBlock;
+    if (g > kMaxGrid) g = kMaxGrid;
+    return g < 1 ? 1 : (int)g;
+}
+
+// small launch helpers shared by the translation units (defined in kernels.hip)
+int launch_interface_update(int64_t nrows, int64_t row0, const schwz_idx *rp, const schwz_idx *col,
+                            const double *val, const double *x, const double *b, double *bt, hipStream_t s);
+int launch_final_norm(const double *partials, int nparts, double *out, hipStream_t s);
+int launch_copy(int64_t n, const double *src, double *dst, hipStream_t s);
+int launch_gather_f32(int64_t n, const schwz_idx *idx, const double *from, float *into, hipStream_t s);
+int launch_scatter_f32(int64_t n, const schwz_idx *idx, const float *from, double *into, hipStream_t s);
+
 int spmv_grid(const CsrView &A, int variant);
 int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipStream_t s);
 int launch_spmv_dict(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s);
@@ -313,3 +329,17 @@ struct schwz_subdomain {
     double *d_h_scalar = nullptr;  // device alias of h_scalar
     hipEvent_t ev_scalar = nullptr;
 };
+
+namespace schwz {
+// host vector -> fresh device allocation; `pad` extra zeroed elements follow the data (the 16-byte
+// SpMV loads may touch them)
+template <typename T>
+inline int upload(const T *h, size_t count, void **d, size_t pad = 0)
+{
+    *d = nullptr;
+    SCHWZ_HIP_TRY(hipMalloc(d, (count + pad ? count + pad : 1) * sizeof(T)));
+    if (count) SCHWZ_HIP_TRY(hipMemcpy(*d, h, count * sizeof(T), hipMemcpyHostToDevice));
+    if (pad) SCHWZ_HIP_TRY(hipMemset((char *)*d + count * sizeof(T), 0, pad * sizeof(T)));
+    return SCHWZ_OK;
+}
+}  // namespace schwz

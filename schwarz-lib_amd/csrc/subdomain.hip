@@ -14,15 +14,6 @@
 
 #include "schwz_internal.hpp"
 
-namespace schwz {
-int launch_interface_update(int64_t nrows, int64_t row0, const schwz_idx *rp, const schwz_idx *col,
-                            const double *val, const double *x, const double *b, double *bt, hipStream_t s);
-int launch_final_norm(const double *partials, int nparts, double *out, hipStream_t s);
-int launch_copy(int64_t n, const double *src, double *dst, hipStream_t s);
-int launch_gather_f32(int64_t n, const schwz_idx *idx, const double *from, float *into, hipStream_t s);
-int launch_scatter_f32(int64_t n, const schwz_idx *idx, const float *from, double *into, hipStream_t s);
-}  // namespace schwz
-
 using namespace schwz;
 
 template <typename T>
