@@ -128,6 +128,9 @@ def main():
         # used to rehearse the N>1 path on a 1-GPU box.  The product backend is nccl (= RCCL).
         backend = os.environ.get("SCHWZ_DIST_BACKEND", "nccl")
         if backend == "nccl":
+            # one GPU per rank; a launcher that masks the devices per rank leaves each rank with
+            # a single visible device (index 0)
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
