@@ -58,7 +58,7 @@ class Csr:
         return 12 * self.nnz + 4 * (self.nrows + 1) + 16 * self.nrows
 
     def close(self):
-        if self.h and lib is not None:
+        if getattr(self, "h", None) and lib is not None:
             lib.schwz_csr_destroy(self.h)
             self.h = None
 
@@ -84,7 +84,7 @@ class Pcg:
         return it.value, rn.value
 
     def close(self):
-        if self.h and lib is not None:
+        if getattr(self, "h", None) and lib is not None:
             lib.schwz_pcg_destroy(self.h)
             self.h = None
 
@@ -111,7 +111,7 @@ class Gmres:
         return it.value, rn.value
 
     def close(self):
-        if self.h and lib is not None:
+        if getattr(self, "h", None) and lib is not None:
             lib.schwz_gmres_destroy(self.h)
             self.h = None
 
@@ -136,7 +136,7 @@ class Trs:
         check(lib.schwz_trs_solve(self.h, ptr(d_b), ptr(d_y), _stream_arg(stream)))
 
     def close(self):
-        if self.h and lib is not None:
+        if getattr(self, "h", None) and lib is not None:
             lib.schwz_trs_destroy(self.h)
             self.h = None
 
@@ -285,7 +285,7 @@ class Problem:
         return part
 
     def close(self):
-        if self.h and lib is not None:
+        if getattr(self, "h", None) and lib is not None:
             lib.schwz_problem_destroy(self.h)
             self.h = None
 
@@ -475,7 +475,7 @@ class Subdomain:
         return int(lib.schwz_ras_algorithmic_bytes(self.h, which))
 
     def close(self):
-        if self.h and lib is not None:
+        if getattr(self, "h", None) and lib is not None:
             lib.schwz_subdomain_destroy(self.h)
             self.h = None
 

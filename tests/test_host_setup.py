@@ -283,3 +283,18 @@ def test_local_solver_names_map_like_the_reference(schwz):
     for bad in ("direct-umfpack", "iterative-dealii", "nope"):
         with pytest.raises(schwz.capi.NotImplementedSchwz):
             code(bad)
+
+
+def test_csr_upload_refuses_malformed_matrices(schwz):
+    """The SpMV kernels index x with the stored columns without a bounds test, so the upload
+    validates row_ptr and the columns on the host -- before any device call (runs without a GPU)."""
+    rp = np.array([0, 2, 4], dtype=np.int32)
+    val = np.ones(4)
+    for col in (np.array([0, 1, 0, 2], dtype=np.int32),      # column 2 of a 2-column matrix
+                np.array([0, -1, 0, 1], dtype=np.int32)):    # negative column
+        with pytest.raises(schwz.SchwzError) as e:
+            schwz.Csr(rp, col, val)
+        assert e.value.code == schwz.capi.ERR_INVALID
+    with pytest.raises(schwz.SchwzError) as e:
+        schwz.Csr(np.array([0, 3, 2], dtype=np.int32), np.array([0, 1, 0], dtype=np.int32), np.ones(3))
+    assert e.value.code == schwz.capi.ERR_INVALID
