@@ -22,6 +22,18 @@ namespace schwz {
 static thread_local std::string g_last_error;
 void set_error(const std::string &msg) { g_last_error = msg; }
 
+bool csr_is_well_formed(int64_t nrows, int64_t ncols, const schwz_idx *rp, const schwz_idx *col)
+{
+    bool ok = true;
+#pragma omp parallel for schedule(static) reduction(&& : ok)
+    for (int64_t i = 0; i < nrows; ++i) {
+        bool row_ok = rp[i + 1] >= rp[i];
+        for (schwz_idx j = rp[i]; row_ok && j < rp[i + 1]; ++j) row_ok = col[j] >= 0 && col[j] < ncols;
+        ok = ok && row_ok;
+    }
+    return ok;
+}
+
 }  // namespace schwz
 
 using namespace schwz;

@@ -207,15 +207,8 @@ int schwz_csr_create(int64_t nrows, int64_t ncols, const schwz_idx *h_rp, const 
     SCHWZ_REQUIRE(h_rp[0] == 0 && nnz >= 0, "schwz_csr_create: malformed row_ptr");
     SCHWZ_REQUIRE(nnz == 0 || (h_col && h_val), "schwz_csr_create: null column / value array");
     // the kernels index x with these columns without a bounds test: refuse a malformed matrix here
-    {
-        bool ok = true;
-#pragma omp parallel for schedule(static) reduction(&& : ok)
-        for (int64_t i = 0; i < nrows; ++i) {
-            ok = ok && h_rp[i + 1] >= h_rp[i];
-            for (schwz_idx j = h_rp[i]; j < h_rp[i + 1] && ok; ++j) ok = h_col[j] >= 0 && h_col[j] < ncols;
-        }
-        SCHWZ_REQUIRE(ok, "schwz_csr_create: row_ptr not monotone or column index out of range");
-    }
+    SCHWZ_REQUIRE(csr_is_well_formed(nrows, ncols, h_rp, h_col),
+                  "schwz_csr_create: row_ptr not monotone or column index out of range");
     // row tiles: consecutive rows, <= kTileRows rows and <= kTileNnz nonzeros; a
     // row longer than kTileNnz forms a tile of its own.
     std::vector<schwz_idx> tiles;

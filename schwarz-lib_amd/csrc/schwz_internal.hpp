@@ -181,6 +181,8 @@ int build_spmv_pair(schwz_csr *A, const schwz_idx *h_rp, const schwz_idx *h_col,
 void free_spmv_pair(schwz_csr *A);
 int pair_set_dual_split(schwz_csr *A, const schwz_idx *h_rp, const schwz_idx *h_col, int64_t split);
 // marks the tiles whose rows or columns reach index >= split (see CsrView::tile_dual)
+// host_setup.cpp (OpenMP): row_ptr monotone and every column in [0, ncols)
+bool csr_is_well_formed(int64_t nrows, int64_t ncols, const schwz_idx *rp, const schwz_idx *col);
 int csr_set_dual_split(schwz_csr *A, const schwz_idx *h_rp, const schwz_idx *h_col, int64_t split);
 }  // namespace schwz
 
