@@ -137,6 +137,8 @@ int schwz_gmres_create(const schwz_csr *A, int precond, int block_size, int rest
 void schwz_gmres_destroy(schwz_gmres *s);
 int schwz_gmres_solve(schwz_gmres *s, const double *d_b, double *d_x, double rtol, int max_iters,
                       int *h_iters, double *h_resnorm, schwz_stream stream);
+/* iterations and residual norm of the last solve (device synchronisation) */
+int schwz_gmres_last_stats(schwz_gmres *s, int *h_iters, double *h_resnorm);
 
 /* Profiling hooks for bench.py's roofline leg: between begin and end, every
  * launch of the dominant kernel (the CSR SpMV inside schwz_pcg_solve) is
@@ -340,6 +342,9 @@ int schwz_ras_local_solve(schwz_subdomain *sd, int *h_inner_iters, schwz_stream 
  * iteration cap once iter_count > settings.reset_local_crit_iter (source/solve.cpp:723-742);
  * max_iters = -1 means local_size_x.  Takes effect from the next local solve. */
 int schwz_ras_set_local_max_iters(schwz_subdomain *sd, int max_iters);
+/* settings.enable_logging (source/solve.cpp:751-771): inner iterations and final residual norm of the
+ * last local solve (0 and 0.0 for the direct path).  Synchronises the solver's stream. */
+int schwz_ras_last_inner_stats(schwz_subdomain *sd, int *h_iters, double *h_resnorm);
 /* steps 2+3 in one enqueue: the check residual of step 2 and the start residual of
  * the CG solve of step 3 come out of ONE pass over A_loc (two gathers per entry,
  * one matrix read), the norm's device->host copy is queued right behind it and

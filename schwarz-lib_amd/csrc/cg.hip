@@ -632,6 +632,15 @@ int precond_apply(schwz_pcg *s, const double *in, double *out, hipStream_t st)
 
 static int pcg_apply_general(schwz_pcg *s, hipStream_t st) { return precond_apply(s, s->r, s->z, st); }
 
+int pcg_last_stats(schwz_pcg *s, int *h_iters, double *h_resnorm)
+{
+    SCHWZ_HIP_TRY(hipDeviceSynchronize());
+    SCHWZ_HIP_TRY(hipMemcpy(&s->h_state[0], s->state, sizeof(CgState), hipMemcpyDeviceToHost));
+    *h_iters = s->h_state[0].iters;
+    *h_resnorm = sqrt(s->h_state[0].rr);
+    return SCHWZ_OK;
+}
+
 static bool pcg_is_general(const schwz_pcg *s)
 {
     return s->precond == SCHWZ_PRECOND_BLOCK_JACOBI || s->precond == SCHWZ_PRECOND_ILU ||

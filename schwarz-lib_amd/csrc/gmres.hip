@@ -256,6 +256,16 @@ void schwz_gmres_destroy(schwz_gmres *s)
     delete s;
 }
 
+int schwz_gmres_last_stats(schwz_gmres *s, int *h_iters, double *h_resnorm)
+{
+    SCHWZ_REQUIRE(s && h_iters && h_resnorm, "schwz_gmres_last_stats: null argument");
+    SCHWZ_HIP_TRY(hipDeviceSynchronize());
+    SCHWZ_HIP_TRY(hipMemcpy(&s->h_state[0], s->state, sizeof(GmresState), hipMemcpyDeviceToHost));
+    *h_iters = s->h_state[0].iters;
+    *h_resnorm = s->h_state[0].resn;
+    return SCHWZ_OK;
+}
+
 int schwz_gmres_solve(schwz_gmres *s, const double *d_b, double *d_x, double rtol, int max_iters, int *h_iters,
                       double *h_resnorm, schwz_stream stream)
 {

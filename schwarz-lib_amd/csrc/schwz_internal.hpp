@@ -192,6 +192,7 @@ int pcg_begin(schwz_pcg *s, const double *d_b, double *d_x, double rtol, bool fu
               int64_t row_limit, hipStream_t st);
 int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream_t st);
 int precond_apply(schwz_pcg *s, const double *in, double *out, hipStream_t st);
+int pcg_last_stats(schwz_pcg *s, int *h_iters, double *h_resnorm);  // device sync + state copy
 }  // namespace schwz
 
 // ---- opaque ABI types -------------------------------------------------------

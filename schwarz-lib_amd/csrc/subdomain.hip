@@ -252,6 +252,18 @@ int schwz_ras_set_local_max_iters(schwz_subdomain *sd, int max_iters)
     return SCHWZ_OK;
 }
 
+int schwz_ras_last_inner_stats(schwz_subdomain *sd, int *h_iters, double *h_resnorm)
+{
+    REQUIRE_DEVICE(sd, "schwz_ras_last_inner_stats");
+    SCHWZ_REQUIRE(h_iters && h_resnorm, "schwz_ras_last_inner_stats: null output");
+    *h_iters = 0;
+    *h_resnorm = 0.0;
+    if (sd->local_size_x == 0) return SCHWZ_OK;
+    if (sd->cg) return pcg_last_stats(sd->cg, h_iters, h_resnorm);
+    if (sd->gmres) return schwz_gmres_last_stats(sd->gmres, h_iters, h_resnorm);
+    return SCHWZ_OK;
+}
+
 int schwz_ras_local_solve(schwz_subdomain *sd, int *h_inner_iters, schwz_stream stream)
 {
     REQUIRE_DEVICE(sd, "schwz_ras_local_solve");

@@ -612,7 +612,7 @@ void SchwarzBase<V, I, M>::run(std::shared_ptr<gko::matrix::Dense<V>> &solution)
         if (std::isnan(local_res)) std::exit(-1);  // solve.cpp:982-984
         ppd.local_residual_vector_out.push_back(local_res);
         ppd.local_converged_resnorm.push_back(local_res / local_res0);
-        ppd.local_converged_iter_count.push_back(0);  // inner counts need enable_logging (solve.cpp:751-775)
+        // inner counts need enable_logging (solve.cpp:751-775); recorded after the solve below
         ppd.local_timestamp.push_back((V)(MPI_Wtime() - m.init_mpi_wtime));
         m.current_residual_norm = local_res;
         m.min_residual_norm = it == 0 ? local_res : std::min(local_res, m.min_residual_norm);
@@ -648,6 +648,14 @@ void SchwarzBase<V, I, M>::run(std::shared_ptr<gko::matrix::Dense<V>> &solution)
         timings[2].push_back((V)(t3 - t2));
         if (num_converged == P) break;
         const double t4 = now();  // the solve was enqueued with the check
+        if (s.enable_logging) {  // solve.cpp:751-771 (costs a device synchronisation per iteration)
+            int inner = 0;
+            double inner_res = 0.0;
+            SCHWZ_CALL(schwz_ras_last_inner_stats(im.sd, &inner, &inner_res));
+            ppd.local_converged_iter_count.push_back((V)inner);
+        } else {
+            ppd.local_converged_iter_count.push_back(0);
+        }
         SCHWZ_CALL(schwz_ras_restrict(im.sd, im.stream));
         const double t5 = now();
         timings[3].push_back((V)(t4 - t3));
@@ -670,7 +678,8 @@ void SchwarzBase<V, I, M>::run(std::shared_ptr<gko::matrix::Dense<V>> &solution)
         std::ofstream file(name);
         file << "iter,resnorm,localiter,localresnorm,timestamp\n";
         for (size_t i = 0; i < ppd.local_residual_vector_out.size(); ++i)
-            file << i << "," << ppd.local_residual_vector_out[i] << "," << ppd.local_converged_iter_count[i] << ","
+            file << i << "," << ppd.local_residual_vector_out[i] << ","
+                 << (i < ppd.local_converged_iter_count.size() ? ppd.local_converged_iter_count[i] : (V)0) << ","
                  << ppd.local_converged_resnorm[i] << "," << ppd.local_timestamp[i] << "\n";
     }
     if (!converged) {

@@ -30,7 +30,7 @@ SYMBOLS = [
     "schwz_gather", "schwz_scatter",
     "schwz_csr_create", "schwz_csr_destroy", "schwz_csr_nnz", "schwz_csr_format", "schwz_csr_spmv",
     "schwz_pcg_create", "schwz_pcg_create_ex", "schwz_pcg_destroy", "schwz_pcg_solve",
-    "schwz_gmres_create", "schwz_gmres_destroy", "schwz_gmres_solve",
+    "schwz_gmres_create", "schwz_gmres_destroy", "schwz_gmres_solve", "schwz_gmres_last_stats",
     "schwz_profile_begin", "schwz_profile_end", "schwz_profile_kind", "schwz_stream_probe",
     "schwz_trs_create", "schwz_trs_destroy", "schwz_trs_solve",
     "schwz_problem_laplacian", "schwz_problem_from_csr", "schwz_problem_from_matrix_market",
@@ -47,6 +47,7 @@ SYMBOLS = [
     "schwz_ras_unpack_f32",
     "schwz_ras_update_boundary", "schwz_ras_local_residual", "schwz_ras_local_residual_launch",
     "schwz_ras_local_residual_wait", "schwz_ras_local_solve", "schwz_ras_set_local_max_iters",
+    "schwz_ras_last_inner_stats",
     "schwz_ras_check_and_solve_launch",
     "schwz_ras_restrict", "schwz_ras_vector", "schwz_ras_local_csr", "schwz_ras_get_interior",
     "schwz_ras_true_residual_sq", "schwz_ras_algorithmic_bytes",
@@ -112,6 +113,7 @@ _sig("schwz_pcg_create_ex", i32, [vp, i32, i32, pvp])
 _sig("schwz_pcg_destroy", None, [vp])
 _sig("schwz_gmres_create", i32, [vp, i32, i32, i32, pvp])
 _sig("schwz_gmres_destroy", None, [vp])
+_sig("schwz_gmres_last_stats", i32, [vp, C.POINTER(C.c_int), C.POINTER(dbl)])
 _sig("schwz_gmres_solve", i32, [vp, vp, vp, dbl, i32, C.POINTER(C.c_int), C.POINTER(dbl), vp])
 _sig("schwz_pcg_solve", i32, [vp, vp, vp, dbl, i32, C.POINTER(C.c_int), C.POINTER(dbl), vp])
 _sig("schwz_profile_begin", i32, [i32])
@@ -160,6 +162,7 @@ _sig("schwz_ras_local_residual_wait", i32, [vp, C.POINTER(dbl)])
 _sig("schwz_ras_check_and_solve_launch", i32, [vp, vp])
 _sig("schwz_ras_local_solve", i32, [vp, C.POINTER(C.c_int), vp])
 _sig("schwz_ras_set_local_max_iters", i32, [vp, i32])
+_sig("schwz_ras_last_inner_stats", i32, [vp, C.POINTER(C.c_int), C.POINTER(dbl)])
 _sig("schwz_ras_restrict", i32, [vp, vp])
 _sig("schwz_ras_vector", i32, [vp, i32, pvp, C.POINTER(i64)])
 _sig("schwz_ras_local_csr", i32, [vp, pvp])

@@ -442,6 +442,13 @@ class Subdomain:
         check(lib.schwz_ras_local_residual_wait(self.h, C.byref(out)))
         return out.value
 
+    def last_inner_stats(self):
+        """(inner iterations, final residual norm) of the last local solve -- settings.enable_logging
+        (solve.cpp:751-771); synchronises the device."""
+        it, rn = C.c_int(0), C.c_double(0.0)
+        check(lib.schwz_ras_last_inner_stats(self.h, C.byref(it), C.byref(rn)))
+        return it.value, rn.value
+
     def set_local_max_iters(self, max_iters):
         """Inner iteration cap of later local solves (two-stage criterion, solve.cpp:723-742)."""
         check(lib.schwz_ras_set_local_max_iters(self.h, int(max_iters)))

@@ -343,6 +343,19 @@ class SolverRAS:
             self._print(" Local direct solve with HIP TRS")
 
     # -------------------------------------------------------------------- run
+    def _log_local_solve(self, locals_):
+        """settings.enable_logging (solve.cpp:751-771): inner iteration count, final inner residual
+        norm and a timestamp per outer iteration.  Reads the solver state, i.e. synchronises."""
+        if not self.settings.enable_logging:
+            return
+        ppd = self.metadata.post_process_data
+        for _, sd in locals_:
+            if hasattr(sd, "last_inner_stats"):
+                it, rn = sd.last_inner_stats()
+                ppd["local_converged_iter_count"].append(it)
+                ppd["local_converged_resnorm"].append(rn)
+                ppd["local_timestamp"].append(time.perf_counter() - self._t_begin)
+
     def _two_stage(self):
         """solve.cpp:723-742: once iter_count > reset_local_crit_iter the local stopping
         criterion is rebuilt with updated_max_iters (-1: local_size_x) as its iteration cap."""
@@ -389,6 +402,7 @@ class SolverRAS:
         self._mask = {me: 0 for me in self.subdomains}
         self._stop = {me: NEVER for me in self.subdomains}
         self._pending = None
+        self._t_begin = time.perf_counter()
         if getattr(self, "_two_stage_on", False):  # a re-run starts with the first-stage cap again
             for _, sd in self.subdomains.items():
                 sd.set_local_max_iters(m.local_max_iters)
@@ -476,6 +490,7 @@ class SolverRAS:
         if not fused:
             for _, sd in locals_:
                 sd.local_solve(stream)
+        self._log_local_solve(locals_)
         t4 = time.perf_counter()
         for _, sd in locals_:
             sd.restrict(stream)
@@ -570,6 +585,7 @@ class SolverRAS:
         if not (tol >= 0.0 and spec):
             for _, sd in locals_:
                 sd.local_solve(stream)
+        self._log_local_solve(locals_)
         t4 = time.perf_counter()
         # 4 restricted write-back
         for _, sd in locals_:

@@ -560,3 +560,23 @@ def test_torchdist_comm_on_the_nccl_backend_single_rank(schwz, oracle, torch_cud
                          oracle.make_settings(max_iters=50, tol=1e-8, precond=1))
     assert got["conv"] and got["iters"] == ref["iter_count"] and got["n"] == N
     assert abs(got["rel"] - ref["residual_norm"] / ref["rhs_norm"]) <= 1e-6 * got["rel"] + 1e-13
+
+
+def test_enable_logging_records_inner_iterations(schwz, oracle, torch_cuda):
+    """settings.enable_logging (solve.cpp:751-771): inner iteration count and final inner residual
+    of every local solve, here against the oracle's inner iteration history."""
+    n, P = 20, 2
+    solver, m, out = _run_gpu(
+        schwz, P, dict(enable_logging=True),
+        dict(oned_laplacian_size=n, tolerance=1e-7, max_iters=200, local_precond="block-jacobi",
+             precond_max_block_size=1, local_solver_tolerance=1e-9))
+    rp, col, val = oracle.laplacian2d(n)
+    N = n * n
+    ref = oracle.ras_run(rp, col, val, np.ones(N), P, oracle.first_rows_regular(N, P),
+                         _oracle_settings(oracle, m, solver.settings))
+    assert out["iter_count"] == ref["iter_count"]
+    got = np.array(m.post_process_data["local_converged_iter_count"]).reshape(-1, P)
+    exp = ref["hist_inner"].reshape(-1, P)[:got.shape[0]]
+    assert got.shape[0] == out["iter_count"] and np.abs(got - exp).max() <= 1
+    assert len(m.post_process_data["local_timestamp"]) == got.size
+    assert all(r > 0 for r in m.post_process_data["local_converged_resnorm"])
