@@ -162,3 +162,18 @@ def test_bench_ras_overlapped_onesided_matches_oracle(oracle, nranks):
     assert ref["converged"] and iters == [ref["iter_count"]], out
     rel = float(re.search(r"relative residual norm of solution ([0-9.eE+-]+)", out).group(1))
     assert abs(rel - ref["residual_norm"] / ref["rhs_norm"]) <= 1e-6 * rel + 1e-12
+
+
+def test_bench_ras_reference_smoke_command(oracle):
+    """The reference's own smoke run (schwarz.org:21): `mpirun -n 4 ./benchmarking/bench_ras
+    --explicit_laplacian --enable_global_check`, every other flag at the driver's default
+    (16 x 16 grid, 100 iterations cap, tolerance 1e-6, CG without preconditioner to 1e-12)."""
+    out = _run(4, "--explicit_laplacian", "--enable_global_check")
+    iters = sorted(set(int(x) for x in re.findall(r"converged in (\d+) iterations", out)))
+    rp, col, val = oracle.laplacian2d(16)
+    ref = oracle.ras_run(rp, col, val, np.ones(256), 4, oracle.first_rows_regular(256, 4),
+                         oracle.make_settings(max_iters=100, tol=1e-6))
+    if ref["converged"]:
+        assert iters == [ref["iter_count"]], out
+    else:
+        assert "did not converge in 100 iterations" in out
