@@ -177,3 +177,23 @@ def test_bench_ras_reference_smoke_command(oracle):
         assert iters == [ref["iter_count"]], out
     else:
         assert "did not converge in 100 iterations" in out
+
+
+def test_bench_ras_authors_iterative_study_settings(oracle):
+    """The flag family of the authors' iterative-local-solve study (my_scripts/run_script:21-54):
+    inexact local CG (local_tol 0.1, <= 70 iterations), block-Jacobi with the driver's default block
+    size 16, overlap 8, one-sided with the decentralized convergence type, 100 outer iterations."""
+    n, P = 48, 4
+    out = _run(P, "--explicit_laplacian", "--set_1d_laplacian_size=%d" % n, "--num_iters=100", "--set_tol=1e-8",
+               "--local_tol=0.1", "--local_max_iters=70", "--restart_iter=40", "--overlap=8",
+               "--local_precond=block-jacobi", "--enable_onesided", "--global_convergence_type=decentralized")
+    rp, col, val = oracle.laplacian2d(n)
+    N = n * n
+    ref = oracle.ras_run(rp, col, val, np.ones(N), P, oracle.first_rows_regular(N, P),
+                         oracle.make_settings(max_iters=100, tol=1e-8, overlap=8, precond=2, precond_block_size=16,
+                                              local_tol=0.1, local_max_iters=70, enable_onesided=1))
+    if ref["converged"]:
+        iters = sorted(set(int(x) for x in re.findall(r"converged in (\d+) iterations", out)))
+        assert len(iters) == 1 and abs(iters[0] - ref["iter_count"]) <= 1, out
+    else:
+        assert out.count("did not converge in 100 iterations") == P, out
