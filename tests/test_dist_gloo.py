@@ -99,6 +99,15 @@ CASES = {
         metadata=dict(oned_laplacian_size=18, tolerance=1e-8, max_iters=300, local_precond="block-jacobi",
                       precond_max_block_size=1, local_solver_tolerance=1e-10, local_max_iters=2,
                       updated_max_iters=40)),
+    # eight ranks, the rank count of the multi-GPU benchmark: slab partition, two neighbours each
+    "lap3d_eight_slabs": dict(
+        world=8, settings=dict(laplacian_dim=3, laplacian_shape=(6, 5, 32)),
+        metadata=dict(tolerance=1e-6, max_iters=400, local_precond="block-jacobi",
+                      precond_max_block_size=1, local_solver_tolerance=0.0, local_max_iters=6)),
+    "lap3d_eight_slabs_overlapped": dict(
+        world=8, settings=dict(laplacian_dim=3, laplacian_shape=(5, 4, 32)), onesided=True, overlap=True,
+        metadata=dict(tolerance=1e-5, max_iters=600, local_precond="block-jacobi",
+                      precond_max_block_size=1, local_solver_tolerance=0.0, local_max_iters=5)),
     "lap2d_direct_overlap3": dict(
         world=2, settings=dict(local_solver="direct-ginkgo", overlap=3),
         metadata=dict(oned_laplacian_size=16, tolerance=1e-9, max_iters=300)),
