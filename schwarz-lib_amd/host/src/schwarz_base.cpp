@@ -21,6 +21,7 @@
 #include <iostream>
 #include <numeric>
 #include <sstream>
+#include <type_traits>
 
 #include <restricted_schwarz.hpp>
 
@@ -82,6 +83,22 @@ struct SchwarzBase<ValueType, IndexType, MixedValueType>::Impl {
     std::vector<int64_t> recv_off, send_off;
     double *d_send = nullptr, *d_recv = nullptr;
     double *h_send = nullptr, *h_recv = nullptr;  // pinned staging
+    // wire format of the halos: fp32 with settings.use_mixed_precision and MixedValueType = float
+    // (restricted_schwarz.cpp:898-903, 929-933, 952-954), fp64 otherwise.  The buffers above are
+    // sized for fp64 either way; offsets into them are counted in wire elements.
+    bool f32_wire = false;
+    size_t wire_size() const { return f32_wire ? sizeof(float) : sizeof(double); }
+    void *wire(double *base, int64_t off) const { return (char *)base + (size_t)off * wire_size(); }
+    ncclDataType_t nccl_type() const { return f32_wire ? ncclFloat : ncclDouble; }
+    MPI_Datatype mpi_type() const { return f32_wire ? MPI_FLOAT : MPI_DOUBLE; }
+    int pack(hipStream_t on)
+    {
+        return f32_wire ? schwz_ras_pack_f32(sd, (float *)d_send, on) : schwz_ras_pack(sd, d_send, on);
+    }
+    int unpack(hipStream_t on)
+    {
+        return f32_wire ? schwz_ras_unpack_f32(sd, (const float *)d_recv, on) : schwz_ras_unpack(sd, d_recv, on);
+    }
     hipStream_t stream = nullptr;
     int device = 0;
     double rhs_sq_interior = 0.0;
@@ -315,6 +332,7 @@ void SchwarzBase<V, I, M>::initialize()
     for (size_t i = 0; i < rhs.size(); ++i) local_rhs->at(i) = (V)rhs[i];
     SCHWZ_CALL(schwz_subdomain_to_device(im.sd, rhs.data(), &opt));
 
+    im.f32_wire = s.use_mixed_precision && std::is_same<M, float>::value;
     const size_t nsend = (size_t)std::max<int64_t>(im.sizes[9], 1), nrecv = (size_t)std::max<int64_t>(im.sizes[8], 1);
     HIP_CALL(hipMalloc((void **)&im.d_send, nsend * sizeof(double)));
     HIP_CALL(hipMalloc((void **)&im.d_recv, nrecv * sizeof(double)));
@@ -401,38 +419,38 @@ void SchwarzBase<V, I, M>::run(std::shared_ptr<gko::matrix::Dense<V>> &solution)
 
     // halo exchange: RCCL send/recv on the compute stream, or staged through pinned host memory
     auto exchange = [&]() {
-        SCHWZ_CALL(schwz_ras_pack(im.sd, im.d_send, im.stream));
+        SCHWZ_CALL(im.pack(im.stream));
         if (im.nccl) {
             // one group = one fused launch; the stream orders it after the pack and before the
             // unpack, so the receive is complete before it is scattered (F8) without a host sync
             NCCL_CALL(ncclGroupStart());
             for (int k = 0; k < n_in; ++k)
-                NCCL_CALL(ncclRecv(im.d_recv + im.recv_off[(size_t)k],
-                                   (size_t)(im.recv_off[(size_t)k + 1] - im.recv_off[(size_t)k]), ncclDouble,
+                NCCL_CALL(ncclRecv(im.wire(im.d_recv, im.recv_off[(size_t)k]),
+                                   (size_t)(im.recv_off[(size_t)k + 1] - im.recv_off[(size_t)k]), im.nccl_type(),
                                    im.nbr_in[(size_t)k], im.nccl, im.stream));
             for (int k = 0; k < n_out; ++k)
-                NCCL_CALL(ncclSend(im.d_send + im.send_off[(size_t)k],
-                                   (size_t)(im.send_off[(size_t)k + 1] - im.send_off[(size_t)k]), ncclDouble,
+                NCCL_CALL(ncclSend(im.wire(im.d_send, im.send_off[(size_t)k]),
+                                   (size_t)(im.send_off[(size_t)k + 1] - im.send_off[(size_t)k]), im.nccl_type(),
                                    im.nbr_out[(size_t)k], im.nccl, im.stream));
             NCCL_CALL(ncclGroupEnd());
-            SCHWZ_CALL(schwz_ras_unpack(im.sd, im.d_recv, im.stream));
+            SCHWZ_CALL(im.unpack(im.stream));
             return;
         }
         if (im.sizes[9] > 0) {
-            HIP_CALL(hipMemcpyAsync(im.h_send, im.d_send, (size_t)im.sizes[9] * sizeof(double), hipMemcpyDeviceToHost, im.stream));
+            HIP_CALL(hipMemcpyAsync(im.h_send, im.d_send, (size_t)im.sizes[9] * im.wire_size(), hipMemcpyDeviceToHost, im.stream));
             HIP_CALL(hipStreamSynchronize(im.stream));
         }
         int r = 0;
         for (int k = 0; k < n_in; ++k)
-            MPI_Irecv(im.h_recv + im.recv_off[(size_t)k], (int)(im.recv_off[(size_t)k + 1] - im.recv_off[(size_t)k]),
-                      MPI_DOUBLE, im.nbr_in[(size_t)k], 0, MPI_COMM_WORLD, &reqs[(size_t)r++]);
+            MPI_Irecv(im.wire(im.h_recv, im.recv_off[(size_t)k]), (int)(im.recv_off[(size_t)k + 1] - im.recv_off[(size_t)k]),
+                      im.mpi_type(), im.nbr_in[(size_t)k], 0, MPI_COMM_WORLD, &reqs[(size_t)r++]);
         for (int k = 0; k < n_out; ++k)
-            MPI_Isend(im.h_send + im.send_off[(size_t)k], (int)(im.send_off[(size_t)k + 1] - im.send_off[(size_t)k]),
-                      MPI_DOUBLE, im.nbr_out[(size_t)k], 0, MPI_COMM_WORLD, &reqs[(size_t)r++]);
+            MPI_Isend(im.wire(im.h_send, im.send_off[(size_t)k]), (int)(im.send_off[(size_t)k + 1] - im.send_off[(size_t)k]),
+                      im.mpi_type(), im.nbr_out[(size_t)k], 0, MPI_COMM_WORLD, &reqs[(size_t)r++]);
         MPI_Waitall(r, reqs.data(), MPI_STATUSES_IGNORE);  // receives complete before the scatter (F8)
         if (im.sizes[8] > 0)
-            HIP_CALL(hipMemcpyAsync(im.d_recv, im.h_recv, (size_t)im.sizes[8] * sizeof(double), hipMemcpyHostToDevice, im.stream));
-        SCHWZ_CALL(schwz_ras_unpack(im.sd, im.d_recv, im.stream));
+            HIP_CALL(hipMemcpyAsync(im.d_recv, im.h_recv, (size_t)im.sizes[8] * im.wire_size(), hipMemcpyHostToDevice, im.stream));
+        SCHWZ_CALL(im.unpack(im.stream));
     };
 
     std::vector<std::vector<V>> timings(5);
@@ -487,10 +505,10 @@ void SchwarzBase<V, I, M>::run(std::shared_ptr<gko::matrix::Dense<V>> &solution)
                 } else {
                     MPI_Waitall(nreq_halo, reqs.data(), MPI_STATUSES_IGNORE);
                     if (im.sizes[8] > 0)
-                        HIP_CALL(hipMemcpyAsync(im.d_recv, im.h_recv, (size_t)im.sizes[8] * sizeof(double),
+                        HIP_CALL(hipMemcpyAsync(im.d_recv, im.h_recv, (size_t)im.sizes[8] * im.wire_size(),
                                                 hipMemcpyHostToDevice, im.stream));
                 }
-                SCHWZ_CALL(schwz_ras_unpack(im.sd, im.d_recv, im.stream));
+                SCHWZ_CALL(im.unpack(im.stream));
                 MPI_Waitall(nreq_flag, freqs.data(), MPI_STATUSES_IGNORE);
                 for (int k = 0; k < n_in; ++k) {
                     mask |= (unsigned long long)flag_in[(size_t)(2 * k)];
@@ -501,35 +519,35 @@ void SchwarzBase<V, I, M>::run(std::shared_ptr<gko::matrix::Dense<V>> &solution)
             const bool last = it == (long long)m.max_iters - 1 || stop == it;
             // (b) post this iteration's halos: x~ after the previous restriction
             if (!last) {
-                SCHWZ_CALL(schwz_ras_pack(im.sd, im.d_send, im.stream));
+                SCHWZ_CALL(im.pack(im.stream));
                 if (im.nccl) {
                     HIP_CALL(hipEventRecord(im.ev_packed, im.stream));
                     HIP_CALL(hipStreamWaitEvent(im.side, im.ev_packed, 0));
                     NCCL_CALL(ncclGroupStart());
                     for (int k = 0; k < n_in; ++k)
-                        NCCL_CALL(ncclRecv(im.d_recv + im.recv_off[(size_t)k],
-                                           (size_t)(im.recv_off[(size_t)k + 1] - im.recv_off[(size_t)k]), ncclDouble,
+                        NCCL_CALL(ncclRecv(im.wire(im.d_recv, im.recv_off[(size_t)k]),
+                                           (size_t)(im.recv_off[(size_t)k + 1] - im.recv_off[(size_t)k]), im.nccl_type(),
                                            im.nbr_in[(size_t)k], im.nccl, im.side));
                     for (int k = 0; k < n_out; ++k)
-                        NCCL_CALL(ncclSend(im.d_send + im.send_off[(size_t)k],
-                                           (size_t)(im.send_off[(size_t)k + 1] - im.send_off[(size_t)k]), ncclDouble,
+                        NCCL_CALL(ncclSend(im.wire(im.d_send, im.send_off[(size_t)k]),
+                                           (size_t)(im.send_off[(size_t)k + 1] - im.send_off[(size_t)k]), im.nccl_type(),
                                            im.nbr_out[(size_t)k], im.nccl, im.side));
                     NCCL_CALL(ncclGroupEnd());
                     HIP_CALL(hipEventRecord(im.ev_arrived, im.side));
                 } else {
                     if (im.sizes[9] > 0) {
-                        HIP_CALL(hipMemcpyAsync(im.h_send, im.d_send, (size_t)im.sizes[9] * sizeof(double),
+                        HIP_CALL(hipMemcpyAsync(im.h_send, im.d_send, (size_t)im.sizes[9] * im.wire_size(),
                                                 hipMemcpyDeviceToHost, im.stream));
                         HIP_CALL(hipStreamSynchronize(im.stream));
                     }
                     nreq_halo = 0;
                     for (int k = 0; k < n_in; ++k)
-                        MPI_Irecv(im.h_recv + im.recv_off[(size_t)k],
-                                  (int)(im.recv_off[(size_t)k + 1] - im.recv_off[(size_t)k]), MPI_DOUBLE,
+                        MPI_Irecv(im.wire(im.h_recv, im.recv_off[(size_t)k]),
+                                  (int)(im.recv_off[(size_t)k + 1] - im.recv_off[(size_t)k]), im.mpi_type(),
                                   im.nbr_in[(size_t)k], 0, MPI_COMM_WORLD, &reqs[(size_t)nreq_halo++]);
                     for (int k = 0; k < n_out; ++k)
-                        MPI_Isend(im.h_send + im.send_off[(size_t)k],
-                                  (int)(im.send_off[(size_t)k + 1] - im.send_off[(size_t)k]), MPI_DOUBLE,
+                        MPI_Isend(im.wire(im.h_send, im.send_off[(size_t)k]),
+                                  (int)(im.send_off[(size_t)k + 1] - im.send_off[(size_t)k]), im.mpi_type(),
                                   im.nbr_out[(size_t)k], 0, MPI_COMM_WORLD, &reqs[(size_t)nreq_halo++]);
                 }
             }

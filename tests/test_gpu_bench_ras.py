@@ -197,3 +197,61 @@ def test_bench_ras_authors_iterative_study_settings(oracle):
         assert len(iters) == 1 and abs(iters[0] - ref["iter_count"]) <= 1, out
     else:
         assert out.count("did not converge in 100 iterations") == P, out
+
+
+TYPES_BIN = os.path.join(ROOT, "schwarz-lib_amd", "build", "ras_types_driver")
+
+
+def _run_types(nranks, types, n, mixed, overlapped, tol, max_iters, env=None):
+    """tests/drivers/ras_types_driver.cpp: the mirror's other template instantiations."""
+    if not os.path.exists(TYPES_BIN):
+        pytest.skip("ras_types_driver not built (`make -C schwarz-lib_amd types_driver`, needs MPI)")
+    if not os.path.exists(MPIEXEC):
+        pytest.skip("no mpiexec on this machine")
+    cmd = [MPIEXEC, "-n", str(nranks), TYPES_BIN, types, str(n), str(int(mixed)), str(int(overlapped)),
+           repr(tol), str(max_iters)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, **(env or {})))
+    assert p.returncode == 0, p.stdout + p.stderr
+    res = re.search(r"RESULT iters=(\d+) solnorm=([0-9.eE+-]+)", p.stdout)
+    assert res, p.stdout
+    return int(res.group(1)), float(res.group(2)), p.stdout
+
+
+@pytest.mark.parametrize("overlapped", [False, True])
+def test_mirror_mixed_precision_halos(oracle, overlapped):
+    """SolverRAS<double, int32, float> with settings.use_mixed_precision: the packed halos cross
+    the wire as fp32 (restricted_schwarz.cpp:898-903, 929-933, 952-954), over MPI staging here
+    (ranks share the GPU).  The oracle rounds the same values the same way."""
+    n, P = 24, 3
+    rp, col, val = oracle.laplacian2d(n)
+    N = n * n
+    extra = dict(enable_onesided=1, enable_overlap=1) if overlapped else {}
+    ref = oracle.ras_run(rp, col, val, np.ones(N), P, oracle.first_rows_regular(N, P),
+                         oracle.make_settings(max_iters=400, tol=1e-4, use_mixed_precision=1, **extra))
+    plain = oracle.ras_run(rp, col, val, np.ones(N), P, oracle.first_rows_regular(N, P),
+                           oracle.make_settings(max_iters=400, tol=1e-4, **extra))
+    it, norm, out = _run_types(P, "d32f", n, True, overlapped, 1e-4, 400)
+    assert ref["converged"] and it == ref["iter_count"], out
+    ref_norm = float(np.linalg.norm(ref["solution"]))
+    assert abs(norm - ref_norm) <= 1e-10 * ref_norm
+    # the fp32 rounding is visible: the fp64-halo answer differs from both
+    assert abs(float(np.linalg.norm(plain["solution"])) - norm) > 1e-9 * ref_norm
+    # MixedValueType = float without the setting keeps fp64 halos (the reference's default)
+    it64, norm64, _ = _run_types(P, "d32f", n, False, overlapped, 1e-4, 400)
+    assert it64 == plain["iter_count"]
+    assert abs(norm64 - float(np.linalg.norm(plain["solution"]))) <= 1e-10 * ref_norm
+
+
+@pytest.mark.parametrize("types", ["d64d", "d64f"])
+def test_mirror_int64_index_instantiations(oracle, types):
+    """IndexType = int64 (settings.hpp:533-537): same iteration as the int32 instantiation."""
+    n, P = 20, 2
+    rp, col, val = oracle.laplacian2d(n)
+    N = n * n
+    mixed = types.endswith("f")
+    ref = oracle.ras_run(rp, col, val, np.ones(N), P, oracle.first_rows_regular(N, P),
+                         oracle.make_settings(max_iters=400, tol=1e-4, use_mixed_precision=int(mixed)))
+    it, norm, out = _run_types(P, types, n, mixed, False, 1e-4, 400)
+    assert ref["converged"] and it == ref["iter_count"], out
+    ref_norm = float(np.linalg.norm(ref["solution"]))
+    assert abs(norm - ref_norm) <= 1e-10 * ref_norm
