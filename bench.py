@@ -220,6 +220,12 @@ def main():
         dom_launches = upd_launches.value
         spmv_name = "spmv_pair_kernel<kSpmvDotOnly> (partial sums of p.(A p), nothing stored; row-pair coded CSR)"
         spmv_tag = "spmv_pair_kernel<5,"
+        if (int(schwz.capi.lib.schwz_csr_symmetric(sd_csr(sd, schwz))) and
+                os.environ.get("SCHWZ_CG_SYM", "1")[:1] != "0"):
+            # the upload found the matrix symmetric: p.(A p) from the upper triangle
+            spmv_name = ("spmv_pair_kernel<kSpmvDotSym> (partial sums of p.(A p) from the upper triangle of the "
+                         "symmetric row-pair coded matrix, nothing stored)")
+            spmv_tag = "spmv_pair_kernel<7,"
     else:
         kernel_name, dom_tag, alg_dom, avg_ms, dom_launches = spmv_name, spmv_tag, alg_spmv, spmv_avg_ms, launches.value
     achieved = alg_dom / (avg_ms * 1e-3) / 1e9 if dom_launches else 0.0

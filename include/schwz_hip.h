@@ -96,6 +96,11 @@ int64_t schwz_csr_nnz(const schwz_csr *A);
  * dictionary tiles, 2 = row-pattern tiles, 3 = row-PAIR pattern tiles (lossless re-encodings
  * built at upload, csrc/spmv_dict.hip and csrc/spmv_pair.hip) */
 int schwz_csr_format(const schwz_csr *A);
+/* 1 when the upload found a row-pair coded matrix symmetric bit for bit and built the
+ * upper-triangle tables the CG iteration takes p.(A p) from (about half the gathers of that
+ * launch); such a matrix need not come from the reference's symmetric problems -- nothing is
+ * assumed, the check runs on every upload.  0 otherwise. */
+int schwz_csr_symmetric(const schwz_csr *A);
 
 /* y = alpha*A*x + beta*y : gko Csr::apply(alpha,x,beta,y), call sites
  * source/restricted_schwarz.cpp:1014-1015, source/solve.cpp:834-835,1079-1080.

@@ -709,6 +709,12 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
         return !(e && e[0] == '0');
     }();
     const bool qfree = qfree_on && !general && A.pair_id && s->variant == 0 && s->diag.mode != 2;
+    // p.(A p) from the upper triangle when the upload found the matrix symmetric (SCHWZ_CG_SYM=0: full rows)
+    static const bool sym_on = [] {
+        const char *e = std::getenv("SCHWZ_CG_SYM");
+        return !(e && e[0] == '0');
+    }();
+    const int dot_mode = !qfree ? kSpmvDot : (sym_on && A.pair_sym_base > 0 ? kSpmvDotSym : kSpmvDotOnly);
     // one CG iteration on stream `q`; `it` only enters through its parity (rho slot) and through
     // "it >= stop_iter", and stop_iter is 0 once the tolerance test has fired: a recorded sequence
     // of an even number of iterations can therefore be replayed as a hipGraph
@@ -721,7 +727,7 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
         a.it = it;
         const bool prof = instrument && g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
         if (prof) SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used], q));
-        int rc = launch_spmv(A, qfree ? kSpmvDotOnly : kSpmvDot, a, s->variant, q);
+        int rc = launch_spmv(A, dot_mode, a, s->variant, q);
         if (rc) return rc;
         if (prof) {
             SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used + 1], q));

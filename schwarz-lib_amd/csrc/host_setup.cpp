@@ -34,6 +34,34 @@ bool csr_is_well_formed(int64_t nrows, int64_t ncols, const schwz_idx *rp, const
     return ok;
 }
 
+// a_ij == a_ji bit for bit and the same sparsity either side of the diagonal.  Rows must have
+// strictly ascending columns (what the row-pair coding requires anyway).
+bool csr_is_symmetric(int64_t nrows, int64_t ncols, const schwz_idx *rp, const schwz_idx *col, const double *val)
+{
+    if (nrows != ncols) return false;
+    bool ok = true;
+    int64_t upper = 0, lower = 0;
+#pragma omp parallel for schedule(static) reduction(&& : ok) reduction(+ : upper, lower)
+    for (int64_t i = 0; i < nrows; ++i) {
+        if (!ok) continue;
+        for (schwz_idx j = rp[i]; j < rp[i + 1]; ++j) {
+            const int64_t c = col[j];
+            if (c < i) {
+                ++lower;
+            } else if (c > i) {
+                ++upper;
+                const schwz_idx *b = col + rp[c], *e = col + rp[c + 1];
+                const schwz_idx *f = std::lower_bound(b, e, (schwz_idx)i);
+                if (f == e || *f != (schwz_idx)i || std::memcmp(&val[f - col], &val[j], sizeof(double)) != 0) {
+                    ok = false;
+                    break;
+                }
+            }
+        }
+    }
+    return ok && upper == lower;
+}
+
 }  // namespace schwz
 
 using namespace schwz;

@@ -364,6 +364,8 @@ int schwz_csr_format(const schwz_csr *A)
     return !A ? 0 : (A->v.pair_id ? 3 : (A->v.pat_id ? 2 : (A->v.code ? 1 : 0)));
 }
 
+int schwz_csr_symmetric(const schwz_csr *A) { return A && A->v.pair_id && A->v.pair_sym_base > 0 ? 1 : 0; }
+
 int schwz_csr_spmv(const schwz_csr *A, double alpha, const double *d_x, double beta, double *d_y,
                    int variant, schwz_stream stream)
 {

@@ -85,6 +85,10 @@ struct CsrView {
     const uint8_t *ptbl_len = nullptr;
     const double *ptbl_val = nullptr;        // 2 per entry
     const schwz_idx *ptbl_meta = nullptr;    // 2 per entry: offset, flags
+    // symmetric matrices only: for table t, table pair_sym_base + t holds the entries with col >= row,
+    // the strictly upper ones doubled: x.(A x) = sum_i x_i (a_ii x_i + 2 sum_{j>i} a_ij x_j) with about
+    // half the gathers (kSpmvDotSym); 0 = not built
+    int pair_sym_base = 0;
 };
 
 // epilogues of the tiled SpMV kernel
@@ -101,7 +105,10 @@ enum SpmvMode {
     kSpmvDotOnly = 5,    // partial sum x_i*(A x)_i, nothing stored
     // alpha = rho / fold(p.q partials); per row q_i = (A p)_i recomputed, x_i += alpha p_i,
     // r_i -= alpha q_i, partials r.z and r.r (what cg_update_kernel does, minus 16 B/row of q)
-    kSpmvCgUpdate = 6
+    kSpmvCgUpdate = 6,
+    // kSpmvDotOnly for a matrix whose upload found it symmetric: the same number from the upper
+    // triangle alone (CsrView::pair_sym_base), about half the gathers
+    kSpmvDotSym = 7
 };
 
 struct SpmvArgs {
@@ -183,6 +190,8 @@ int pair_set_dual_split(schwz_csr *A, const schwz_idx *h_rp, const schwz_idx *h_
 // marks the tiles whose rows or columns reach index >= split (see CsrView::tile_dual)
 // host_setup.cpp (OpenMP): row_ptr monotone and every column in [0, ncols)
 bool csr_is_well_formed(int64_t nrows, int64_t ncols, const schwz_idx *rp, const schwz_idx *col);
+// host_setup.cpp (OpenMP): a_ij == a_ji bit for bit (rows with ascending columns)
+bool csr_is_symmetric(int64_t nrows, int64_t ncols, const schwz_idx *rp, const schwz_idx *col, const double *val);
 int csr_set_dual_split(schwz_csr *A, const schwz_idx *h_rp, const schwz_idx *h_col, int64_t split);
 }  // namespace schwz
 

@@ -33,7 +33,7 @@ constexpr int kPairPats = 64;      // patterns per table
 constexpr int kPairEntries = 512;  // staged entries per table (npat * stride)
 constexpr int kPairChunk = 8;      // gathers issued back to back per lane
 
-__host__ __device__ inline int pair_stride(int lmax) { return (lmax + kPairChunk - 1) / kPairChunk * kPairChunk; }
+__host__ __device__ inline int pair_stride(int lmax, int ch = kPairChunk) { return (lmax + ch - 1) / ch * ch; }
 
 struct __attribute__((aligned(16))) PairVal {
     double a, b;
@@ -62,9 +62,12 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
 #pragma clang fp contract(off)
     __shared__ PairVal pv[kPairEntries];
     __shared__ int poff[kPairEntries];             // col - row of the entry
-    __shared__ int pmask[kPairEntries / kPairChunk];  // per chunk: bit k = row r has entry k, bit 8+k = row r+1
-    __shared__ int plen[kPairPats];
-    if (MODE == kSpmvDot || MODE == kSpmvResidInit || MODE == kSpmvDotOnly) {
+    // gathers issued back to back per lane; the upper-triangle tables of kSpmvDotSym are about half as long
+    constexpr int CH = MODE == kSpmvDotSym ? kPairChunk / 2 : kPairChunk;
+    constexpr bool kDotOnly = MODE == kSpmvDotOnly || MODE == kSpmvDotSym;
+    __shared__ int pmask[kPairEntries / CH];  // per group of CH entries: bit k = row r has entry k, bit 8+k = row r+1
+    __shared__ int plen[kPairPats];            // length | (a gathered entry has col - row == 0) << 16
+    if (MODE == kSpmvDot || MODE == kSpmvResidInit || kDotOnly) {
         if (a.stop_iter && a.it >= *a.stop_iter) return;
     }
     __shared__ double red[4];
@@ -83,14 +86,15 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
     const int slots = ((nchunks + (kXcds << sh) - 1) >> (sh + 3)) << sh;  // sequence slots per XCD
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
     const bool dual = (MODE == kSpmvResidDual) && a.x2 != nullptr;
-    constexpr bool kWantOwn = MODE == kSpmvDot || MODE == kSpmvDotOnly || MODE == kSpmvCgUpdate;  // x[row] itself
+    constexpr bool kWantOwn = MODE == kSpmvDot || kDotOnly || MODE == kSpmvCgUpdate;  // x[row] itself
     int cached = -1, ls = 0, reach = 0;  // staged table, its row stride, its largest |col - row|
 
     auto stage_table = [&](int tb) {  // workgroup-uniform
-        const int eoff = A.ptbl_desc[5 * tb], loff = A.ptbl_desc[5 * tb + 1];
-        const int npat = A.ptbl_desc[5 * tb + 2], lmax = A.ptbl_desc[5 * tb + 3];
-        ls = pair_stride(lmax);
-        reach = A.ptbl_desc[5 * tb + 4];
+        const int td = MODE == kSpmvDotSym ? A.pair_sym_base + tb : tb;
+        const int eoff = A.ptbl_desc[5 * td], loff = A.ptbl_desc[5 * td + 1];
+        const int npat = A.ptbl_desc[5 * td + 2], lmax = A.ptbl_desc[5 * td + 3];
+        ls = pair_stride(lmax, CH);
+        reach = A.ptbl_desc[5 * td + 4];
         lds_barrier();  // everyone is done with the previous table
         for (int i = tid; i < npat * ls; i += kBlock) {
             const int pt = i / ls, k = i - pt * ls;
@@ -105,17 +109,24 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
             pv[i] = v;
             poff[i] = off;
         }
-        for (int i = tid; i < npat * ls / kPairChunk; i += kBlock) {
-            const int pt = i / (ls / kPairChunk), k0 = (i - pt * (ls / kPairChunk)) * kPairChunk;
+        for (int i = tid; i < npat * ls / CH; i += kBlock) {
+            const int pt = i / (ls / CH), k0 = (i - pt * (ls / CH)) * CH;
             int m = 0;
-            for (int k = 0; k < kPairChunk && k0 + k < lmax; ++k) {
+            for (int k = 0; k < CH && k0 + k < lmax; ++k) {
                 const int fl = A.ptbl_meta[2 * (eoff + pt * lmax + k0 + k) + 1];
                 m |= (fl & 1) << k;
                 m |= ((fl >> 1) & 1) << (kPairChunk + k);
             }
             pmask[i] = m;
         }
-        if (tid < npat) plen[tid] = A.ptbl_len[loff + tid];
+        lds_barrier();
+        if (tid < npat) {
+            // does a gather of this pattern (padding included) fetch x[r], x[r + 1] themselves?
+            const int len = A.ptbl_len[loff + tid];
+            int zero = 0;
+            for (int k = 0; k < pair_stride(len, CH); ++k) zero |= poff[tid * ls + k] == 0;
+            plen[tid] = len | (zero << 16);
+        }
         lds_barrier();
         cached = tb;
     };
@@ -135,26 +146,26 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
     // operand that exists on its own.
     auto accumulate = [&](const double *xv, int ra, int base, int len, bool safe, double &s0, double &s1,
                           pvd2 &own, bool want_own) {
-        for (int j = 0; j < len; j += kPairChunk) {
-            const int mask = pmask[(base + j) / kPairChunk];
-            pvd2 t[kPairChunk];
+        for (int j = 0; j < len; j += CH) {
+            const int mask = pmask[(base + j) / CH];
+            pvd2 t[CH];
             if (!safe) {
 #pragma unroll
-                for (int k = 0; k < kPairChunk; ++k) {
+                for (int k = 0; k < CH; ++k) {
                     const int off = poff[base + j + k];
                     t[k] = ld16(xv, ra + off);
                     if (want_own && off == 0) own = t[k];
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < kPairChunk; ++k) {
+                for (int k = 0; k < CH; ++k) {
                     const int c = ra + poff[base + j + k];
                     t[k].x = (mask >> k) & 1 ? xv[c] : 0.0;
                     t[k].y = (mask >> (kPairChunk + k)) & 1 ? xv[c + 1] : 0.0;
                 }
             }
 #pragma unroll
-            for (int k = 0; k < kPairChunk; ++k) {
+            for (int k = 0; k < CH; ++k) {
                 const PairVal v = pv[base + j + k];
                 if ((mask >> k) & 1) s0 += v.a * t[k].x;
                 if ((mask >> (kPairChunk + k)) & 1) s1 += v.b * t[k].y;
@@ -164,8 +175,12 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
     // one row straight from val / col (chunks that are not pair coded)
     auto plain_row = [&](int row, bool dual_t, double &sum, double &sum2) {
         for (int j = A.rp[row]; j < A.rp[row + 1]; ++j) {
-            const double vv = A.val[j];
+            double vv = A.val[j];
             const int cc = A.col[j];
+            if (MODE == kSpmvDotSym) {  // upper triangle, off-diagonal entries twice
+                if (cc < row) continue;
+                if (cc > row) vv *= 2.0;
+            }
             sum += vv * a.x[cc];
             if (dual_t) sum2 += vv * a.x2[cc];
         }
@@ -176,7 +191,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
         pz = 0.0;
         if (MODE == kSpmvPlain) {
             yv = (a.beta == 0.0) ? a.alpha * sum : a.alpha * sum + a.beta * ob;
-        } else if (MODE == kSpmvDot || MODE == kSpmvDotOnly) {
+        } else if (MODE == kSpmvDot || kDotOnly) {
             acc0 += ox * sum;
         } else if (MODE == kSpmvCgUpdate) {
             // ob: r_i, od: 1/diag_i, ox: p_i, sum: q_i = (A p)_i; yv <- new r_i; pz <- alpha p_i (x increment)
@@ -255,13 +270,14 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
         bool own_from_gathers = false;
         if (tb >= 0) {
             const int pid = A.pair_id[ra >> 1];
-            const int len = plen[pid];
+            const int lenz = plen[pid];
+            const int len = lenz & 0xffff;
             const int base = pid * ls;
             const bool edge = ra < reach || ra + 1 + reach >= (int)A.ncols;
             const bool safe = __builtin_amdgcn_ballot_w64(edge) != 0;
             // the fused dot needs x[ra], x[ra + 1]: the padding entries (col - row = 0) gather exactly
             // that pair, as does a diagonal entry; waves on the safe path load it themselves
-            own_from_gathers = kWantOwn && !safe && (len % kPairChunk) != 0;
+            own_from_gathers = kWantOwn && !safe && (lenz >> 16) != 0;
             pvd2 unused = {0.0, 0.0};
             accumulate(a.x, ra, base, len, safe, s0, s1, own, own_from_gathers);
             if (dual_t) accumulate(a.x2, ra, base, len, safe, t0, t1, unused, false);
@@ -286,7 +302,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
                 a.cg_r[ra] = y0;
                 a.cg_x[ra] = cgx.x + p0;
             }
-        } else if (MODE != kSpmvResidNorm && MODE != kSpmvDotOnly) {
+        } else if (MODE != kSpmvResidNorm && !kDotOnly) {
             if (has_b) {
                 const pvd2 yy = {y0, y1};
                 __builtin_memcpy(a.y + ra, &yy, 16);
@@ -333,6 +349,7 @@ int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hi
     case kSpmvResidInit: SCHWZ_PAIR_LAUNCH(kSpmvResidInit) break;
     case kSpmvResidDual: SCHWZ_PAIR_LAUNCH(kSpmvResidDual) break;
     case kSpmvDotOnly: SCHWZ_PAIR_LAUNCH(kSpmvDotOnly) break;
+    case kSpmvDotSym: SCHWZ_PAIR_LAUNCH(kSpmvDotSym) break;
     case kSpmvCgUpdate: SCHWZ_PAIR_LAUNCH(kSpmvCgUpdate) break;
     default: SCHWZ_PAIR_LAUNCH(kSpmvResidNorm) break;
     }
@@ -538,6 +555,46 @@ int build_spmv_pair(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, con
     const bool force = env && env[0] == '2';
     if (A->pair_fraction < 0.9 && !force) return SCHWZ_OK;
     if (!single && tables.size() * 4 > (size_t)nchunks && !force) return SCHWZ_OK;  // tables must be shared to pay off
+    // Symmetric matrix (checked bit for bit): a second set of tables with the entries on and above the
+    // diagonal only, the strictly upper ones doubled (exact), for kSpmvDotSym.  SCHWZ_SPMV_SYM=0 skips it.
+    int sym_base = 0;
+    const char *sym_env = std::getenv("SCHWZ_SPMV_SYM");
+    if (!(sym_env && sym_env[0] == '0') && csr_is_symmetric(nrows, A->v.ncols, rp, col, val)) {
+        sym_base = (int)tables.size();
+        std::vector<PairTable> upper((size_t)sym_base);
+        for (int t = 0; t < sym_base; ++t) {
+            const PairTable &src = tables[(size_t)t];
+            PairTable &u = upper[(size_t)t];
+            u.npat = src.npat;
+            u.len.assign((size_t)u.npat, 0);
+            u.lmax = 1;
+            for (int q = 0; q < src.npat; ++q) {
+                int cnt = 0;
+                for (int k = 0; k < (int)src.len[(size_t)q]; ++k) cnt += src.ent[(size_t)q * src.lmax + k].off >= 0;
+                u.len[(size_t)q] = (uint8_t)cnt;
+                u.lmax = std::max(u.lmax, cnt);
+            }
+            u.ent.assign((size_t)u.npat * u.lmax, PairEntryH{0, 0, 0, 0});
+            for (int q = 0; q < src.npat; ++q) {
+                int w = 0;
+                for (int k = 0; k < (int)src.len[(size_t)q]; ++k) {
+                    PairEntryH e = src.ent[(size_t)q * src.lmax + k];
+                    if (e.off < 0) continue;
+                    if (e.off > 0) {
+                        double va, vb;
+                        std::memcpy(&va, &e.va, 8);
+                        std::memcpy(&vb, &e.vb, 8);
+                        va *= 2.0;
+                        vb *= 2.0;
+                        std::memcpy(&e.va, &va, 8);
+                        std::memcpy(&e.vb, &vb, 8);
+                    }
+                    u.ent[(size_t)q * u.lmax + w++] = e;
+                }
+            }
+        }
+        for (PairTable &u : upper) tables.push_back(std::move(u));
+    }
     std::vector<schwz_idx> desc, meta;
     std::vector<uint8_t> lens;
     std::vector<double> vals;
@@ -572,6 +629,7 @@ int build_spmv_pair(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, con
     A->v.ptbl_val = (const double *)A->d_ptbl_val;
     A->v.ptbl_meta = (const schwz_idx *)A->d_ptbl_meta;
     A->v.pair_single = single ? 1 : 0;
+    A->v.pair_sym_base = sym_base;
     // the XCD deal of the chunks: the tile deal's run length in rows, in chunks (a power of two)
     int sh = A->v.xcd_shift;
     const int64_t rows_per_tile = std::max<int64_t>(1, nrows / std::max<int64_t>(1, (int64_t)tiles.size() - 1));
@@ -610,6 +668,7 @@ void free_spmv_pair(schwz_csr *A)
     A->d_chunk_dual = nullptr;
     A->v.pair_id = nullptr;
     A->v.chunk_dual = nullptr;
+    A->v.pair_sym_base = 0;
 }
 
 }  // namespace schwz

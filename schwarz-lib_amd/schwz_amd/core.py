@@ -53,6 +53,10 @@ class Csr:
         """Coding variant 0 uses: 0 plain CSR, 1 per-entry dictionaries, 2 row patterns, 3 row pairs."""
         return int(lib.schwz_csr_format(self.h))
 
+    def symmetric(self):
+        """True when the upload found the (row-pair coded) matrix symmetric bit for bit."""
+        return bool(lib.schwz_csr_symmetric(self.h))
+
     def algorithmic_bytes(self):
         # SURVEY 8(d): 12 nnz + 4 (rows+1) + 16 rows
         return 12 * self.nnz + 4 * (self.nrows + 1) + 16 * self.nrows

@@ -420,7 +420,9 @@ def test_coded_tiles_are_bit_identical_to_plain_csr(schwz, oracle, torch_cuda, m
     assert torch.equal(ys[0], ys[6]) and torch.equal(ys[7], ys[6])
     exp = oracle.spmv(rp, col, val, x.cpu().numpy())
     assert np.abs(ys[0].cpu().numpy() - exp).max() <= 1e-12 * max(np.abs(exp).max(), 1.0)
-    # matrices that are entirely coded: CG trajectories must coincide bit for bit
+    # matrices that are entirely coded: CG trajectories must coincide bit for bit (with p.(A p)
+    # summed over full rows: the upper-triangle form of symmetric pair-coded matrices rounds differently)
+    monkeypatch.setenv("SCHWZ_SPMV_SYM", "0")
     rp, col, val = oracle.laplacian3d(33, 21, 17)
     n = len(rp) - 1
     b = rng.standard_normal(n)
@@ -472,6 +474,87 @@ def test_qfree_cg_with_every_diagonal_representation(schwz, oracle, torch_cuda, 
     d_b, d_x = _dev(torch, b), torch.zeros(n, dtype=torch.float64, device="cuda")
     it_g, rn_g = cg.solve(d_b.data_ptr(), d_x.data_ptr(), 1e-9, n)
     assert abs(it_g - it_o) <= 1 and np.abs(d_x.cpu().numpy() - exp).max() <= 1e-7 * np.abs(exp).max()
+
+
+def _symmetric_test_matrix(oracle, rng, rough):
+    """40^3 Laplacian with a piecewise-constant diagonal shift (several pair tables); `rough`:
+    a band of rows gets random symmetric couplings, so its chunks stay plain CSR rows."""
+    import scipy.sparse as sp
+    rp, col, val = oracle.laplacian3d(40, 40, 40)
+    n = len(rp) - 1
+    M = sp.csr_matrix((val, col, rp), shape=(n, n))
+    U = sp.triu(M, 1).tocoo()
+    data = U.data.copy()
+    if rough:
+        band = (U.row >= 20000) & (U.row < 23000)
+        data[band] *= 1.0 - 0.5 * rng.random(int(band.sum()))  # weaker couplings: still diagonally dominant
+    U = sp.coo_matrix((data, (U.row, U.col)), shape=(n, n)).tocsr()
+    diag = M.diagonal() + 3.0 * ((np.arange(n) // 4096) % 5) / 5.0
+    S = (sp.diags(diag) + U + U.T).tocsr()
+    S.sort_indices()
+    return S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.copy()
+
+
+@pytest.mark.parametrize("rough", [False, True])
+def test_symmetric_matrices_take_the_dot_from_the_upper_triangle(schwz, oracle, torch_cuda, monkeypatch, rough):
+    """A pair-coded matrix that the upload finds symmetric bit for bit gets upper-triangle tables,
+    and the q-free CG iteration takes p.(A p) = sum_i p_i (a_ii p_i + 2 sum_{j>i} a_ij p_j) from
+    them (kSpmvDotSym): same iterates as the oracle within the CG tolerance, and as the full-row
+    form (SCHWZ_SPMV_SYM=0) to rounding.  One changed value or one missing mirror entry and the
+    matrix is not symmetric: no tables, and the result is the full-row one bit for bit."""
+    torch = torch_cuda
+    rng = np.random.default_rng(77)
+    rp, col, val = _symmetric_test_matrix(oracle, rng, rough)
+    n = len(rp) - 1
+    monkeypatch.setenv("SCHWZ_SPMV_PATTERN", "2")
+    monkeypatch.setenv("SCHWZ_SPMV_PAIR", "2")
+    b = rng.standard_normal(n)
+    x0 = 0.1 * rng.standard_normal(n)
+
+    def solve(rp_, col_, val_, iters, rtol=0.0):
+        A = schwz.Csr(rp_, col_, val_)
+        assert A.format() == 3
+        cg = schwz.Pcg(A, 1)
+        d_b, d_x = _dev(torch, b), _dev(torch, x0)
+        it, rn = cg.solve(d_b.data_ptr(), d_x.data_ptr(), rtol, iters)
+        return A.symmetric(), it, rn, d_x.cpu().numpy()
+
+    sym, it, rn, x = solve(rp, col, val, 30)
+    assert sym
+    exp, it_o, rn_o = oracle.pcg(rp, col, val, b, x0, 1, 0.0, 30)
+    assert it == it_o == 30
+    assert np.abs(x - exp).max() <= RTOL_CG * np.abs(exp).max()
+    assert abs(rn - rn_o) <= 1e-8 * rn_o
+    # to convergence, with the stopping test on
+    sym, it_c, rn_c, x_c = solve(rp, col, val, n, 1e-9)
+    exp_c, it_oc, _ = oracle.pcg(rp, col, val, b, x0, 1, 1e-9, n)
+    assert abs(it_c - it_oc) <= 1 and np.abs(x_c - exp_c).max() <= 1e-7 * np.abs(exp_c).max()
+    # the full-row form of the same matrix
+    monkeypatch.setenv("SCHWZ_SPMV_SYM", "0")
+    sym_f, _, rn_f, x_f = solve(rp, col, val, 30)
+    assert not sym_f
+    assert np.abs(x - x_f).max() <= 1e-11 * np.abs(x_f).max()
+    monkeypatch.delenv("SCHWZ_SPMV_SYM")
+    # one value off its mirror image
+    val2 = val.copy()
+    j = rp[12345] + 1
+    assert col[j] != 12345
+    val2[j] *= 1.0 + 2.0 ** -40
+    sym2, _, rn2, x2 = solve(rp, col, val2, 30)
+    assert not sym2
+    monkeypatch.setenv("SCHWZ_SPMV_SYM", "0")
+    _, _, rn2f, x2f = solve(rp, col, val2, 30)
+    assert np.array_equal(x2, x2f) and rn2 == rn2f
+    monkeypatch.delenv("SCHWZ_SPMV_SYM")
+    # one entry without its mirror entry (row 777 loses its last coupling)
+    keep = np.ones(len(col), dtype=bool)
+    keep[rp[778] - 1] = False
+    assert col[rp[778] - 1] > 777
+    rp3 = np.concatenate([[0], np.cumsum(np.bincount(np.repeat(np.arange(n), np.diff(rp))[keep], minlength=n))])
+    sym3, _, _, x3 = solve(rp3.astype(np.int32), col[keep], val[keep], 10)
+    assert not sym3
+    exp3, _, _ = oracle.pcg(rp3.astype(np.int32), col[keep], val[keep], b, x0, 1, 0.0, 10)
+    assert np.abs(x3 - exp3).max() <= RTOL_CG * np.abs(exp3).max()
 
 
 @pytest.mark.parametrize("nshift", [1, 3, 40])
