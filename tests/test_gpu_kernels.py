@@ -4,6 +4,8 @@ All calls go through the C ABI (include/schwz_hip.h).  Integer/index results
 are bit-exact; fp64 results are compared with the tolerances written below
 (parallel reduction order differs from the oracle's sequential sums).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -476,9 +478,9 @@ def test_qfree_cg_with_every_diagonal_representation(schwz, oracle, torch_cuda, 
     assert abs(it_g - it_o) <= 1 and np.abs(d_x.cpu().numpy() - exp).max() <= 1e-7 * np.abs(exp).max()
 
 
-def _symmetric_test_matrix(oracle, rng, rough):
-    """40^3 Laplacian with a piecewise-constant diagonal shift (several pair tables); `rough`:
-    a band of rows gets random symmetric couplings, so its chunks stay plain CSR rows."""
+def _symmetric_test_matrix(oracle, rng, rough, shifted=True):
+    """40^3 Laplacian, `shifted`: with a piecewise-constant diagonal shift (several pair tables);
+    `rough`: a band of rows gets random symmetric couplings, so its chunks stay plain CSR rows."""
     import scipy.sparse as sp
     rp, col, val = oracle.laplacian3d(40, 40, 40)
     n = len(rp) - 1
@@ -489,42 +491,59 @@ def _symmetric_test_matrix(oracle, rng, rough):
         band = (U.row >= 20000) & (U.row < 23000)
         data[band] *= 1.0 - 0.5 * rng.random(int(band.sum()))  # weaker couplings: still diagonally dominant
     U = sp.coo_matrix((data, (U.row, U.col)), shape=(n, n)).tocsr()
-    diag = M.diagonal() + 3.0 * ((np.arange(n) // 4096) % 5) / 5.0
+    diag = M.diagonal() + (3.0 * ((np.arange(n) // 4096) % 5) / 5.0 if shifted else 0.0)
     S = (sp.diags(diag) + U + U.T).tocsr()
     S.sort_indices()
     return S.indptr.astype(np.int32), S.indices.astype(np.int32), S.data.copy()
 
 
+@pytest.mark.parametrize("diag", ["uniform", "vector"])
 @pytest.mark.parametrize("rough", [False, True])
-def test_symmetric_matrices_take_the_dot_from_the_upper_triangle(schwz, oracle, torch_cuda, monkeypatch, rough):
+def test_symmetric_matrices_take_the_dot_from_the_upper_triangle(schwz, oracle, torch_cuda, monkeypatch, rough, diag):
     """A pair-coded matrix that the upload finds symmetric bit for bit gets upper-triangle tables,
     and the q-free CG iteration takes p.(A p) = sum_i p_i (a_ii p_i + 2 sum_{j>i} a_ij p_j) from
     them (kSpmvDotSym): same iterates as the oracle within the CG tolerance, and as the full-row
     form (SCHWZ_SPMV_SYM=0) to rounding.  One changed value or one missing mirror entry and the
-    matrix is not symmetric: no tables, and the result is the full-row one bit for bit."""
+    matrix is not symmetric: no tables, and the result is the full-row one bit for bit.
+    Run with the Jacobi diagonal as a scalar (`uniform`), as a full vector (`vector`; as 1-byte
+    codes the iteration keeps a stored q and never takes this launch) or absent (precond 0)."""
+    import ctypes
     torch = torch_cuda
     rng = np.random.default_rng(77)
-    rp, col, val = _symmetric_test_matrix(oracle, rng, rough)
+    rp, col, val = _symmetric_test_matrix(oracle, rng, rough, shifted=diag == "vector")
     n = len(rp) - 1
+    if diag == "vector":
+        monkeypatch.setenv("SCHWZ_DIAG_DICT", "0")   # 5 distinct values would otherwise become 1-byte codes
     monkeypatch.setenv("SCHWZ_SPMV_PATTERN", "2")
     monkeypatch.setenv("SCHWZ_SPMV_PAIR", "2")
     b = rng.standard_normal(n)
     x0 = 0.1 * rng.standard_normal(n)
 
-    def solve(rp_, col_, val_, iters, rtol=0.0):
+    def solve(rp_, col_, val_, iters, rtol=0.0, precond=1):
         A = schwz.Csr(rp_, col_, val_)
         assert A.format() == 3
-        cg = schwz.Pcg(A, 1)
+        cg = schwz.Pcg(A, precond)
         d_b, d_x = _dev(torch, b), _dev(torch, x0)
         it, rn = cg.solve(d_b.data_ptr(), d_x.data_ptr(), rtol, iters)
         return A.symmetric(), it, rn, d_x.cpu().numpy()
 
+    for precond in (1, 0):
+        for iters in (1, 2, 30):
+            # the q-free iteration ran: its update launch is the one the profiling hook files as kind 1
+            schwz.capi.check(schwz.capi.lib.schwz_profile_begin(4 * iters + 8))
+            sym, it, rn, x = solve(rp, col, val, iters, precond=precond)
+            tot, launches = ctypes.c_double(0.0), ctypes.c_int64(0)
+            schwz.capi.check(schwz.capi.lib.schwz_profile_end(ctypes.byref(tot), ctypes.byref(launches)))
+            upd_ms, upd = ctypes.c_double(0.0), ctypes.c_int64(0)
+            schwz.capi.check(schwz.capi.lib.schwz_profile_kind(1, ctypes.byref(upd_ms), ctypes.byref(upd)))
+            assert sym and launches.value == iters
+            if os.environ.get("SCHWZ_CG_QFREE", "1")[:1] != "0":
+                assert upd.value == iters
+            exp, it_o, rn_o = oracle.pcg(rp, col, val, b, x0, precond, 0.0, iters)
+            assert it == it_o == iters
+            assert np.abs(x - exp).max() <= RTOL_CG * np.abs(exp).max()
+            assert abs(rn - rn_o) <= 1e-8 * rn_o
     sym, it, rn, x = solve(rp, col, val, 30)
-    assert sym
-    exp, it_o, rn_o = oracle.pcg(rp, col, val, b, x0, 1, 0.0, 30)
-    assert it == it_o == 30
-    assert np.abs(x - exp).max() <= RTOL_CG * np.abs(exp).max()
-    assert abs(rn - rn_o) <= 1e-8 * rn_o
     # to convergence, with the stopping test on
     sym, it_c, rn_c, x_c = solve(rp, col, val, n, 1e-9)
     exp_c, it_oc, _ = oracle.pcg(rp, col, val, b, x0, 1, 1e-9, n)
