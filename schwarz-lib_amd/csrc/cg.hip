@@ -715,6 +715,20 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
         return !(e && e[0] == '0');
     }();
     const int dot_mode = !qfree ? kSpmvDot : (sym_on && A.pair_sym_base > 0 ? kSpmvDotSym : kSpmvDotOnly);
+    // Two launches per iteration where launches, not bytes, set the pace (systems up to kGraphRows
+    // rows): the direction update and the NEXT iteration's p.(A p) share one launch
+    // (kSpmvDirDotSym), p alternating between s->p and the otherwise unused s->q (a launch that
+    // recomputes its neighbours' new p must not overwrite the old one).  The first p.(A p) of a
+    // solve is launched on its own below.  On large systems the fused launch costs what the two it
+    // replaces cost (0.118 vs 0.069 + 0.044 ms at 256^3), so they keep three.
+    // SCHWZ_CG_FUSEDIR=0: never, =2: every size.
+    static const int fusedir_mode = [] {
+        const char *e = std::getenv("SCHWZ_CG_FUSEDIR");
+        return e ? std::atoi(e) : 1;
+    }();
+    const bool fusedir = dot_mode == kSpmvDotSym && (fusedir_mode == 2 || (fusedir_mode == 1 && n <= kGraphRows));
+    const int flavour = !qfree ? 0 : (fusedir ? 2 : 1);
+    double *const pbuf[2] = {s->p, fusedir ? s->q : s->p};
     // one CG iteration on stream `q`; `it` only enters through its parity (rho slot) and through
     // "it >= stop_iter", and stop_iter is 0 once the tolerance test has fired: a recorded sequence
     // of an even number of iterations can therefore be replayed as a hipGraph
@@ -726,20 +740,22 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
         a.stop_iter = &s->state->stop_iter;
         a.it = it;
         const bool prof = instrument && g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
-        if (prof) SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used], q));
-        int rc = launch_spmv(A, dot_mode, a, s->variant, q);
-        if (rc) return rc;
-        if (prof) {
-            SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used + 1], q));
-            g_prof.kind[g_prof.used / 2] = 0;
-            g_prof.used += 2;
+        int rc = SCHWZ_OK;
+        if (!fusedir) {
+            if (prof) SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used], q));
+            if ((rc = launch_spmv(A, dot_mode, a, s->variant, q))) return rc;
+            if (prof) {
+                SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used + 1], q));
+                g_prof.kind[g_prof.used / 2] = 0;
+                g_prof.used += 2;
+            }
         }
         if (qfree) {
             // q = A p is never stored: the update pass recomputes (A p)_i row by row while it
             // streams x and r (spmv_pair.hip, kSpmvCgUpdate): 16 B per row less HBM traffic, a
             // third of the stores of these two launches
             SpmvArgs u;
-            u.x = s->p;
+            u.x = pbuf[it & 1];
             u.cg_x = d_x;
             u.cg_r = s->r;
             u.cg_state = s->state;
@@ -758,8 +774,36 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
                 g_prof.kind[g_prof.used / 2] = 1;
                 g_prof.used += 2;
             }
-            hipLaunchKernelGGL((cg_direction_kernel<1, false>), dim3(gv), dim3(kBlock), 0, q, n, s->p, s->r, s->diag,
-                               part_vec, gs, s->state, it, rtol);
+            if (fusedir && !(instrument && it == max_iters - 1)) {
+                // p' = z + beta p into the other buffer and the partial sums of p'.(A p') for the next
+                // iteration (the last iteration of a solve only needs the direction kernel's state
+                // update; recorded graphs replay mid-solve, so they keep the fused launch)
+                SpmvArgs f;
+                f.x = pbuf[it & 1];
+                f.y = pbuf[(it + 1) & 1];
+                f.cg_r = s->r;
+                f.cg_state = s->state;
+                f.pq_partials = part_vec;
+                f.pq_nparts = gs;
+                f.diag_mode = s->diag.mode;
+                f.diag_uniform = s->diag.uniform;
+                f.dinv = s->dinv;
+                f.partials = part_spmv;
+                f.it = it;
+                f.cg_rtol = rtol;
+                const bool prof3 = instrument && g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
+                if (prof3) SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used], q));
+                if ((rc = launch_spmv(A, s->diag.mode == 1 ? kSpmvDirDotSymVec : kSpmvDirDotSym, f, s->variant, q)))
+                    return rc;
+                if (prof3) {
+                    SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used + 1], q));
+                    g_prof.kind[g_prof.used / 2] = 0;
+                    g_prof.used += 2;
+                }
+            } else {
+                hipLaunchKernelGGL((cg_direction_kernel<1, false>), dim3(gv), dim3(kBlock), 0, q, n, pbuf[it & 1], s->r,
+                                   s->diag, part_vec, gs, s->state, it, rtol);
+            }
         } else if (!general) {
             hipLaunchKernelGGL((cg_update_kernel<1, false>), dim3(gv), dim3(kBlock), 0, q, n, d_x, s->r, s->p, s->q,
                                s->diag, part_spmv, gs, s->state, it, part_vec);
@@ -791,7 +835,7 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
     hipGraphExec_t replay = nullptr;
     if (graphable && max_iters >= kGraphIters) {
         for (const auto &g : s->graphs)
-            if (g.x == d_x && g.rtol == rtol && g.variant == s->variant && g.qfree == qfree) replay = g.exec;
+            if (g.x == d_x && g.rtol == rtol && g.variant == s->variant && g.qfree == flavour) replay = g.exec;
         if (!replay && s->graphs.size() < 4) {
             if (!s->capture_stream) SCHWZ_HIP_TRY(hipStreamCreateWithFlags(&s->capture_stream, hipStreamNonBlocking));
             if (hipStreamBeginCapture(s->capture_stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
@@ -804,13 +848,23 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
                     return rc;
                 }
                 if (e1 == hipSuccess && hipGraphInstantiate(&replay, graph, nullptr, nullptr, 0) == hipSuccess)
-                    s->graphs.push_back({d_x, rtol, s->variant, qfree, replay});
+                    s->graphs.push_back({d_x, rtol, s->variant, flavour, replay});
                 else
                     replay = nullptr;
                 if (graph) (void)hipGraphDestroy(graph);
             }
             (void)hipGetLastError();
         }
+    }
+    if (fusedir && max_iters > 0) {
+        // p0.(A p0): every later p.(A p) comes out of the fused direction launch
+        SpmvArgs a;
+        a.x = s->p;
+        a.partials = part_spmv;
+        a.stop_iter = &s->state->stop_iter;
+        a.it = 0;
+        int rc = launch_spmv(A, kSpmvDotSym, a, s->variant, st);
+        if (rc) return rc;
     }
     int chunk = 16;
     int it = 0, pending = -1, bank = 0;

@@ -108,7 +108,13 @@ enum SpmvMode {
     kSpmvCgUpdate = 6,
     // kSpmvDotOnly for a matrix whose upload found it symmetric: the same number from the upper
     // triangle alone (CsrView::pair_sym_base), about half the gathers
-    kSpmvDotSym = 7
+    kSpmvDotSym = 7,
+    // the direction update and the next iteration's kSpmvDotSym in one launch: beta from the folded
+    // partials, p' = z + beta p computed wherever the upper-triangle gathers need it (own entry and
+    // neighbours alike, from r and the OLD p, which this launch only reads), own p' stored to a
+    // second buffer, partial sums of p'.(A p'); CgState advanced by workgroup 0
+    kSpmvDirDotSym = 8,
+    kSpmvDirDotSymVec = 9  // ... with the Jacobi diagonal as a full vector (gathered like r and p)
 };
 
 struct SpmvArgs {
@@ -130,6 +136,7 @@ struct SpmvArgs {
     int pq_nparts = 0;
     int diag_mode = 0;          // 0 none, 1 full vector (dinv), 3 uniform scalar
     double diag_uniform = 1.0;
+    double cg_rtol = 0.0;       // kSpmvDirDotSym: relative tolerance of the stopping test
 };
 
 // launch grid of the streaming vector kernels: one lane per element up to kMaxGrid workgroups
@@ -247,7 +254,7 @@ struct schwz_pcg {
         double *x;
         double rtol;
         int variant;
-        bool qfree;
+        int qfree;  // 0 stored q, 1 q-free (3 launches), 2 q-free with the fused direction + dot launch
         hipGraphExec_t exec;
     };
     std::vector<Captured> graphs;

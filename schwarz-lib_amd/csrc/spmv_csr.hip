@@ -785,7 +785,8 @@ int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipS
         break;                                                                                         \
     }
     if (variant == 0 && A.pair_id) return launch_spmv_pair(A, mode, a, grid, s);
-    if (mode == kSpmvDotOnly || mode == kSpmvDotSym || mode == kSpmvCgUpdate) {
+    if (mode == kSpmvDotOnly || mode == kSpmvDotSym || mode == kSpmvDirDotSym || mode == kSpmvDirDotSymVec ||
+        mode == kSpmvCgUpdate) {
         set_error("launch_spmv: the q-free CG modes exist for row-pair coded matrices only");
         return SCHWZ_ERR_INVALID;
     }

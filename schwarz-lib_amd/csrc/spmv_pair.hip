@@ -63,15 +63,24 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
     __shared__ PairVal pv[kPairEntries];
     __shared__ int poff[kPairEntries];             // col - row of the entry
     // gathers issued back to back per lane; the upper-triangle tables of kSpmvDotSym are about half as long
-    constexpr int CH = MODE == kSpmvDotSym ? kPairChunk / 2 : kPairChunk;
-    constexpr bool kDotOnly = MODE == kSpmvDotOnly || MODE == kSpmvDotSym;
+    constexpr bool kDirVec = MODE == kSpmvDirDotSymVec;
+    constexpr bool kDir = MODE == kSpmvDirDotSym || kDirVec;
+    constexpr bool kSym = MODE == kSpmvDotSym || kDir;
+    constexpr int CH = kSym ? kPairChunk / 2 : kPairChunk;
+    constexpr bool kDotOnly = MODE == kSpmvDotOnly || kSym;
     __shared__ int pmask[kPairEntries / CH];  // per group of CH entries: bit k = row r has entry k, bit 8+k = row r+1
     __shared__ int plen[kPairPats];            // length | (a gathered entry has col - row == 0) << 16
     if (MODE == kSpmvDot || MODE == kSpmvResidInit || kDotOnly) {
         if (a.stop_iter && a.it >= *a.stop_iter) return;
     }
     __shared__ double red[4];
-    double cg_alpha = 0.0;
+    double cg_alpha = 0.0, cg_beta = 0.0, cg_rho_new = 0.0, cg_rr = 0.0;
+    if (kDir) {
+        if (a.it >= a.cg_state->stop_iter) return;
+        cg_rho_new = fold_partials(a.pq_partials, a.pq_nparts, red);
+        cg_rr = fold_partials(a.pq_partials + a.pq_nparts, a.pq_nparts, red);
+        cg_beta = cg_rho_new / a.cg_state->rho[a.it & 1];
+    }
     if (MODE == kSpmvCgUpdate) {
         if (a.it >= a.cg_state->stop_iter) return;
         cg_alpha = a.cg_state->rho[a.it & 1] / fold_partials(a.pq_partials, a.pq_nparts, red);
@@ -90,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
     int cached = -1, ls = 0, reach = 0;  // staged table, its row stride, its largest |col - row|
 
     auto stage_table = [&](int tb) {  // workgroup-uniform
-        const int td = MODE == kSpmvDotSym ? A.pair_sym_base + tb : tb;
+        const int td = kSym ? A.pair_sym_base + tb : tb;
         const int eoff = A.ptbl_desc[5 * td], loff = A.ptbl_desc[5 * td + 1];
         const int npat = A.ptbl_desc[5 * td + 2], lmax = A.ptbl_desc[5 * td + 3];
         ls = pair_stride(lmax, CH);
@@ -172,14 +181,67 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
             }
         }
     };
+    // kSpmvDirDotSym: the new search direction p' = z + beta p at column c, z = D^-1 r -- one
+    // expression for the stored copy and for every neighbour's recomputed one
+    auto dir2 = [&](pvd2 rv, pvd2 pv, pvd2 dv) -> pvd2 {
+        const pvd2 z = a.diag_mode ? dv * rv : rv;
+        pvd2 o;
+        o.x = __builtin_fma(cg_beta, pv.x, z.x);
+        o.y = __builtin_fma(cg_beta, pv.y, z.y);
+        return o;
+    };
+    auto dir1 = [&](int c) -> double {
+        const double rv = a.cg_r[c];
+        const double z = kDirVec ? a.dinv[c] * rv : (a.diag_mode ? a.diag_uniform * rv : rv);
+        return __builtin_fma(cg_beta, a.x[c], z);
+    };
+    auto accumulate_dir = [&](int ra, int base, int len, bool safe, double &s0, double &s1, pvd2 &own) {
+        const pvd2 du = {a.diag_uniform, a.diag_uniform};
+        for (int j = 0; j < len; j += CH) {
+            const int mask = pmask[(base + j) / CH];
+            pvd2 t[CH];
+            if (!safe) {
+                pvd2 tr[CH], tp[CH], td[kDirVec ? CH : 1];
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    const int off = poff[base + j + k];
+                    tr[k] = ld16(a.cg_r, ra + off);
+                    tp[k] = ld16(a.x, ra + off);
+                    if (kDirVec) td[k] = ld16(a.dinv, ra + off);
+                }
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    t[k] = dir2(tr[k], tp[k], kDirVec ? td[kDirVec ? k : 0] : du);
+                    if (poff[base + j + k] == 0) own = t[k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    const int c = ra + poff[base + j + k];
+                    t[k].x = (mask >> k) & 1 ? dir1(c) : 0.0;
+                    t[k].y = (mask >> (kPairChunk + k)) & 1 ? dir1(c + 1) : 0.0;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const PairVal v = pv[base + j + k];
+                if ((mask >> k) & 1) s0 += v.a * t[k].x;
+                if ((mask >> (kPairChunk + k)) & 1) s1 += v.b * t[k].y;
+            }
+        }
+    };
     // one row straight from val / col (chunks that are not pair coded)
     auto plain_row = [&](int row, bool dual_t, double &sum, double &sum2) {
         for (int j = A.rp[row]; j < A.rp[row + 1]; ++j) {
             double vv = A.val[j];
             const int cc = A.col[j];
-            if (MODE == kSpmvDotSym) {  // upper triangle, off-diagonal entries twice
+            if (kSym) {  // upper triangle, off-diagonal entries twice
                 if (cc < row) continue;
                 if (cc > row) vv *= 2.0;
+            }
+            if (kDir) {
+                sum += vv * dir1(cc);
+                continue;
             }
             sum += vv * a.x[cc];
             if (dual_t) sum2 += vv * a.x2[cc];
@@ -279,15 +341,19 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
             // that pair, as does a diagonal entry; waves on the safe path load it themselves
             own_from_gathers = kWantOwn && !safe && (lenz >> 16) != 0;
             pvd2 unused = {0.0, 0.0};
-            accumulate(a.x, ra, base, len, safe, s0, s1, own, own_from_gathers);
-            if (dual_t) accumulate(a.x2, ra, base, len, safe, t0, t1, unused, false);
+            if (kDir) {
+                accumulate_dir(ra, base, len, safe, s0, s1, own);
+            } else {
+                accumulate(a.x, ra, base, len, safe, s0, s1, own, own_from_gathers);
+                if (dual_t) accumulate(a.x2, ra, base, len, safe, t0, t1, unused, false);
+            }
         } else {
             plain_row(ra, dual_t, s0, t0);
             if (has_b) plain_row(ra + 1, dual_t, s1, t1);
         }
         if (kWantOwn && !own_from_gathers) {
-            own.x = a.x[ra];
-            if (has_b) own.y = a.x[ra + 1];
+            own.x = kDir ? dir1(ra) : a.x[ra];
+            if (has_b) own.y = kDir ? dir1(ra + 1) : a.x[ra + 1];
         }
         double y0, y1 = 0.0, p0, p1 = 0.0;
         finish(ra, s0, t0, dual_t, own.x, ob0, od0, y0, p0);
@@ -302,6 +368,11 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
                 a.cg_r[ra] = y0;
                 a.cg_x[ra] = cgx.x + p0;
             }
+        } else if (kDir) {  // the pair's own new direction
+            if (has_b)
+                __builtin_memcpy(a.y + ra, &own, 16);
+            else
+                a.y[ra] = own.x;
         } else if (MODE != kSpmvResidNorm && !kDotOnly) {
             if (has_b) {
                 const pvd2 yy = {y0, y1};
@@ -331,6 +402,15 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
             if (tid == 0) a.partials[2 * gridDim.x + blockIdx.x] = s2v;
         }
     }
+    if (kDir && blockIdx.x == 0 && tid == 0) {
+        // what cg_direction_kernel's workgroup 0 does: the rho slot written is the one no launch of
+        // this iteration reads; stop_iter = 0 makes every later launch leave at once
+        CgState *st = const_cast<CgState *>(a.cg_state);
+        st->rho[(a.it + 1) & 1] = cg_rho_new;
+        st->rr = cg_rr;
+        st->iters = st->iters + 1;
+        if (sqrt(cg_rr) <= a.cg_rtol * st->r0) st->stop_iter = 0;
+    }
 }
 
 int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s)
@@ -350,6 +430,8 @@ int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hi
     case kSpmvResidDual: SCHWZ_PAIR_LAUNCH(kSpmvResidDual) break;
     case kSpmvDotOnly: SCHWZ_PAIR_LAUNCH(kSpmvDotOnly) break;
     case kSpmvDotSym: SCHWZ_PAIR_LAUNCH(kSpmvDotSym) break;
+    case kSpmvDirDotSym: SCHWZ_PAIR_LAUNCH(kSpmvDirDotSym) break;
+    case kSpmvDirDotSymVec: SCHWZ_PAIR_LAUNCH(kSpmvDirDotSymVec) break;
     case kSpmvCgUpdate: SCHWZ_PAIR_LAUNCH(kSpmvCgUpdate) break;
     default: SCHWZ_PAIR_LAUNCH(kSpmvResidNorm) break;
     }
