@@ -216,6 +216,12 @@ def main():
                        "x += alpha p, r -= alpha q, z = D^-1 r, partial r.z and r.r)")
         dom_tag = "spmv_pair_kernel<6,"
         alg_dom = alg_spmv + 96 * n_rows
+        if n_rows > (1 << 21) and os.environ.get("SCHWZ_CG_DEFERX", "1")[:1] != "0":
+            # large systems: x += alpha p is not part of this launch (deferred, applied to up to 16
+            # search directions at once by cg_flush_x_kernel): 24 n fewer algorithmic bytes
+            kernel_name = ("spmv_pair_kernel<kSpmvCgUpdate> (row-pair coded A: q_i = (A p)_i recomputed, "
+                           "r -= alpha q, z = D^-1 r, partial r.z and r.r; x += alpha p deferred)")
+            alg_dom = alg_spmv + 72 * n_rows
         avg_ms = upd_ms.value / upd_launches.value
         dom_launches = upd_launches.value
         spmv_name = "spmv_pair_kernel<kSpmvDotOnly> (partial sums of p.(A p), nothing stored; row-pair coded CSR)"

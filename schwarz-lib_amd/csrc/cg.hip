@@ -158,12 +158,14 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, double *__
 
 // beta = rho'/rho ; p = dinv r + beta p ; state update by workgroup 0
 template <int U, bool NT>
-__global__ __launch_bounds__(kBlock) void cg_direction_kernel(int64_t n, double *__restrict__ p,
-                                                              const double *__restrict__ r,
+__global__ __launch_bounds__(kBlock) void cg_direction_kernel(int64_t n, double *p, const double *__restrict__ r,
                                                               const DiagView dg,
                                                               const double *partials_in, int nparts,
-                                                              CgState *st, int it, double rtol)
+                                                              CgState *st, int it, double rtol, double *p_out = nullptr)
 {
+    // p_out: the new direction goes to another vector (the ring of the deferred x update); each
+    // element is read and written by the same lane, so p_out == p (in place) is the default
+    if (!p_out) p_out = p;
     // with a general preconditioner `r` is already z = M^-1 r and dg.mode is 0
     __shared__ double red[4];
     __shared__ double ddict[256];
@@ -198,14 +200,14 @@ __global__ __launch_bounds__(kBlock) void cg_direction_kernel(int64_t n, double 
             const int64_t i = i0 + u * stride;
             if (i < n2) {
                 if (dg.mode) zv[u] *= dv[u];
-                store2<NT>(p, i, zv[u] + beta * pv[u]);
+                store2<NT>(p_out, i, zv[u] + beta * pv[u]);
             }
         }
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const int64_t i = n - 1;
         const double z = dg.mode ? diag_one(dg, ddict, i) * r[i] : r[i];
-        p[i] = z + beta * p[i];
+        p_out[i] = z + beta * p[i];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // other workgroups read rho[it&1] concurrently: the slot written here is the other one
@@ -223,6 +225,57 @@ __global__ __launch_bounds__(kBlock) void cg_direction_kernel(int64_t n, double 
 // < 1 % (0.403 / 0.406 / 0.417 ms for U = 1 / 2 / 4): these kernels sit at the mixed
 // read+write HBM ceiling (~5.0-5.5 TB/s), so the plain shape is used.
 
+
+// Deferred x update: x_i += alpha_k p_k,i for the iterations b0 <= k < b0 + count that were actually
+// carried out, in iteration order and with the product rounded before the sum -- the very
+// operations kSpmvCgUpdate performs when it updates x itself, so the bits are the same.
+// Carried out: k < st->iters (the direction launch counts), plus iteration `pending` when this
+// launch sits between its update launch and its direction launch and the update launch ran
+// (pending < stop_iter, which only direction launches lower).
+struct PRing {
+    const double *slot[kDeferDepth];
+};
+
+__global__ __launch_bounds__(kBlock) void cg_flush_x_kernel(int64_t n, double *__restrict__ x, const PRing ring,
+                                                            const double *__restrict__ alpha_hist,
+                                                            const CgState *st, int b0, int count, int pending)
+{
+#pragma clang fp contract(off)
+    __shared__ double alpha[kDeferDepth];
+    const int done = st->iters + ((pending >= 0 && pending < st->stop_iter) ? 1 : 0);
+    const int kmax = min(count, done - b0);
+    if (kmax <= 0) return;
+    if ((int)threadIdx.x < kmax) alpha[threadIdx.x] = alpha_hist[(b0 + threadIdx.x) % kDeferDepth];
+    __syncthreads();
+    const int64_t n2 = n >> 1;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    vd2 *x2 = reinterpret_cast<vd2 *>(x);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
+        vd2 xv = __builtin_nontemporal_load(x2 + i);
+        for (int k0 = 0; k0 < kmax; k0 += 4) {
+            vd2 pv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k0 + k < kmax)
+                    pv[k] = __builtin_nontemporal_load(reinterpret_cast<const vd2 *>(ring.slot[(b0 + k0 + k) % kDeferDepth]) + i);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k0 + k < kmax) {
+                    const vd2 inc = alpha[k0 + k] * pv[k];
+                    xv = xv + inc;
+                }
+        }
+        __builtin_nontemporal_store(xv, x2 + i);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        double xv = x[n - 1];
+        for (int k = 0; k < kmax; ++k) {
+            const double inc = alpha[k] * ring.slot[(b0 + k) % kDeferDepth][n - 1];
+            xv = xv + inc;
+        }
+        x[n - 1] = xv;
+    }
+}
 
 // dinv[i] = 1 / A[i][i] (1 when the row stores no diagonal): scalar Jacobi, i.e.
 // block-Jacobi with max_block_size 1
@@ -570,6 +623,8 @@ void schwz_pcg_destroy(schwz_pcg *s)
     (void)hipFree(s->r);
     (void)hipFree(s->p);
     (void)hipFree(s->q);
+    (void)hipFree(s->p_ring);
+    (void)hipFree(s->alpha_hist);
     (void)hipFree(s->dinv);
     (void)hipFree(s->z);
     (void)hipFree(s->d_blk_id);
@@ -726,15 +781,45 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
         const char *e = std::getenv("SCHWZ_CG_FUSEDIR");
         return e ? std::atoi(e) : 1;
     }();
-    const bool fusedir = dot_mode == kSpmvDotSym && (fusedir_mode == 2 || (fusedir_mode == 1 && n <= kGraphRows));
+    const char *dx_env = std::getenv("SCHWZ_CG_DEFERX");  // read per solve: tests switch it
+    const int dx_mode = dx_env ? std::atoi(dx_env) : 1;
+    const bool fusedir = dot_mode == kSpmvDotSym && dx_mode != 2 &&
+                         (fusedir_mode == 2 || (fusedir_mode == 1 && n <= kGraphRows));
     const int flavour = !qfree ? 0 : (fusedir ? 2 : 1);
+    // Large systems: x is not touched inside the iteration.  The search directions of up to
+    // kDeferDepth iterations stay in a ring (slots 0 and 1 are s->p and the otherwise unused s->q),
+    // the update launch stores alpha_k instead of updating x, and one launch per kDeferDepth
+    // iterations (and one at the end) applies x += sum_k alpha_k p_k in iteration order -- the same
+    // bits, (depth + 2) / depth vectors of traffic per iteration instead of 2.
+    // SCHWZ_CG_DEFERX=0: never, =2: every size (tests).
+    bool deferx = qfree && !fusedir && !s->ring_failed && (dx_mode == 2 || (dx_mode == 1 && n > kGraphRows));
+    if (deferx && !s->p_ring) {
+        const size_t nb = (size_t)((n + 1) & ~int64_t(1)) * sizeof(double);
+        if (hipMalloc((void **)&s->p_ring, nb * (kDeferDepth - 2)) != hipSuccess ||
+            hipMalloc((void **)&s->alpha_hist, kDeferDepth * sizeof(double)) != hipSuccess) {
+            (void)hipGetLastError();  // not enough memory for the ring: the plain iteration
+            (void)hipFree(s->p_ring);
+            s->p_ring = nullptr;
+            s->ring_failed = true;
+            deferx = false;
+        }
+    }
+    PRing ring;
+    const int64_t n_pad = (n + 1) & ~int64_t(1);
+    for (int k = 0; k < kDeferDepth; ++k)
+        ring.slot[k] = k == 0 ? s->p : (k == 1 ? s->q : (s->p_ring ? s->p_ring + (int64_t)(k - 2) * n_pad : s->p));
+    auto slot = [&](int it) -> double * { return const_cast<double *>(ring.slot[it % kDeferDepth]); };
+    auto flush_x = [&](int b0, int count, int pending, hipStream_t q) {
+        hipLaunchKernelGGL(cg_flush_x_kernel, dim3(gv), dim3(kBlock), 0, q, n, d_x, ring, s->alpha_hist, s->state, b0,
+                           count, pending);
+    };
     double *const pbuf[2] = {s->p, fusedir ? s->q : s->p};
     // one CG iteration on stream `q`; `it` only enters through its parity (rho slot) and through
     // "it >= stop_iter", and stop_iter is 0 once the tolerance test has fired: a recorded sequence
     // of an even number of iterations can therefore be replayed as a hipGraph
     auto launch_iteration = [&](int it, hipStream_t q, bool instrument) -> int {
         SpmvArgs a;
-        a.x = s->p;
+        a.x = deferx ? slot(it) : s->p;
         a.y = s->q;
         a.partials = part_spmv;
         a.stop_iter = &s->state->stop_iter;
@@ -755,8 +840,9 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
             // streams x and r (spmv_pair.hip, kSpmvCgUpdate): 16 B per row less HBM traffic, a
             // third of the stores of these two launches
             SpmvArgs u;
-            u.x = pbuf[it & 1];
-            u.cg_x = d_x;
+            u.x = deferx ? slot(it) : pbuf[it & 1];
+            u.cg_x = deferx ? nullptr : d_x;
+            u.alpha_out = deferx ? s->alpha_hist + it % kDeferDepth : nullptr;
             u.cg_r = s->r;
             u.cg_state = s->state;
             u.pq_partials = part_spmv;
@@ -800,6 +886,12 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
                     g_prof.kind[g_prof.used / 2] = 0;
                     g_prof.used += 2;
                 }
+            } else if (deferx) {
+                // the ring is full: apply its kDeferDepth increments before slot (it + 1) % depth,
+                // the oldest direction, is overwritten
+                if ((it + 1) % kDeferDepth == 0) flush_x(it + 1 - kDeferDepth, kDeferDepth, it, q);
+                hipLaunchKernelGGL((cg_direction_kernel<1, false>), dim3(gv), dim3(kBlock), 0, q, n, slot(it), s->r,
+                                   s->diag, part_vec, gs, s->state, it, rtol, slot(it + 1));
             } else {
                 hipLaunchKernelGGL((cg_direction_kernel<1, false>), dim3(gv), dim3(kBlock), 0, q, n, pbuf[it & 1], s->r,
                                    s->diag, part_vec, gs, s->state, it, rtol);
@@ -831,7 +923,7 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
         const char *e = std::getenv("SCHWZ_CG_GRAPH");
         return e ? std::atoi(e) : 1;
     }();
-    const bool graphable = graph_mode != 0 && !general && !g_prof.on && (graph_mode == 2 || n <= kGraphRows);
+    const bool graphable = graph_mode != 0 && !general && !g_prof.on && !deferx && (graph_mode == 2 || n <= kGraphRows);
     hipGraphExec_t replay = nullptr;
     if (graphable && max_iters >= kGraphIters) {
         for (const auto &g : s->graphs)
@@ -893,6 +985,12 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
             bank ^= 1;
             if (chunk < 64) chunk *= 2;
         }
+    }
+    // the increments of the last, partly filled ring (iterations past a tolerance stop are not
+    // counted by CgState::iters and add nothing)
+    if (deferx && it % kDeferDepth != 0) {
+        flush_x(it - it % kDeferDepth, it % kDeferDepth, -1, st);
+        SCHWZ_HIP_TRY(hipGetLastError());
     }
     return SCHWZ_OK;
 }

@@ -42,6 +42,7 @@ constexpr int kMaxGrid = 2048;   // 256 CUs x 8 workgroups, grid-stride beyond
 constexpr int kXcds = 8;
 constexpr int kGraphIters = 16;          // CG iterations per recorded hipGraph (even: rho slots repeat)
 constexpr int64_t kGraphRows = 1 << 21;  // systems up to this many rows replay their CG loop as graphs
+constexpr int kDeferDepth = 16;          // search directions kept before x += sum alpha_k p_k is applied
 constexpr int kWaveTileNnz = 512;  // products staged per wave (4 KiB fp64)
 
 struct CsrView {
@@ -137,6 +138,8 @@ struct SpmvArgs {
     int diag_mode = 0;          // 0 none, 1 full vector (dinv), 3 uniform scalar
     double diag_uniform = 1.0;
     double cg_rtol = 0.0;       // kSpmvDirDotSym: relative tolerance of the stopping test
+    // kSpmvCgUpdate with cg_x == nullptr: x is not touched, alpha is stored here instead (workgroup 0)
+    double *alpha_out = nullptr;
 };
 
 // launch grid of the streaming vector kernels: one lane per element up to kMaxGrid workgroups
@@ -259,6 +262,10 @@ struct schwz_pcg {
     };
     std::vector<Captured> graphs;
     hipStream_t capture_stream = nullptr;
+    // deferred x update of large systems (pcg_iterate): ring of search directions and their alphas
+    double *p_ring = nullptr;      // kDeferDepth - 2 vectors; slots 0 and 1 of the ring are p and q
+    double *alpha_hist = nullptr;  // kDeferDepth
+    bool ring_failed = false;
 };
 
 struct schwz_trs {

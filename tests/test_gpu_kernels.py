@@ -607,3 +607,42 @@ def test_pcg_diagonal_representations_agree(schwz, oracle, torch_cuda, monkeypat
     assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
     exp, _, rn_o = oracle.pcg(rp, col, val, b, None, 1, 0.0, 15)
     assert np.abs(res[0][0] - exp).max() <= RTOL_CG * np.abs(exp).max()
+
+
+@pytest.mark.parametrize("n_edge", [(24, 20, 17), (21, 19, 15)])
+def test_deferred_x_update_is_bit_identical(schwz, oracle, torch_cuda, monkeypatch, n_edge):
+    """Large systems keep x out of the CG iteration: the search directions of up to 16 iterations
+    stay in a ring, the update launch stores alpha_k, and one launch per full ring (and one at the
+    end) applies x += sum alpha_k p_k in iteration order.  Forced on a small system here
+    (SCHWZ_CG_DEFERX=2) and compared bit for bit with the iteration that updates x itself: fixed
+    iteration counts around the ring length, a tolerance stop inside a ring, even and odd n."""
+    torch = torch_cuda
+    rp, col, val = oracle.laplacian3d(*n_edge)
+    n = len(rp) - 1
+    monkeypatch.setenv("SCHWZ_SPMV_PATTERN", "2")
+    monkeypatch.setenv("SCHWZ_SPMV_PAIR", "2")
+    rng = np.random.default_rng(5)
+    b = rng.standard_normal(n)
+    x0 = 0.1 * rng.standard_normal(n)
+    A = schwz.Csr(rp, col, val)
+    assert A.format() == 3
+    cg = schwz.Pcg(A, 1)
+
+    def solve(mode, iters, rtol):
+        monkeypatch.setenv("SCHWZ_CG_DEFERX", mode)
+        d_b, d_x = _dev(torch, b), _dev(torch, x0)
+        it, rn = cg.solve(d_b.data_ptr(), d_x.data_ptr(), rtol, iters)
+        return it, rn, d_x.cpu().numpy()
+
+    for iters in (1, 2, 15, 16, 17, 31, 32, 33, 50):
+        it0, rn0, x_plain = solve("0", iters, 0.0)
+        it1, rn1, x_def = solve("2", iters, 0.0)
+        assert it0 == it1 == iters and rn0 == rn1
+        assert np.array_equal(x_plain, x_def), iters
+    exp, it_o, rn_o = oracle.pcg(rp, col, val, b, x0, 1, 0.0, 33)
+    assert np.abs(solve("2", 33, 0.0)[2] - exp).max() <= RTOL_CG * np.abs(exp).max()
+    for rtol in (1e-3, 1e-6, 1e-10):
+        it0, rn0, x_plain = solve("0", n, rtol)
+        it1, rn1, x_def = solve("2", n, rtol)
+        assert it0 == it1 and rn0 == rn1 and it0 < n
+        assert np.array_equal(x_plain, x_def), rtol
