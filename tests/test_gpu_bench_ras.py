@@ -255,3 +255,24 @@ def test_mirror_int64_index_instantiations(oracle, types):
     assert ref["converged"] and it == ref["iter_count"], out
     ref_norm = float(np.linalg.norm(ref["solution"]))
     assert abs(norm - ref_norm) <= 1e-10 * ref_norm
+
+
+def test_bench_ras_onesided_rma_flavour_flags(oracle):
+    """The reference's MPI RMA flavours (put instead of get, one message per value, local flush,
+    local lock: bench_ras.cpp:73-97) and its default convergence type (centralized-tree) select
+    calls, not values: the one-sided iteration is the same one."""
+    n, P = 32, 3
+    rp, col, val = oracle.laplacian2d(n)
+    N = n * n
+    ref = oracle.ras_run(rp, col, val, np.ones(N), P, oracle.first_rows_regular(N, P),
+                         oracle.make_settings(max_iters=600, tol=1e-6, enable_onesided=1))
+    assert ref["converged"]
+    base = ["--explicit_laplacian", "--set_1d_laplacian_size=%d" % n, "--num_iters=600", "--set_tol=1e-6",
+            "--enable_onesided"]
+    for extra in ([], ["--remote_comm_type=put", "--enable_one_by_one", "--flush_type=flush-local",
+                       "--lock_type=lock-local"]):
+        out = _run(P, *(base + extra))
+        iters = sorted(set(int(x) for x in re.findall(r"converged in (\d+) iterations", out)))
+        assert iters == [ref["iter_count"]], out
+        rel = float(re.search(r"relative residual norm of solution ([0-9.eE+-]+)", out).group(1))
+        assert abs(rel - ref["residual_norm"] / ref["rhs_norm"]) <= 1e-6 * rel + 1e-12
