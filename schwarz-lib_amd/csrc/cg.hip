@@ -576,7 +576,9 @@ static int pcg_build(schwz_pcg *s, const schwz_csr *A, int precond)
             if (ok && dict.size() == 1) {
                 s->diag.mode = 3;
                 s->diag.uniform = dict[0];
-            } else if (ok && dict.size() <= 16) {  // linear search above stays cheap
+            } else if (ok && dict.size() <= 16 && !A->v.pair_id) {  // linear search above stays cheap
+                // (row-pair coded matrices keep the full vector: their q-free iteration reads it as
+                // such and beats the stored-q iteration the codes would select)
                 int rc;
                 if ((rc = upload(code.data(), code.size(), &s->d_dcode)) ||
                     (rc = upload(dict.data(), dict.size(), &s->d_ddict)))

@@ -444,11 +444,9 @@ def test_coded_tiles_are_bit_identical_to_plain_csr(schwz, oracle, torch_cuda, m
 @pytest.mark.parametrize("nvalues", [1, 5, 40])
 def test_qfree_cg_with_every_diagonal_representation(schwz, oracle, torch_cuda, monkeypatch, nvalues):
     """The q-free CG iteration of row-pair coded matrices (q = A p recomputed inside the update
-    launch) with the Jacobi diagonal as a scalar (1 distinct value), as the full vector (40
-    values: no dictionary) and -- 5 values: dictionary codes, which the fused launch does not
-    take -- through the stored-q iteration; each against the oracle and against the stored-q
-    iteration forced by SCHWZ_CG_QFREE=0 in a fresh process-independent way (same library, the
-    switch is read once, so the comparison is made through the oracle tolerance)."""
+    launch) with the Jacobi diagonal as a scalar (1 distinct value) and as the full vector (5 or
+    40 values: a pair-coded matrix never gets 1-byte diagonal codes, which would select the
+    slower stored-q iteration); each against the oracle."""
     torch = torch_cuda
     rp, col, val = oracle.laplacian3d(40, 40, 40)
     n = len(rp) - 1
@@ -585,8 +583,10 @@ def test_symmetric_matrices_take_the_dot_from_the_upper_triangle(schwz, oracle, 
 def test_pcg_diagonal_representations_agree(schwz, oracle, torch_cuda, monkeypatch, nshift):
     """Jacobi 1/diag as a scalar (1 distinct value), as 1-byte codes into a dictionary (3), or as
     the full vector (40 distinct -> no coding): identical bits to the forced full-vector run, and
-    the oracle's iterates within tolerance.  n is odd to exercise the tail element."""
+    the oracle's iterates within tolerance.  n is odd to exercise the tail element.  Row-pair
+    coding is switched off: pair-coded matrices always keep the full vector."""
     torch = torch_cuda
+    monkeypatch.setenv("SCHWZ_SPMV_PAIR", "0")
     rp, col, val = oracle.laplacian2d(21)  # 441 rows
     n = len(rp) - 1
     val = val.copy()
