@@ -115,6 +115,12 @@ def cpu_baseline(shape, inner, iters):
 
 def main():
     a = parse()
+    # stdout carries the one JSON line and nothing else: libraries that print to the C-level stdout
+    # (RCCL writes its version banner there when the first communicator comes up, on every rank) are
+    # pointed at stderr until the line is written
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import schwz_amd as schwz
     N = a.gpus
@@ -357,8 +363,9 @@ def main():
         del s2
     if rank == 0 and N == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(shape, a.inner, a.cpu_iters)
+    sys.stdout.flush()
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         comm.barrier()
