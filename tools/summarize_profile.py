@@ -69,7 +69,14 @@ def main():
                              source=tag + "_summary.json",
                              note="(2*FETCH_SIZE + WRITE_SIZE) KiB per launch, separate --pmc passes")
     if ent:
-        json.dump({key: ent}, open(tpath, "w"), indent=1, sort_keys=True)
+        allent = {}
+        if os.path.exists(tpath):  # one entry per grid shape: keep the others
+            try:
+                allent = json.load(open(tpath))
+            except Exception:
+                allent = {}
+        allent[key] = ent
+        json.dump(allent, open(tpath, "w"), indent=1, sort_keys=True)
     for k, v in sorted(summary.items(), key=lambda kv: -kv[1]["pct"])[:8]:
         print("%-60s calls %4d avg %9.1f us  hbm %s" % (
             k[:60], v["calls"], v["avg_ns"] / 1e3,
