@@ -70,6 +70,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
     constexpr bool kDotOnly = MODE == kSpmvDotOnly || kSym;
     __shared__ int pmask[kPairEntries / CH];  // per group of CH entries: bit k = row r has entry k, bit 8+k = row r+1
     __shared__ int plen[kPairPats];            // length | (a gathered entry has col - row == 0) << 16
+    __shared__ int pmin[kPairPats], pmax[kPairPats];  // smallest / largest col - row the pattern gathers at
     if (MODE == kSpmvDot || MODE == kSpmvResidInit || kDotOnly) {
         if (a.stop_iter && a.it >= *a.stop_iter) return;
     }
@@ -97,14 +98,13 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
     const bool dual = (MODE == kSpmvResidDual) && a.x2 != nullptr;
     constexpr bool kWantOwn = MODE == kSpmvDot || kDotOnly || MODE == kSpmvCgUpdate;  // x[row] itself
-    int cached = -1, ls = 0, reach = 0;  // staged table, its row stride, its largest |col - row|
+    int cached = -1, ls = 0;  // staged table, its row stride
 
     auto stage_table = [&](int tb) {  // workgroup-uniform
         const int td = kSym ? A.pair_sym_base + tb : tb;
         const int eoff = A.ptbl_desc[5 * td], loff = A.ptbl_desc[5 * td + 1];
         const int npat = A.ptbl_desc[5 * td + 2], lmax = A.ptbl_desc[5 * td + 3];
         ls = pair_stride(lmax, CH);
-        reach = A.ptbl_desc[5 * td + 4];
         lds_barrier();  // everyone is done with the previous table
         for (int i = tid; i < npat * ls; i += kBlock) {
             const int pt = i / ls, k = i - pt * ls;
@@ -133,9 +133,16 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
         if (tid < npat) {
             // does a gather of this pattern (padding included) fetch x[r], x[r + 1] themselves?
             const int len = A.ptbl_len[loff + tid];
-            int zero = 0;
-            for (int k = 0; k < pair_stride(len, CH); ++k) zero |= poff[tid * ls + k] == 0;
+            int zero = 0, mn = 0, mx = 0;  // the padding entries gather at offset 0
+            for (int k = 0; k < pair_stride(len, CH); ++k) {
+                const int off = poff[tid * ls + k];
+                zero |= off == 0;
+                mn = min(mn, off);
+                mx = max(mx, off);
+            }
             plen[tid] = len | (zero << 16);
+            pmin[tid] = mn;
+            pmax[tid] = mx;
         }
         lds_barrier();
         cached = tb;
@@ -151,9 +158,9 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
         }
         return t;
     };
-    // Both rows' dot products with xv.  `safe`: some lane of the wave sits within `reach` rows of the
-    // first or last column, where a 16-byte load could leave the vector: those waves load each
-    // operand that exists on its own.
+    // Both rows' dot products with xv.  `safe`: some lane of the wave has a pattern whose 16-byte
+    // gathers could leave the vector (first / last column): those waves load each operand that
+    // exists on its own.
     auto accumulate = [&](const double *xv, int ra, int base, int len, bool safe, double &s0, double &s1,
                           pvd2 &own, bool want_own) {
         for (int j = 0; j < len; j += CH) {
@@ -339,7 +346,11 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
             const int lenz = plen[pid];
             const int len = lenz & 0xffff;
             const int base = pid * ls;
-            const bool edge = ra < reach || ra + 1 + reach >= (int)A.ncols;
+            // a 16-byte gather at offset d reads x[ra + d] and x[ra + d + 1] whether or not both rows have
+            // the entry: the lane is an edge lane when that could leave [0, ncols) for ITS pattern (a
+            // subdomain's overlap rows sit at the end of the local numbering, so a table-wide bound
+            // would send every wave of an interior subdomain down the safe path)
+            const bool edge = ra + pmin[pid] < 0 || ra + 1 + pmax[pid] >= (int)A.ncols;
             const bool safe = __builtin_amdgcn_ballot_w64(edge) != 0;
             // the fused dot needs x[ra], x[ra + 1]: the padding entries (col - row = 0) gather exactly
             // that pair, as does a diagonal entry; waves on the safe path load it themselves
