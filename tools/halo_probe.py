@@ -15,7 +15,8 @@ import bench  # noqa: E402
 
 for P in ([int(t) for t in sys.argv[1].split(',')] if len(sys.argv) > 1 else (1, 2, 4)):
     comm = S.InProcessComm(P)
-    solver, m = bench.make_solver(S, comm, (512, 512, 64 * P), 10, 1e-30, 100, 0.0, 0)
+    solver, m = bench.make_solver(S, comm, (512, 512, 64 * P), 10, 1e-30, 100, 0.0, 0,
+                                  overlapped=os.environ.get("HALO_PROBE_OVERLAPPED") == "1")
     solver.begin_run()
     for _ in range(3):
         solver.step()
