@@ -724,6 +724,12 @@ int pcg_begin(schwz_pcg *s, const double *d_b, double *d_x, double rtol, bool fu
     // x2 == x over all rows: the check residual IS the start residual (rr bank)
     const bool same = fused && d_x2 == nullptr && row_limit >= s->n;
     if (pcg_is_general(s)) a.dinv = nullptr;  // p := r for now, z follows
+    if (!pcg_is_general(s) && A.pair_id && s->variant == 0 && s->diag.mode == 3) {
+        // row-pair kernel: a uniform Jacobi diagonal travels as a scalar, not as a vector of n equal values
+        a.dinv = nullptr;
+        a.diag_mode = 3;
+        a.diag_uniform = s->diag.uniform;
+    }
     int rc = launch_spmv(A, (fused && !same) ? kSpmvResidDual : kSpmvResidInit, a, s->variant, st);
     if (rc) return rc;
     if (pcg_is_general(s)) {

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
             acc1 += r * r;
         } else if (MODE == kSpmvResidInit || MODE == kSpmvResidDual) {
             const double r = ob - sum;
-            const double z = a.dinv ? od * r : r;
+            const double z = (a.dinv || a.diag_mode == 3) ? od * r : r;
             yv = r;
             pz = z;
             acc0 += r * z;
@@ -304,13 +304,32 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
         const bool has_b = ra + 1 < nrows;
         // own operands of the fused epilogues, requested ahead of the gathers
         double ob0 = 0.0, ob1 = 0.0, od0 = 1.0, od1 = 1.0;
-        if (MODE == kSpmvResidInit || MODE == kSpmvResidDual || MODE == kSpmvResidNorm) {
-            if (MODE != kSpmvResidNorm || ra < a.row_limit) ob0 = a.b[ra];
-            if (has_b && (MODE != kSpmvResidNorm || ra + 1 < a.row_limit)) ob1 = a.b[ra + 1];
+        if (MODE == kSpmvResidNorm) {
+            if (ra < a.row_limit) ob0 = a.b[ra];
+            if (has_b && ra + 1 < a.row_limit) ob1 = a.b[ra + 1];
         }
-        if ((MODE == kSpmvResidInit || MODE == kSpmvResidDual) && a.dinv) {
-            od0 = a.dinv[ra];
-            if (has_b) od1 = a.dinv[ra + 1];
+        if (MODE == kSpmvResidInit || MODE == kSpmvResidDual) {
+            // b and 1/diag only stream through: one 16-byte non-temporal load each (the caller's b
+            // need not be 16-byte aligned), so that they do not push the gathered x lines out of L2
+            typedef double pvd2u __attribute__((ext_vector_type(2), aligned(8)));
+            if (has_b) {
+                const pvd2u bb = __builtin_nontemporal_load(reinterpret_cast<const pvd2u *>(a.b + ra));
+                ob0 = bb.x;
+                ob1 = bb.y;
+            } else {
+                ob0 = a.b[ra];
+            }
+            if (a.diag_mode == 3) {
+                od0 = od1 = a.diag_uniform;
+            } else if (a.dinv) {
+                if (has_b) {
+                    const pvd2u dd = __builtin_nontemporal_load(reinterpret_cast<const pvd2u *>(a.dinv + ra));
+                    od0 = dd.x;
+                    od1 = dd.y;
+                } else {
+                    od0 = a.dinv[ra];
+                }
+            }
         }
         if (MODE == kSpmvPlain && a.beta != 0.0) {
             ob0 = a.y[ra];
@@ -391,7 +410,10 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
         } else if (MODE != kSpmvResidNorm && !kDotOnly) {
             if (has_b) {
                 const pvd2 yy = {y0, y1};
-                __builtin_memcpy(a.y + ra, &yy, 16);
+                if (MODE == kSpmvResidInit || MODE == kSpmvResidDual)  // r of the CG start: written once, read much later
+                    __builtin_nontemporal_store(yy, reinterpret_cast<pvd2 *>(a.y + ra));
+                else
+                    __builtin_memcpy(a.y + ra, &yy, 16);
             } else {
                 a.y[ra] = y0;
             }
@@ -399,7 +421,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
         if (MODE == kSpmvResidInit || MODE == kSpmvResidDual) {
             if (has_b) {
                 const pvd2 pp = {p0, p1};
-                __builtin_memcpy(a.p + ra, &pp, 16);
+                __builtin_nontemporal_store(pp, reinterpret_cast<pvd2 *>(a.p + ra));
             } else {
                 a.p[ra] = p0;
             }
