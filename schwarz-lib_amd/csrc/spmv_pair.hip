@@ -351,8 +351,13 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
                 if (a.cg_x) cgx.x = a.cg_x[ra];
             }
             if (a.diag_mode == 1) {
-                od0 = a.dinv[ra];
-                if (has_b) od1 = a.dinv[ra + 1];
+                if (has_b) {
+                    const pvd2 dd = __builtin_nontemporal_load(reinterpret_cast<const pvd2 *>(a.dinv + ra));
+                    od0 = dd.x;
+                    od1 = dd.y;
+                } else {
+                    od0 = a.dinv[ra];
+                }
             } else if (a.diag_mode == 3) {
                 od0 = od1 = a.diag_uniform;
             }
