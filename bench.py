@@ -354,7 +354,7 @@ def main():
     if not a.no_ttr:
         del solver
         torch.cuda.empty_cache()
-        s2, m2 = make_solver(schwz, comm, shape, 70, 1e-6, 2000, 0.1, a.spmv_variant)
+        s2, m2 = make_solver(schwz, comm, shape, 70, 1e-6, 3000, 0.1, a.spmv_variant)
         out = s2.run(gather_solution=False)
         line["time_to_residual_1e-6_s"] = out["elapsed"]
         line["time_to_residual_iters"] = out["iter_count"]
