@@ -646,3 +646,28 @@ def test_deferred_x_update_is_bit_identical(schwz, oracle, torch_cuda, monkeypat
         it1, rn1, x_def = solve("2", n, rtol)
         assert it0 == it1 and rn0 == rn1 and it0 < n
         assert np.array_equal(x_plain, x_def), rtol
+
+
+def test_pcg_accepts_a_right_hand_side_that_is_only_8_byte_aligned(schwz, oracle, torch_cuda):
+    """The CG start residual reads b with 16-byte loads; the caller's b need only be aligned like
+    a double (x must be 16-byte aligned, which the entry point checks)."""
+    torch = torch_cuda
+    rp, col, val = oracle.laplacian3d(24, 24, 24)
+    n = len(rp) - 1
+    rng = np.random.default_rng(3)
+    b = rng.standard_normal(n)
+    A = schwz.Csr(rp, col, val)
+    cg = schwz.Pcg(A, 1)
+    res = []
+    for shift in (0, 1):
+        buf = torch.zeros(n + 2, dtype=torch.float64, device="cuda")
+        view = buf[shift:shift + n]
+        view.copy_(torch.from_numpy(b))
+        assert view.data_ptr() % 16 == 8 * shift
+        d_x = torch.zeros(n, dtype=torch.float64, device="cuda")
+        it, rn = cg.solve(view.data_ptr(), d_x.data_ptr(), 0.0, 20)
+        res.append((d_x.cpu().numpy(), rn))
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
+    with pytest.raises(schwz.capi.SchwzError):
+        d_x = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
+        cg.solve(buf.data_ptr(), d_x[1:].data_ptr(), 0.0, 2)
