@@ -671,3 +671,63 @@ def test_pcg_accepts_a_right_hand_side_that_is_only_8_byte_aligned(schwz, oracle
     with pytest.raises(schwz.capi.SchwzError):
         d_x = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
         cg.solve(buf.data_ptr(), d_x[1:].data_ptr(), 0.0, 2)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_pair_coding_on_random_banded_matrices(schwz, oracle, torch_cuda, monkeypatch, seed):
+    """Random banded matrices (random sets of diagonals, some reaching almost across the whole
+    matrix, piecewise constant values so that pair tables exist, rows near both ends losing the
+    entries that fall outside): the row-pair SpMV against plain CSR bit for bit, and the q-free
+    CG (symmetric and not quite symmetric values, i.e. with and without the upper-triangle
+    tables) against the oracle.  Exercises the per-pattern decision between 16-byte gathers and
+    the element-wise path at the ends of the vector."""
+    import scipy.sparse as sp
+    torch = torch_cuda
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(700, 6000))
+    if seed % 3 == 0:
+        n |= 1   # odd sizes: the last pair has one row
+    nd = int(rng.integers(1, 5))
+    offs = sorted(set(int(o) for o in np.concatenate([rng.integers(1, 40, nd), rng.integers(1, n - 1, 2)])))
+    blocks = (np.arange(n) // 512) % 3
+    diags, offsets = [], []
+    for o in offs:
+        v = -(0.2 + 0.1 * ((blocks[:n - o] + o) % 3))
+        diags += [v, v]
+        offsets += [o, -o]
+    M = sp.diags(diags, offsets, shape=(n, n), format="csr")
+    d = np.asarray(abs(M).sum(axis=1)).ravel() + 1.0 + 0.5 * blocks
+    M = (M + sp.diags(d)).tocsr()
+    M.sort_indices()
+    symmetric = seed % 2 == 0
+    val = M.data.copy()
+    if not symmetric:
+        val[int(M.indptr[n // 2]) + 0] *= 1.0 + 2.0 ** -30   # one entry off its mirror image
+    rp, col = M.indptr.astype(np.int32), M.indices.astype(np.int32)
+    monkeypatch.setenv("SCHWZ_SPMV_PATTERN", "2")
+    monkeypatch.setenv("SCHWZ_SPMV_PAIR", "2")
+    monkeypatch.setenv("SCHWZ_DIAG_DICT", "0")
+    A = schwz.Csr(rp, col, val)
+    assert A.format() == 3
+    assert col[M.indptr[n // 2]] != n // 2   # the perturbed entry is an off-diagonal one
+    assert A.symmetric() == symmetric
+    x = _dev(torch, rng.standard_normal(n))
+    y0 = torch.zeros(n, dtype=torch.float64, device="cuda")
+    y6 = torch.zeros(n, dtype=torch.float64, device="cuda")
+    A.spmv(x.data_ptr(), y0.data_ptr(), 1.0, 0.0, 0)
+    A.spmv(x.data_ptr(), y6.data_ptr(), 1.0, 0.0, 6)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y6)
+    exp = oracle.spmv(rp, col, val, x.cpu().numpy())
+    assert np.abs(y0.cpu().numpy() - exp).max() <= 1e-12 * max(np.abs(exp).max(), 1.0)
+    b = rng.standard_normal(n)
+    x0 = 0.1 * rng.standard_normal(n)
+    for mode in ("0", "2"):   # x updated inside the iteration / deferred
+        monkeypatch.setenv("SCHWZ_CG_DEFERX", mode)
+        cg = schwz.Pcg(A, 1)
+        d_b, d_x = _dev(torch, b), _dev(torch, x0)
+        it, rn = cg.solve(d_b.data_ptr(), d_x.data_ptr(), 0.0, 15)
+        ex, it_o, rn_o = oracle.pcg(rp, col, val, b, x0, 1, 0.0, 15)
+        assert it == it_o == 15
+        assert np.abs(d_x.cpu().numpy() - ex).max() <= RTOL_CG * np.abs(ex).max()
+        assert abs(rn - rn_o) <= 1e-8 * max(rn_o, 1e-300)
