@@ -29,6 +29,15 @@ public:
     // halo index lists and uploads everything (schwarz_base.cpp:128-271)
     void initialize();
 
+    // Extension: the global system handed over as host CSR arrays (+ right-hand side, ones when
+    // null), the same on every rank -- what the reference's deal.II overload does with
+    // dealii::SparseMatrix / Vector (include/schwarz_base.hpp:96-97, source/schwarz_base.cpp:128-160)
+    // without the deal.II types.  Rows must have ascending columns.  With a permuting partition
+    // (regular2d / metis) rows are renumbered like for a matrix read from file;
+    // metadata.permutation maps new to old.
+    void initialize(IndexType num_rows, const IndexType *row_ptrs, const IndexType *col_idxs,
+                    const ValueType *values, const ValueType *rhs = nullptr);
+
     // the outer RAS loop (schwarz_base.cpp:323-506); `solution` is allocated if null and filled
     // on rank 0
     void run(std::shared_ptr<gko::matrix::Dense<ValueType>> &solution);

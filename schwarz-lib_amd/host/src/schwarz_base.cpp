@@ -102,6 +102,11 @@ struct SchwarzBase<ValueType, IndexType, MixedValueType>::Impl {
     hipStream_t stream = nullptr;
     int device = 0;
     double rhs_sq_interior = 0.0;
+    // initialize(num_rows, row_ptrs, ...): the caller's system, copied
+    bool have_user = false;
+    std::vector<int64_t> user_rp;
+    std::vector<schwz_idx> user_col;
+    std::vector<double> user_val, user_rhs;
     ncclComm_t nccl = nullptr;  // halo exchange over RCCL; nullptr: staged through host over MPI
     hipStream_t side = nullptr;  // overlapped mode: the halo transfers run here, beside the local solve
     hipEvent_t ev_packed = nullptr, ev_arrived = nullptr;
@@ -160,6 +165,23 @@ template <typename V, typename I, typename M>
 SchwarzBase<V, I, M>::~SchwarzBase() = default;
 
 template <typename V, typename I, typename M>
+void SchwarzBase<V, I, M>::initialize(I num_rows, const I *row_ptrs, const I *col_idxs, const V *values, const V *rhs)
+{
+    auto &im = *impl_;
+    if (num_rows < 0 || !row_ptrs || (num_rows > 0 && (!col_idxs || !values)))
+        throw ::BadDimension(__FILE__, __LINE__, "initialize", "null or negative CSR input");
+    const size_t n = (size_t)num_rows, nnz = (size_t)row_ptrs[n];
+    im.user_rp.assign(row_ptrs, row_ptrs + n + 1);
+    im.user_col.resize(nnz);
+    for (size_t j = 0; j < nnz; ++j) im.user_col[j] = (schwz_idx)col_idxs[j];
+    im.user_val.assign(values, values + nnz);
+    im.user_rhs.clear();
+    if (rhs) im.user_rhs.assign(rhs, rhs + n);
+    im.have_user = true;
+    initialize();
+}
+
+template <typename V, typename I, typename M>
 void SchwarzBase<V, I, M>::initialize()
 {
     auto &m = metadata;
@@ -205,7 +227,14 @@ void SchwarzBase<V, I, M>::initialize()
     // ---- Initialize::setup_global_matrix (initialization.cpp:197-272) ----------------------
     // extension: "--matrix_filename=poisson3d:NX[xNYxNZ]" or SCHWZ_LAPLACIAN_DIM=3 select the 3-D
     // 7-point generator (the reference only has the 2-D one)
-    if (s.matrix_filename.rfind("poisson3d:", 0) == 0) {
+    if (im.have_user) {
+        SCHWZ_CALL(schwz_problem_from_csr((int64_t)im.user_rp.size() - 1, im.user_rp.data(), im.user_col.data(),
+                                          im.user_val.data(), &im.problem));
+        if (me == 0) std::cout << "Matrix handed over by the caller " << std::endl;
+        std::vector<int64_t>().swap(im.user_rp);
+        std::vector<schwz_idx>().swap(im.user_col);
+        std::vector<double>().swap(im.user_val);
+    } else if (s.matrix_filename.rfind("poisson3d:", 0) == 0) {
         long long nx = 0, ny = 0, nz = 0;
         std::string spec = s.matrix_filename.substr(10);
         for (auto &ch : spec)
@@ -326,6 +355,15 @@ void SchwarzBase<V, I, M>::initialize()
         std::vector<int64_t> l2g((size_t)(im.sizes[1] + im.sizes[3]));
         SCHWZ_CALL(schwz_subdomain_local_to_global(im.sd, l2g.data()));
         SCHWZ_CALL(schwz_rhs_random((int64_t)rhs.size(), l2g.data(), rhs.data()));
+    }
+    if (im.have_user && !im.user_rhs.empty()) {
+        // the caller's right-hand side by global row id (old numbering under a permuting partition)
+        std::vector<int64_t> l2g((size_t)(im.sizes[1] + im.sizes[3]));
+        SCHWZ_CALL(schwz_subdomain_local_to_global(im.sd, l2g.data()));
+        for (size_t i = 0; i < rhs.size(); ++i) {
+            const int64_t g = l2g[i];
+            rhs[i] = im.user_rhs[(size_t)(m.permutation.empty() ? g : (int64_t)m.permutation[(size_t)g])];
+        }
     }
     im.rhs_sq_interior = 0.0;
     for (gko::size_type i = 0; i < m.local_size; ++i) im.rhs_sq_interior += rhs[i] * rhs[i];

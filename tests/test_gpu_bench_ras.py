@@ -202,14 +202,14 @@ def test_bench_ras_authors_iterative_study_settings(oracle):
 TYPES_BIN = os.path.join(ROOT, "schwarz-lib_amd", "build", "ras_types_driver")
 
 
-def _run_types(nranks, types, n, mixed, overlapped, tol, max_iters, env=None):
+def _run_types(nranks, types, n, mixed, overlapped, tol, max_iters, env=None, extra=()):
     """tests/drivers/ras_types_driver.cpp: the mirror's other template instantiations."""
     if not os.path.exists(TYPES_BIN):
         pytest.skip("ras_types_driver not built (`make -C schwarz-lib_amd types_driver`, needs MPI)")
     if not os.path.exists(MPIEXEC):
         pytest.skip("no mpiexec on this machine")
     cmd = [MPIEXEC, "-n", str(nranks), TYPES_BIN, types, str(n), str(int(mixed)), str(int(overlapped)),
-           repr(tol), str(max_iters)]
+           repr(tol), str(max_iters)] + list(extra)
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, **(env or {})))
     assert p.returncode == 0, p.stdout + p.stderr
     res = re.search(r"RESULT iters=(\d+) solnorm=([0-9.eE+-]+)", p.stdout)
@@ -276,3 +276,23 @@ def test_bench_ras_onesided_rma_flavour_flags(oracle):
         assert iters == [ref["iter_count"]], out
         rel = float(re.search(r"relative residual norm of solution ([0-9.eE+-]+)", out).group(1))
         assert abs(rel - ref["residual_norm"] / ref["rhs_norm"]) <= 1e-6 * rel + 1e-12
+
+
+@pytest.mark.parametrize("types", ["d32d", "d64d"])
+def test_mirror_initialize_from_csr_arrays(oracle, types):
+    """initialize(num_rows, row_ptrs, col_idxs, values, rhs): the caller's CSR system and right-hand
+    side (the deal.II-free analogue of the reference's initialize(dealii::SparseMatrix, Vector),
+    include/schwarz_base.hpp:96-97), for both index types, against the oracle on the same system."""
+    n, P = 24, 3
+    rp, col, val = oracle.laplacian2d(n)
+    N = n * n
+    rhs = 1.0 + (np.arange(N) % 7)
+    ref = oracle.ras_run(rp, col, val, rhs, P, oracle.first_rows_regular(N, P),
+                         oracle.make_settings(max_iters=500, tol=1e-8))
+    it, norm, out = _run_types(P, types, n, False, False, 1e-8, 500, extra=("csr",))
+    assert "Matrix handed over by the caller" in out
+    assert ref["converged"] and it == ref["iter_count"], out
+    ref_norm = float(np.linalg.norm(ref["solution"]))
+    assert abs(norm - ref_norm) <= 1e-10 * ref_norm
+    rel = float(re.search(r"relative residual norm of solution ([0-9.eE+-]+)", out).group(1))
+    assert abs(rel - ref["residual_norm"] / ref["rhs_norm"]) <= 1e-6 * rel + 1e-12
