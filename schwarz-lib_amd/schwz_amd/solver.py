@@ -216,6 +216,7 @@ class SolverRAS:
                 capi.ERR_NOT_IMPLEMENTED,
                 "executor '%s' is not available: only 'hip' (MI355X) exists and there is "
                 "no CPU fallback" % settings.executor_string)
+        self._user_matrix, self._user_rhs = None, None
         self.comm = comm if comm is not None else InProcessComm(max(metadata.num_subdomains, 1))
         self.backend = backend if backend is not None else HipBackend(
             getattr(self.comm, "device_index", 0))
@@ -235,7 +236,10 @@ class SolverRAS:
     def _setup_global_matrix(self):
         """Initialize::setup_global_matrix (initialization.cpp:197-272)."""
         s, m, be = self.settings, self.metadata, self.backend
-        if s.matrix_filename != "null":
+        if self._user_matrix is not None:
+            prob = be.problem_from_csr(*self._user_matrix)
+            self._print("Matrix handed over by the caller ")
+        elif s.matrix_filename != "null":
             prob = be.problem_from_matrix_market(s.matrix_filename)
             self._print("Matrix from file " + s.matrix_filename)
         elif s.explicit_laplacian:
@@ -283,15 +287,25 @@ class SolverRAS:
     def _rhs(self, ids):
         """rhs = 1.0, or the default-seeded uniform(0,1) sequence when enable_random_rhs is set
         together with explicit_laplacian (schwarz_base.cpp:169-173, initialization.cpp:88-96).
-        As in the reference the rhs is indexed by the (possibly permuted) row id."""
+        As in the reference the rhs is indexed by the (possibly permuted) row id.  A right-hand
+        side handed to initialize() is indexed by the caller's (old) row id."""
+        if self._user_rhs is not None:
+            perm = self.metadata.permutation
+            ids = np.asarray(ids, dtype=np.int64)
+            return self._user_rhs[ids if perm is None else np.asarray(perm, dtype=np.int64)[ids]]
         if self.settings.enable_random_rhs and self.settings.explicit_laplacian \
                 and self.settings.matrix_filename == "null":
             return core.rhs_random(ids)
         return np.ones(len(ids), dtype=np.float64)
 
-    def initialize(self):
-        """SchwarzBase::initialize (schwarz_base.cpp:128-271)."""
+    def initialize(self, matrix=None, rhs=None):
+        """SchwarzBase::initialize (schwarz_base.cpp:128-271).  `matrix` = (row_ptr, col, val) of
+        the global system and `rhs` (ones when None), the same on every rank: the analogue of
+        the reference's initialize(dealii::SparseMatrix, dealii::Vector) overload
+        (include/schwarz_base.hpp:96-97) for callers that assemble their own system."""
         s, m, be, comm = self.settings, self.metadata, self.backend, self.comm
+        self._user_matrix = matrix
+        self._user_rhs = None if rhs is None else np.ascontiguousarray(rhs, dtype=np.float64)
         solver_code = _local_solver_code(s)
         precond_code = _precond_code(m)
         if s.non_symmetric_matrix and solver_code != capi.SOLVER_ITERATIVE:

@@ -580,3 +580,39 @@ def test_enable_logging_records_inner_iterations(schwz, oracle, torch_cuda):
     assert got.shape[0] == out["iter_count"] and np.abs(got - exp).max() <= 1
     assert len(m.post_process_data["local_timestamp"]) == got.size
     assert all(r > 0 for r in m.post_process_data["local_converged_resnorm"])
+
+
+@pytest.mark.parametrize("partition", ["regular", "metis"])
+def test_initialize_from_csr_arrays_and_rhs(schwz, oracle, torch_cuda, partition):
+    """SolverRAS.initialize(matrix=(rp, col, val), rhs=...): the caller's system instead of a file
+    or the generator (the analogue of the reference's deal.II overload).  With a permuting
+    partition the right-hand side follows the rows: compared with the oracle run on the permuted
+    system with the permuted right-hand side, and with a direct solve of the original system."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    n, P = 20, 3
+    rp, col, val = oracle.laplacian2d(n)
+    N = n * n
+    rhs = 1.0 + (np.arange(N) % 5) + 0.25 * np.sin(np.arange(N))
+    s = schwz.Settings(partition=schwz.PARTITION_METIS if partition == "metis" else schwz.PARTITION_REGULAR,
+                       explicit_laplacian=False)
+    s.convergence_settings.enable_global_check = True
+    m = schwz.Metadata(num_subdomains=P, tolerance=1e-9, max_iters=600)
+    solver = schwz.SolverRAS(s, m, comm=schwz.InProcessComm(P), quiet=True)
+    solver.initialize(matrix=(rp, col, val), rhs=rhs)
+    out = solver.run()
+    assert out["converged"]
+    perm = None if m.permutation is None else np.asarray(m.permutation, dtype=np.int64)
+    A = sp.csr_matrix((val, col, rp), shape=(N, N))
+    x_direct = spla.spsolve(A.tocsc(), rhs)
+    sol = np.asarray(out["solution"])
+    x_old = sol if perm is None else np.empty(N)
+    if perm is not None:
+        x_old[perm] = sol          # entry `new` of the solution belongs to row perm[new] of the caller
+    assert np.abs(x_old - x_direct).max() <= 1e-6 * np.abs(x_direct).max()
+    assert abs(out["rhs_norm"] - np.linalg.norm(rhs)) <= 1e-12 * np.linalg.norm(rhs)
+    if perm is None:
+        ref = oracle.ras_run(rp, col, val, rhs, P, np.asarray(m.first_row, dtype=np.int32),
+                             _oracle_settings(oracle, m, s))
+        assert ref["converged"] and ref["iter_count"] == out["iter_count"]
+        assert np.abs(sol - ref["solution"]).max() <= TOL_SOL * np.abs(ref["solution"]).max()
