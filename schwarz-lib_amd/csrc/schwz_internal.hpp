@@ -78,6 +78,10 @@ struct CsrView {
     // row-pair pattern coding (spmv_pair.hip): one byte per PAIR of adjacent rows selects a merged
     // (col - row, value of row r, value of row r+1, presence bits) sequence
     const uint8_t *pair_id = nullptr;        // (nrows + 1) / 2: pattern of rows (2i, 2i + 1)
+    // the same ids run-length coded per chunk: 8 x (first pair of the run | id << 8), 16 bytes a chunk
+    // read with one wave-uniform load instead of one byte per lane; first word 0xffff: more than 8
+    // runs, the chunk's ids come from pair_id (nullptr: not built)
+    const uint4 *pair_rle = nullptr;
     const schwz_idx *chunk_ptable = nullptr; // per chunk of 512 rows: pair table id, -1 = not pair coded
     const uint8_t *chunk_dual = nullptr;     // per chunk: the fused dual residual needs its second product
     int pair_shift = 0;                      // log2 of the run length of the XCD deal of the chunks
@@ -222,6 +226,7 @@ struct schwz_csr {
     void *d_code = nullptr, *d_vptr = nullptr, *d_dptr = nullptr, *d_vdict = nullptr, *d_ddict = nullptr;
     void *d_pat_id = nullptr, *d_tile_table = nullptr, *d_tbl_desc = nullptr, *d_tbl_len = nullptr, *d_tbl_val = nullptr,
          *d_tbl_delta = nullptr;
+    void *d_pair_rle = nullptr;
     void *d_pair_id = nullptr, *d_tile_ptable = nullptr, *d_ptbl_desc = nullptr, *d_ptbl_len = nullptr,
          *d_ptbl_val = nullptr, *d_ptbl_meta = nullptr, *d_chunk_dual = nullptr;
     void *d_tile_dual = nullptr;

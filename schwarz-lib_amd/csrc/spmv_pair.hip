@@ -366,7 +366,31 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
         pvd2 own = {0.0, 0.0};
         bool own_from_gathers = false;
         if (tb >= 0) {
-            const int pid = A.pair_id[ra >> 1];
+            int pid;
+            uint4 rle = {0xffffu, 0u, 0u, 0u};
+            if (A.pair_rle) {
+                // chunk is workgroup-uniform and the table is never written by a kernel: read it through
+                // the constant address space, i.e. with a scalar load that costs no vector-memory slot
+                typedef const unsigned __attribute__((address_space(4))) *const_words;
+                const const_words q = (const_words)(uintptr_t)(A.pair_rle + chunk);
+                rle.x = q[0];
+                rle.y = q[1];
+                rle.z = q[2];
+                rle.w = q[3];
+            }
+            if ((rle.x & 0xffffu) != 0xffffu) {
+                // the id of the last run that starts at or before this lane's pair (runs ascending,
+                // unused slots repeat the last run)
+                const unsigned w[4] = {rle.x, rle.y, rle.z, rle.w};
+                pid = (int)((w[0] >> 8) & 0xffu);
+#pragma unroll
+                for (int k = 1; k < 8; ++k) {
+                    const unsigned e = (w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+                    if ((unsigned)tid >= (e & 0xffu)) pid = (int)(e >> 8);
+                }
+            } else {
+                pid = A.pair_id[ra >> 1];
+            }
             const int lenz = plen[pid];
             const int len = lenz & 0xffff;
             const int base = pid * ls;
@@ -747,6 +771,33 @@ int build_spmv_pair(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, con
         (rc = upv(meta, &A->d_ptbl_meta)))
         return rc;
     A->v.pair_id = (const uint8_t *)A->d_pair_id;
+    // run-length form of the ids, chunk by chunk (SCHWZ_SPMV_RLE=0: byte ids only)
+    const char *rle_env = std::getenv("SCHWZ_SPMV_RLE");
+    if (!(rle_env && rle_env[0] == '0')) {
+        std::vector<uint16_t> rle((size_t)nchunks * 8, 0xffffu);
+        for (int c = 0; c < nchunks; ++c) {
+            if (chunk_ptable[(size_t)c] < 0) continue;
+            const int64_t p0 = (int64_t)c * (kPairRows / 2), p1 = std::min<int64_t>(p0 + kPairRows / 2, (nrows + 1) / 2);
+            uint16_t runs[8];
+            int nr = 0;
+            bool fits = true;
+            for (int64_t p = p0; p < p1 && fits; ++p) {
+                if (nr == 0 || pair_id[(size_t)p] != (uint8_t)(runs[nr - 1] >> 8)) {
+                    if (nr == 8) {
+                        fits = false;
+                        break;
+                    }
+                    runs[nr++] = (uint16_t)((p - p0) | ((int)pair_id[(size_t)p] << 8));
+                }
+            }
+            if (!fits || nr == 0) continue;
+            for (int k = nr; k < 8; ++k) runs[k] = runs[nr - 1];
+            if (runs[0] == 0xffffu) continue;  // would read as the "not coded" marker
+            std::copy(runs, runs + 8, rle.begin() + (size_t)c * 8);
+        }
+        if ((rc = upv(rle, &A->d_pair_rle))) return rc;
+        A->v.pair_rle = (const uint4 *)A->d_pair_rle;
+    }
     A->v.chunk_ptable = (const schwz_idx *)A->d_tile_ptable;
     A->v.ptbl_desc = (const schwz_idx *)A->d_ptbl_desc;
     A->v.ptbl_len = (const uint8_t *)A->d_ptbl_len;
@@ -785,6 +836,9 @@ int pair_set_dual_split(schwz_csr *A, const schwz_idx *h_rp, const schwz_idx *h_
 
 void free_spmv_pair(schwz_csr *A)
 {
+    (void)hipFree(A->d_pair_rle);
+    A->d_pair_rle = nullptr;
+    A->v.pair_rle = nullptr;
     void *ptrs[] = {A->d_pair_id, A->d_tile_ptable, A->d_ptbl_desc, A->d_ptbl_len, A->d_ptbl_val, A->d_ptbl_meta,
                     A->d_chunk_dual};
     for (void *p : ptrs) (void)hipFree(p);
