@@ -98,13 +98,14 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
     const bool dual = (MODE == kSpmvResidDual) && a.x2 != nullptr;
     constexpr bool kWantOwn = MODE == kSpmvDot || kDotOnly || MODE == kSpmvCgUpdate;  // x[row] itself
-    int cached = -1, ls = 0;  // staged table, its row stride
+    int cached = -1, ls = 0, tl = 0;  // staged table, its row stride, its longest pattern
 
     auto stage_table = [&](int tb) {  // workgroup-uniform
         const int td = kSym ? A.pair_sym_base + tb : tb;
         const int eoff = A.ptbl_desc[5 * td], loff = A.ptbl_desc[5 * td + 1];
         const int npat = A.ptbl_desc[5 * td + 2], lmax = A.ptbl_desc[5 * td + 3];
         ls = pair_stride(lmax, CH);
+        tl = lmax;
         lds_barrier();  // everyone is done with the previous table
         for (int i = tid; i < npat * ls; i += kBlock) {
             const int pt = i / ls, k = i - pt * ls;
@@ -134,7 +135,9 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
             // does a gather of this pattern (padding included) fetch x[r], x[r + 1] themselves?
             const int len = A.ptbl_len[loff + tid];
             int zero = 0, mn = 0, mx = 0;  // the padding entries gather at offset 0
-            for (int k = 0; k < pair_stride(len, CH); ++k) {
+            // entries at or past the longest pattern of the table are padding for every lane: no
+            // launch gathers them
+            for (int k = 0; k < min(pair_stride(len, CH), lmax); ++k) {
                 const int off = poff[tid * ls + k];
                 zero |= off == 0;
                 mn = min(mn, off);
@@ -165,10 +168,16 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
                           pvd2 &own, bool want_own) {
         for (int j = 0; j < len; j += CH) {
             const int mask = pmask[(base + j) / CH];
+            const bool skip_last = CH == kPairChunk && j + CH - 1 >= tl;  // workgroup-uniform; groups of 8 only
             pvd2 t[CH];
             if (!safe) {
 #pragma unroll
                 for (int k = 0; k < CH; ++k) {
+                    // the last slot of a group is padding for every lane when the table's longest
+                    // pattern ends one short of it (7 entries in groups of 8: the 7-point stencil):
+                    // one straight-line copy of the loads without it (a per-slot test would break
+                    // the back-to-back issue of the gathers: measured 0.100 -> 0.141 ms)
+                    if (k == CH - 1 && skip_last) continue;
                     const int off = poff[base + j + k];
                     t[k] = ld16(xv, ra + off);
                     if (want_own && off == 0) own = t[k];
