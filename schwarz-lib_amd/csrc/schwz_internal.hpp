@@ -94,6 +94,11 @@ struct CsrView {
     // the strictly upper ones doubled: x.(A x) = sum_i x_i (a_ii x_i + 2 sum_{j>i} a_ij x_j) with about
     // half the gathers (kSpmvDotSym); 0 = not built
     int pair_sym_base = 0;
+    // single-table matrices whose commonest pattern is a stencil row pair {n2, n1, -1, 0, +1, p1, p2}:
+    // that offset layout (pair_canon[0..6]; pair_canon[7] != 0: valid).  Waves whose lanes all have
+    // patterns inside the layout gather its 6 outer slots and take the operands of the offset-0 slot
+    // from the -1 and +1 gathers.
+    int pair_canon[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 // epilogues of the tiled SpMV kernel

@@ -71,6 +71,12 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
     __shared__ int pmask[kPairEntries / CH];  // per group of CH entries: bit k = row r has entry k, bit 8+k = row r+1
     __shared__ int plen[kPairPats];            // length | (a gathered entry has col - row == 0) << 16
     __shared__ int pmin[kPairPats], pmax[kPairPats];  // smallest / largest col - row the pattern gathers at
+    // canonical stencil layout (CsrView::pair_canon): every pattern expanded to the 7 fixed slots, with
+    // presence bits; -1: the pattern has an entry outside the layout
+    constexpr bool kCanon = SINGLE && !kSym;
+    __shared__ PairVal cpv[kCanon ? kPairPats * 8 : 1];
+    __shared__ int cmask[kCanon ? kPairPats : 1];
+    const bool canon_on = kCanon && A.pair_canon[7] != 0;
     if (MODE == kSpmvDot || MODE == kSpmvResidInit || kDotOnly) {
         if (a.stop_iter && a.it >= *a.stop_iter) return;
     }
@@ -146,6 +152,27 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
             plen[tid] = len | (zero << 16);
             pmin[tid] = mn;
             pmax[tid] = mx;
+            if (kCanon && canon_on) {
+                // slot of each entry: the first layout slot with its offset (duplicated filler slots
+                // therefore never receive one)
+                int cm = 0;
+                for (int k = 0; k < 8; ++k) cpv[tid * 8 + k] = PairVal{0.0, 0.0};
+                const int gm = len ? pmask[(tid * ls) / CH] : 0;
+                for (int k = 0; k < len && cm >= 0; ++k) {
+                    const int off = poff[tid * ls + k];
+                    int slot = -1;
+                    for (int q = 6; q >= 0; --q)
+                        if (A.pair_canon[q] == off) slot = q;
+                    if (slot < 0 || len > CH) {
+                        cm = -1;
+                        break;
+                    }
+                    cpv[tid * 8 + slot] = pv[tid * ls + k];
+                    cm |= ((gm >> k) & 1) << slot;
+                    cm |= ((gm >> (kPairChunk + k)) & 1) << (kPairChunk + slot);
+                }
+                cmask[tid] = cm;
+            }
         }
         lds_barrier();
         cached = tb;
@@ -196,6 +223,29 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
                 if ((mask >> k) & 1) s0 += v.a * t[k].x;
                 if ((mask >> (kPairChunk + k)) & 1) s1 += v.b * t[k].y;
             }
+        }
+    };
+    // The same sums for a wave whose patterns all live in the canonical stencil layout: six gathers at
+    // workgroup-uniform offsets; the operands of the offset-0 slot, x[r] and x[r + 1], are the second
+    // half of the -1 gather and the first half of the +1 gather.  Products in slot order = entry order,
+    // absent entries masked: the same bits as the generic walk.
+    auto accumulate_canon = [&](const double *xv, int ra, int pid, double &s0, double &s1, pvd2 &own) {
+        const int mask = cmask[pid];
+        pvd2 t[7];
+        t[0] = ld16(xv, ra + A.pair_canon[0]);
+        t[1] = ld16(xv, ra + A.pair_canon[1]);
+        t[2] = ld16(xv, ra - 1);
+        t[4] = ld16(xv, ra + 1);
+        t[5] = ld16(xv, ra + A.pair_canon[5]);
+        t[6] = ld16(xv, ra + A.pair_canon[6]);
+        t[3].x = t[2].y;
+        t[3].y = t[4].x;
+        own = t[3];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const PairVal v = cpv[pid * 8 + k];
+            if ((mask >> k) & 1) s0 += v.a * t[k].x;
+            if ((mask >> (kPairChunk + k)) & 1) s1 += v.b * t[k].y;
         }
     };
     // kSpmvDirDotSym: the new search direction p' = z + beta p at column c, z = D^-1 r -- one
@@ -413,7 +463,17 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
             // that pair, as does a diagonal entry; waves on the safe path load it themselves
             own_from_gathers = kWantOwn && !safe && (lenz >> 16) != 0;
             pvd2 unused = {0.0, 0.0};
-            if (kDir) {
+            bool canon = false;
+            if (kCanon && canon_on) {
+                const bool fits = cmask[pid] >= 0 && ra + A.pair_canon[0] >= 0 &&
+                                  ra + 1 + A.pair_canon[6] < (int)A.ncols;
+                canon = __builtin_amdgcn_ballot_w64(!fits) == 0;
+            }
+            if (kCanon && canon) {
+                accumulate_canon(a.x, ra, pid, s0, s1, own);
+                own_from_gathers = kWantOwn;
+                if (dual_t) accumulate_canon(a.x2, ra, pid, t0, t1, unused);
+            } else if (kDir) {
                 accumulate_dir(ra, base, len, safe, s0, s1, own);
             } else {
                 accumulate(a.x, ra, base, len, safe, s0, s1, own, own_from_gathers);
@@ -813,6 +873,40 @@ int build_spmv_pair(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, con
     A->v.ptbl_val = (const double *)A->d_ptbl_val;
     A->v.ptbl_meta = (const schwz_idx *)A->d_ptbl_meta;
     A->v.pair_single = single ? 1 : 0;
+    // canonical stencil layout of a single-table matrix (SCHWZ_SPMV_CANON=0: off): the offsets of its
+    // commonest pattern when they read {<= 2 below -1, -1, 0, +1, <= 2 above +1}; missing outer slots
+    // repeat their neighbour outwards, so an entry always lands in the lowest slot with its offset and
+    // the slots stay in ascending entry order
+    for (int k = 0; k < 8; ++k) A->v.pair_canon[k] = 0;
+    const char *canon_env = std::getenv("SCHWZ_SPMV_CANON");
+    if (single && !(canon_env && canon_env[0] == '0')) {
+        const PairTable &tb = tables[0];
+        std::vector<int64_t> freq((size_t)tb.npat, 0);
+        for (uint8_t id : pair_id) ++freq[(size_t)id];
+        const int best = (int)(std::max_element(freq.begin(), freq.end()) - freq.begin());
+        std::vector<schwz_idx> neg, pos;
+        bool has_m1 = false, has_0 = false, has_p1 = false, ok = true;
+        for (int k = 0; k < (int)tb.len[(size_t)best]; ++k) {
+            const schwz_idx off = tb.ent[(size_t)best * tb.lmax + k].off;
+            if (off == -1) has_m1 = true;
+            else if (off == 0) has_0 = true;
+            else if (off == 1) has_p1 = true;
+            else if (off < 0) neg.push_back(off);
+            else pos.push_back(off);
+        }
+        ok = has_m1 && has_0 && has_p1 && neg.size() <= 2 && pos.size() <= 2;
+        if (ok) {
+            std::sort(neg.begin(), neg.end());  // most negative first
+            std::sort(pos.begin(), pos.end());
+            const schwz_idx n2 = neg.size() >= 1 ? neg[0] : -1;
+            const schwz_idx n1 = neg.size() == 2 ? neg[1] : n2;
+            const schwz_idx p2 = pos.size() >= 1 ? pos.back() : 1;
+            const schwz_idx p1 = pos.size() == 2 ? pos[0] : p2;
+            const schwz_idx lay[7] = {n2, n1, -1, 0, 1, p1, p2};
+            for (int k = 0; k < 7; ++k) A->v.pair_canon[k] = lay[k];
+            A->v.pair_canon[7] = 1;
+        }
+    }
     A->v.pair_sym_base = sym_base;
     // the XCD deal of the chunks: the tile deal's run length in rows, in chunks (a power of two)
     int sh = A->v.xcd_shift;

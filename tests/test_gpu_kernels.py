@@ -731,3 +731,60 @@ def test_pair_coding_on_random_banded_matrices(schwz, oracle, torch_cuda, monkey
         assert it == it_o == 15
         assert np.abs(d_x.cpu().numpy() - ex).max() <= RTOL_CG * np.abs(ex).max()
         assert abs(rn - rn_o) <= 1e-8 * max(rn_o, 1e-300)
+
+
+@pytest.mark.parametrize("kind", ["tridiagonal", "five_point_wide", "seven_point_with_extra_band"])
+def test_canonical_stencil_layout_variants(schwz, oracle, torch_cuda, monkeypatch, kind):
+    """Single-table matrices whose commonest row pair reads {.., -1, 0, +1, ..}: waves whose
+    patterns all fit that layout take the offset-0 operands from the -1 and +1 gathers.  Layouts
+    with filler slots (1-D: no outer offsets; 2-D: one each side) and a matrix in which some rows
+    carry an entry outside the layout (those waves walk the generic table): SpMV bit for bit
+    against plain CSR and against SCHWZ_SPMV_CANON=0, CG against the oracle."""
+    import scipy.sparse as sp
+    torch = torch_cuda
+    rng = np.random.default_rng(17)
+    if kind == "tridiagonal":
+        n = 5001
+        M = sp.diags([-1.0, 2.5, -1.0], [-1, 0, 1], shape=(n, n), format="lil")
+    elif kind == "five_point_wide":
+        nx, ny = 300, 21
+        n = nx * ny
+        rp0, col0, val0 = oracle.laplacian2d(21)   # only for the generator's conventions
+        ex = sp.diags([-1.0, -1.0], [-1, 1], shape=(nx, nx))
+        ey = sp.diags([-1.0, -1.0], [-1, 1], shape=(ny, ny))
+        M = (sp.kron(sp.identity(ny), ex) + sp.kron(ey, sp.identity(nx)) + 4.0 * sp.identity(n)).tolil()
+    else:
+        rp0, col0, val0 = oracle.laplacian3d(24, 20, 16)
+        n = len(rp0) - 1
+        M = sp.csr_matrix((val0, col0, rp0), shape=(n, n)).tolil()
+        for i in range(1000, 1400, 7):      # a few rows with one more (symmetric) coupling far away
+            j = i + 3000
+            M[i, j] = -0.25
+            M[j, i] = -0.25
+            M[i, i] += 0.25
+            M[j, j] += 0.25
+    M = M.tocsr()
+    M.sort_indices()
+    rp, col, val = M.indptr.astype(np.int32), M.indices.astype(np.int32), M.data.copy()
+    monkeypatch.setenv("SCHWZ_SPMV_PATTERN", "2")
+    monkeypatch.setenv("SCHWZ_SPMV_PAIR", "2")
+    x = _dev(torch, rng.standard_normal(n))
+    outs = []
+    for canon in ("1", "0"):
+        monkeypatch.setenv("SCHWZ_SPMV_CANON", canon)
+        A = schwz.Csr(rp, col, val)
+        assert A.format() == 3
+        y0 = torch.zeros(n, dtype=torch.float64, device="cuda")
+        y6 = torch.zeros(n, dtype=torch.float64, device="cuda")
+        A.spmv(x.data_ptr(), y0.data_ptr(), 1.0, 0.0, 0)
+        A.spmv(x.data_ptr(), y6.data_ptr(), 1.0, 0.0, 6)
+        torch.cuda.synchronize()
+        assert torch.equal(y0, y6)
+        b = rng.standard_normal(n) if not outs else outs[0][2]
+        cg = schwz.Pcg(A, 1)
+        d_b, d_x = _dev(torch, b), torch.zeros(n, dtype=torch.float64, device="cuda")
+        it, rn = cg.solve(d_b.data_ptr(), d_x.data_ptr(), 0.0, 12)
+        outs.append((d_x.cpu().numpy(), rn, b))
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+    ex_x, it_o, rn_o = oracle.pcg(rp, col, val, outs[0][2], None, 1, 0.0, 12)
+    assert np.abs(outs[0][0] - ex_x).max() <= RTOL_CG * np.abs(ex_x).max()
