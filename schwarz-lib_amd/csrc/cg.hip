@@ -778,21 +778,22 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
         return !(e && e[0] == '0');
     }();
     const int dot_mode = !qfree ? kSpmvDot : (sym_on && A.pair_sym_base > 0 ? kSpmvDotSym : kSpmvDotOnly);
-    // Two launches per iteration where launches, not bytes, set the pace (systems up to kGraphRows
-    // rows): the direction update and the NEXT iteration's p.(A p) share one launch
-    // (kSpmvDirDotSym), p alternating between s->p and the otherwise unused s->q (a launch that
-    // recomputes its neighbours' new p must not overwrite the old one).  The first p.(A p) of a
-    // solve is launched on its own below.  On large systems the fused launch costs what the two it
-    // replaces cost (0.118 vs 0.069 + 0.044 ms at 256^3), so they keep three.
-    // SCHWZ_CG_FUSEDIR=0: never, =2: every size.
+    // Two launches per iteration: the direction update and the NEXT iteration's p.(A p) share one
+    // launch (kSpmvDirDotSym), p alternating between two buffers (a launch that recomputes its
+    // neighbours' new p must not overwrite the old one): s->p and the otherwise unused s->q, or the
+    // slots of the deferred-x ring.  The first p.(A p) of a solve is launched on its own below.
+    // On launch-bound systems (up to kGraphRows rows) this is -11 to -13 % per outer iteration.  On
+    // large ones the fused launch costs what the two it replaces cost -- 0.102 vs 0.067 + 0.045 ms on the
+    // 256^3 cube (+1 % on the bench line), 0.111 vs 0.067 + 0.043 ms on the 512 x 512 x 64 slab of the
+    // multi-GPU runs (-1 %) -- so they keep three launches.  SCHWZ_CG_FUSEDIR=0: never, =2: every size
+    // (it combines with the deferred x update).
     static const int fusedir_mode = [] {
         const char *e = std::getenv("SCHWZ_CG_FUSEDIR");
         return e ? std::atoi(e) : 1;
     }();
     const char *dx_env = std::getenv("SCHWZ_CG_DEFERX");  // read per solve: tests switch it
     const int dx_mode = dx_env ? std::atoi(dx_env) : 1;
-    const bool fusedir = dot_mode == kSpmvDotSym && dx_mode != 2 &&
-                         (fusedir_mode == 2 || (fusedir_mode == 1 && n <= kGraphRows));
+    const bool fusedir = dot_mode == kSpmvDotSym && (fusedir_mode == 2 || (fusedir_mode == 1 && n <= kGraphRows));
     const int flavour = !qfree ? 0 : (fusedir ? 2 : 1);
     // Large systems: x is not touched inside the iteration.  The search directions of up to
     // kDeferDepth iterations stay in a ring (slots 0 and 1 are s->p and the otherwise unused s->q),
@@ -800,7 +801,7 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
     // iterations (and one at the end) applies x += sum_k alpha_k p_k in iteration order -- the same
     // bits, (depth + 2) / depth vectors of traffic per iteration instead of 2.
     // SCHWZ_CG_DEFERX=0: never, =2: every size (tests).
-    bool deferx = qfree && !fusedir && !s->ring_failed && (dx_mode == 2 || (dx_mode == 1 && n > kGraphRows));
+    bool deferx = qfree && !s->ring_failed && (dx_mode == 2 || (dx_mode == 1 && n > kGraphRows));
     if (deferx && !s->p_ring) {
         const size_t nb = (size_t)((n + 1) & ~int64_t(1)) * sizeof(double);
         if (hipMalloc((void **)&s->p_ring, nb * (kDeferDepth - 2)) != hipSuccess ||
@@ -872,9 +873,10 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
                 // p' = z + beta p into the other buffer and the partial sums of p'.(A p') for the next
                 // iteration (the last iteration of a solve only needs the direction kernel's state
                 // update; recorded graphs replay mid-solve, so they keep the fused launch)
+                if (deferx && (it + 1) % kDeferDepth == 0) flush_x(it + 1 - kDeferDepth, kDeferDepth, it, q);
                 SpmvArgs f;
-                f.x = pbuf[it & 1];
-                f.y = pbuf[(it + 1) & 1];
+                f.x = deferx ? slot(it) : pbuf[it & 1];
+                f.y = deferx ? slot(it + 1) : pbuf[(it + 1) & 1];
                 f.cg_r = s->r;
                 f.cg_state = s->state;
                 f.pq_partials = part_vec;
