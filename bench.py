@@ -1,8 +1,14 @@
 #!/usr/bin/env python3
 """bench.py -- RAS iterations/sec of the MI355X hot path on the 3-D Poisson problem.
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W
+
+N = 1 runs in this process.  N > 1 without a launcher around it (no WORLD_SIZE in the
+environment) starts N rank processes itself -- before anything touches the GPU -- and relays
+rank 0's JSON line; under `python -m torch.distributed.run ... bench.py --gpus N` the ranks are
+already there and each one runs the same code.  One rank per GPU, halos over RCCL (backend
+"nccl"); when fewer GPUs than ranks are visible (rehearsal on a 1-GPU box) the ranks share the
+GPU over gloo and the line says so.
 
 A "step" is one outer iteration of SchwarzBase::run (schwarz_base.cpp:387-452):
 halo exchange -> boundary update -> convergence check (local residual SpMV +
@@ -15,10 +21,20 @@ N > 1 : weak scaling with the same 16.8 M rows per GPU: grid 512 x 512 x 64N,
         z-slab partition (regular), overlap 2, RCCL halo exchange; N = 8 is
         BASELINE.json configs[2] (512^3, 8 subdomains).
 value = N * (outer iterations / s): subdomain-iterations per second, whole job.
+
+Roofline fields.  `roofline.achieved` prices the dominant launch on the bytes the LAUNCHED matrix
+format needs (matrix bytes of the coding the upload chose + every vector of the launch once), so
+`frac` <= 1 is an HBM fraction; the same launch priced on uncoded CSR bytes is kept
+as `csr_equivalent_x` = how many times faster than an ideal plain-CSR launch it runs.
+`roofline_csr_plain` is the plain-CSR SpMV on the same matrix (north_star's ">= 60 %" figure) and
+`csr_plain_loop` the whole step with every coding switched off (general-matrix path).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,7 +48,7 @@ except Exception:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy ceiling)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -48,11 +64,74 @@ def parse():
                     help="one-sided overlapped exchange with decentralised convergence (configs[4] flavour)")
     ap.add_argument("--mixed-halo", action="store_true", help="fp32 halo wire format (use_mixed_precision)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-ttr", action="store_true", help="skip the time-to-residual run")
+    ap.add_argument("--no-ttr", action="store_true", help="skip the time-to-residual runs")
+    ap.add_argument("--no-plain-loop", action="store_true", help="skip the plain-CSR leg of the whole step")
+    ap.add_argument("--ttr-subdomains", default="1,2,4,8",
+                    help="N=1: time-to-residual(1e-6) of the same grid cut into this many z-slabs, all held by "
+                         "this GPU (the iterations-vs-subdomains half of the metric)")
+    ap.add_argument("--ttr-budget-s", type=float, default=40.0,
+                    help="wall-clock cap of each time-to-residual run (reported as not converged past it)")
     ap.add_argument("--cpu-iters", type=int, default=30,
                     help="outer iterations of the CPU sample (about 10-30 s of CPU work)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
+
+# ----------------------------------------------------------------------------- self launch
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` with no launcher around it: N rank processes of this same
+    script, started as CHILDREN (never exec) before this process has imported torch or touched
+    the GPU.  Rank 0's stdout is the JSON line and is relayed; the exit code is the worst one."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    deadline = time.time() + 120.0
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()  # the exact child started above
+            p.wait()
+        rc = rc or p.returncode
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return rc
+
+
+def launch_probe(a):
+    """SCHWZ_BENCH_LAUNCH_PROBE=1 (tests/test_dist_gloo.py): every rank joins a gloo group under the
+    environment self_launch (or an outer launcher) gave it, the ranks are all-gathered and rank 0
+    prints them -- the rendezvous of bench.py without the GPU work."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    mine = torch.tensor([dist.get_rank(), int(os.environ["LOCAL_RANK"])], dtype=torch.int64)
+    out = [torch.zeros(2, dtype=torch.int64) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    if dist.get_rank() == 0:
+        print(json.dumps({"launch_probe": True, "n_gpus": a.gpus, "world": dist.get_world_size(),
+                          "ranks": [[int(t[0]), int(t[1])] for t in out]}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
+# ----------------------------------------------------------------------------- helpers
 
 def make_solver(schwz, comm, shape, inner, tol, max_iters, local_tol, variant, quiet=True, overlapped=False,
                 mixed=False):
@@ -74,7 +153,7 @@ def make_solver(schwz, comm, shape, inner, tol, max_iters, local_tol, variant, q
 
 
 def sd_csr(sd, schwz):
-    """schwz_csr handle of the subdomain's local matrix (for the plain-CSR roofline probe)."""
+    """schwz_csr handle of the subdomain's local matrix."""
     import ctypes
     h = ctypes.c_void_p()
     schwz.capi.check(schwz.capi.lib.schwz_ras_local_csr(sd.h, ctypes.byref(h)))
@@ -113,8 +192,86 @@ def cpu_baseline(shape, inner, iters):
                        (r["iter_count"], shape[0], shape[1], shape[2], inner, r["elapsed_s"]))
 
 
+def kernel_source_hash():
+    """Hash of the kernel sources of this tree: profiles/traffic.json carries the hash of the tree
+    its counters were taken on, and a PMC figure is only quoted for the very same kernels."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "schwarz-lib_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(shape, tags):
+    """HBM bytes per launch from profiles/traffic.json ((2 FETCH_SIZE + WRITE_SIZE) KiB of separate
+    --pmc passes, tools/profile_bench.sh) for the kernels named by `tags`; None unless the entry was
+    taken on this very grid shape AND on these very kernel sources."""
+    out = {t: None for t in tags}
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        tj = json.load(open(tpath))
+        ent = tj.get("%dx%dx%d" % shape, {})
+        if ent.get("kernel_source_hash") != kernel_source_hash():
+            return out, "stale" if ent else "absent"
+        for t in tags:
+            out[t] = ent.get(t, {}).get("hbm_bytes_per_launch")
+        return out, "profiles/traffic.json (kernel sources match)"
+    except Exception:
+        return out, "absent"
+
+
+def timed_steps(solver, comm, torch, warmup, steps):
+    solver.begin_run()
+    for _ in range(warmup):
+        solver.step()
+    torch.cuda.synchronize()
+    comm.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        solver.step()
+    torch.cuda.synchronize()
+    comm.barrier()
+    return time.perf_counter() - t0
+
+
+def time_to_residual(schwz, torch, comm, shape, variant, budget_s):
+    """time-to-residual(1e-6) at the authors' inexact setting (local_tol 0.1, <= 70 inner
+    iterations; run_script:35-38), capped at 3000 outer iterations and `budget_s` seconds."""
+    s2, m2 = make_solver(schwz, comm, shape, 70, 1e-6, 3000, 0.1, variant)
+    s2.begin_run()
+    torch.cuda.synchronize()
+    comm.barrier()
+    t0 = time.perf_counter()
+    done = False
+    while m2.iter_count < m2.max_iters:
+        if s2.step():
+            done = True
+            break
+        if comm.size == 1 or type(comm).__name__ == "InProcessComm":
+            if time.perf_counter() - t0 > budget_s:
+                break
+    torch.cuda.synchronize()
+    comm.barrier()
+    elapsed = time.perf_counter() - t0
+    out = s2.finish_run(elapsed, gather_solution=False)
+    res = dict(subdomains=m2.num_subdomains, seconds=elapsed, outer_iters=out["iter_count"],
+               converged=bool(out["converged"] and done),
+               true_relative_residual=out["residual_norm"] / out["rhs_norm"])
+    del s2
+    torch.cuda.empty_cache()
+    return res
+
+
+# ----------------------------------------------------------------------------- main
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("SCHWZ_BENCH_NO_SPAWN") != "1":
+        sys.exit(self_launch(a.gpus, sys.argv[1:]))
+    if os.environ.get("SCHWZ_BENCH_LAUNCH_PROBE") == "1":
+        sys.exit(launch_probe(a))
     # stdout carries the one JSON line and nothing else: libraries that print to the C-level stdout
     # (RCCL writes its version banner there when the first communicator comes up, on every rank) are
     # pointed at stderr until the line is written
@@ -123,25 +280,27 @@ def main():
     os.dup2(2, 1)
     import torch
     import schwz_amd as schwz
+    import ctypes
     N = a.gpus
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    backend = None
     # SCHWZ_BENCH_FORCE_DIST=1: take the torch.distributed branch with a single rank as well
     # (brings the nccl process group, the gloo side group and the slab workload up on a 1-GPU box)
     if N > 1 or world > 1 or os.environ.get("SCHWZ_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        # SCHWZ_DIST_BACKEND=gloo: several ranks may share one GPU (halos staged through host);
-        # used to rehearse the N>1 path on a 1-GPU box.  The product backend is nccl (= RCCL).
-        backend = os.environ.get("SCHWZ_DIST_BACKEND", "nccl")
+        ndev = max(torch.cuda.device_count(), 1)
+        # One GPU per rank over RCCL.  With fewer visible GPUs than ranks the ranks share them and the
+        # halos are staged through host memory over gloo: a rehearsal of the N > 1 code path on a
+        # smaller box, named in config.exchange_backend.  SCHWZ_DIST_BACKEND overrides.
+        # (source/schwarz_base.cpp:102-109: device = node-local rank)
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        backend = os.environ.get("SCHWZ_DIST_BACKEND") or ("nccl" if ndev >= local_world else "gloo")
+        local_rank = local_rank % ndev  # a launcher that masks the devices per rank leaves index 0 only
+        torch.cuda.set_device(local_rank)
         if backend == "nccl":
-            # one GPU per rank; a launcher that masks the devices per rank leaves each rank with
-            # a single visible device (index 0)
-            local_rank = local_rank % max(torch.cuda.device_count(), 1)
-            torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
-            local_rank = local_rank % torch.cuda.device_count()
-            torch.cuda.set_device(local_rank)
             dist.init_process_group(backend)
         comm = schwz.TorchDistComm(device=torch.device("cuda", local_rank))
         comm.device_index = local_rank
@@ -163,30 +322,20 @@ def main():
             shape = (a.size, a.size, a.size)
             workload = "3D Poisson %d^3, 1 subdomain on 1 MI355X (BASELINE configs[1])" % a.size
     rank = comm.rank
+    lib, check = schwz.capi.lib, schwz.capi.check
 
     t_setup = time.perf_counter()
     solver, m = make_solver(schwz, comm, shape, a.inner, 1e-30, a.warmup + 2 * a.steps + 2, 0.0,
                             a.spmv_variant, overlapped=a.overlapped, mixed=a.mixed_halo)
     setup_s = time.perf_counter() - t_setup
     sd = solver.subdomains[comm.local_ranks[0]]
-    solver.begin_run()
-    for _ in range(a.warmup):
-        solver.step()
-    torch.cuda.synchronize()
-    comm.barrier()
-    # timed region: exactly K steps, no instrumentation
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        solver.step()
-    torch.cuda.synchronize()
-    comm.barrier()
-    elapsed = time.perf_counter() - t0
+    # timed region: W warmup steps, then exactly K steps, no instrumentation
+    elapsed = timed_steps(solver, comm, torch, a.warmup, a.steps)
     # roofline leg: the same K steps again with a HIP-event pair around every launch of the
     # dominant kernel on its launch stream.  Kept out of the timed region above because each
     # event record costs ~5 us of GPU idle (measured with rocprofv3 --kernel-trace), which
     # would tax the headline value; the kernel durations themselves are unaffected.
-    import ctypes
-    schwz.capi.check(schwz.capi.lib.schwz_profile_begin(2 * a.steps * a.inner + 8))
+    check(lib.schwz_profile_begin(2 * a.steps * a.inner + 8))
     t1 = time.perf_counter()
     for _ in range(a.steps):
         solver.step()
@@ -194,86 +343,76 @@ def main():
     comm.barrier()
     elapsed_instrumented = time.perf_counter() - t1
     tot_ms, launches = ctypes.c_double(0.0), ctypes.c_int64(0)
-    schwz.capi.check(schwz.capi.lib.schwz_profile_end(ctypes.byref(tot_ms), ctypes.byref(launches)))
+    check(lib.schwz_profile_end(ctypes.byref(tot_ms), ctypes.byref(launches)))
     if N > 1:
         elapsed = max(comm.allgather_scalars({rank: elapsed}))
         elapsed_instrumented = max(comm.allgather_scalars({rank: elapsed_instrumented}))
     upd_ms, upd_launches = ctypes.c_double(0.0), ctypes.c_int64(0)
-    schwz.capi.check(schwz.capi.lib.schwz_profile_kind(1, ctypes.byref(upd_ms), ctypes.byref(upd_launches)))
+    check(lib.schwz_profile_kind(1, ctypes.byref(upd_ms), ctypes.byref(upd_launches)))
     iters_per_s = a.steps / elapsed
-    alg_spmv = sd.algorithmic_bytes(0)
     n_rows = sd.local_size_x
+    csr_spmv_bytes = sd.algorithmic_bytes(0)  # 12 nnz + 4 (n + 1) + 16 n, uncoded CSR
     hist = m.post_process_data["global_residual_vector_out"]
-    fmt = int(schwz.capi.lib.schwz_csr_format(sd_csr(sd, schwz))) if a.spmv_variant == 0 else 0
-    dict_coded = fmt != 0
+    csr_h = sd_csr(sd, schwz)
+    fmt = int(lib.schwz_csr_format(csr_h)) if a.spmv_variant == 0 else 0
+    mat_bytes = int(lib.schwz_csr_matrix_bytes(csr_h, a.spmv_variant))  # matrix bytes of the launched format
+    coded = fmt != 0
     qfree = upd_launches.value > 0
     spmv_avg_ms = tot_ms.value / max(launches.value, 1)
+    fmt_name = {3: "row-pair coded", 2: "row-pattern coded", 1: "dictionary coded", 0: "plain CSR"}[fmt]
     spmv_name = {3: "spmv_pair_kernel<kSpmvDot> (q = A p, fused p.q; row-pair pattern coded CSR)",
                  2: "spmv_pattern_kernel<kSpmvDot> (q = A p, fused p.q; row-pattern coded CSR tiles)",
                  1: "spmv_dict_kernel<kSpmvDot> (q = A p, fused p.q; dictionary-coded CSR tiles)",
                  0: "spmv_tiled2_kernel<kSpmvDot> (q = A p, fused p.q; plain CSR)"}[fmt]
     spmv_tag = {3: "spmv_pair_kernel<1,", 2: "spmv_pattern_kernel<1,", 1: "spmv_dict_kernel<1>",
                 0: "spmv_tiled2_kernel<1>"}[fmt]
+    # bytes of the SpMV launch in its own format: the matrix once, x once, y once
+    spmv_fmt_bytes = mat_bytes + 16 * n_rows
     if qfree:
         # q-free CG iteration (row-pair coded matrix): the launch that recomputes (A p)_i row by row
-        # while it updates x and r is the longest one.  Algorithmic bytes, SURVEY 8(d): the SpMV
-        # (B_spmv) + the x and r updates (2 x 24n) + Jacobi (24n) + the r.z dot (16n) + the norm (8n).
+        # while it updates r (and x) is the longest one.  Bytes of the launched format: the pair codes,
+        # p once (gathered), r read + written, [x read + written], [1/diag when it is a full vector].
+        # CSR-equivalent bytes, SURVEY 8(d): B_spmv + the x and r updates (2 x 24n) + Jacobi (24n) +
+        # the r.z dot (16n) + the norm (8n), minus the 24n of a deferred x update.
+        deferred = n_rows > (1 << 21) and os.environ.get("SCHWZ_CG_DEFERX", "1")[:1] != "0"
+        diag_vec = 8 * n_rows if int(lib.schwz_ras_jacobi_form(sd.h)) == 1 else 0
         kernel_name = ("spmv_pair_kernel<kSpmvCgUpdate> (row-pair coded A: q_i = (A p)_i recomputed, "
-                       "x += alpha p, r -= alpha q, z = D^-1 r, partial r.z and r.r)")
+                       + ("" if deferred else "x += alpha p, ") + "r -= alpha q, z = D^-1 r, partial r.z and r.r"
+                       + ("; x += alpha p deferred)" if deferred else ")"))
         dom_tag = "spmv_pair_kernel<6,"
-        alg_dom = alg_spmv + 96 * n_rows
-        if n_rows > (1 << 21) and os.environ.get("SCHWZ_CG_DEFERX", "1")[:1] != "0":
-            # large systems: x += alpha p is not part of this launch (deferred, applied to up to 16
-            # search directions at once by cg_flush_x_kernel): 24 n fewer algorithmic bytes
-            kernel_name = ("spmv_pair_kernel<kSpmvCgUpdate> (row-pair coded A: q_i = (A p)_i recomputed, "
-                           "r -= alpha q, z = D^-1 r, partial r.z and r.r; x += alpha p deferred)")
-            alg_dom = alg_spmv + 72 * n_rows
+        dom_fmt_bytes = mat_bytes + 24 * n_rows + (0 if deferred else 16 * n_rows) + diag_vec
+        dom_csr_bytes = csr_spmv_bytes + (72 if deferred else 96) * n_rows
         avg_ms = upd_ms.value / upd_launches.value
         dom_launches = upd_launches.value
-        spmv_name = "spmv_pair_kernel<kSpmvDotOnly> (partial sums of p.(A p), nothing stored; row-pair coded CSR)"
-        spmv_tag = "spmv_pair_kernel<5,"
-        if (int(schwz.capi.lib.schwz_csr_symmetric(sd_csr(sd, schwz))) and
-                os.environ.get("SCHWZ_CG_SYM", "1")[:1] != "0"):
-            # the upload found the matrix symmetric: p.(A p) from the upper triangle
-            spmv_name = ("spmv_pair_kernel<kSpmvDotSym> (partial sums of p.(A p) from the upper triangle of the "
-                         "symmetric row-pair coded matrix, nothing stored)")
-            spmv_tag = "spmv_pair_kernel<7,"
+        sym = bool(lib.schwz_csr_symmetric(csr_h)) and os.environ.get("SCHWZ_CG_SYM", "1")[:1] != "0"
+        spmv_name = ("spmv_pair_kernel<kSpmvDotSym> (partial sums of p.(A p) from the upper triangle of the "
+                     "symmetric row-pair coded matrix, nothing stored)") if sym else \
+            "spmv_pair_kernel<kSpmvDotOnly> (partial sums of p.(A p), nothing stored; row-pair coded CSR)"
+        spmv_tag = "spmv_pair_kernel<7," if sym else "spmv_pair_kernel<5,"
+        spmv_fmt_bytes = mat_bytes + 8 * n_rows  # the pair codes and p once; nothing is stored
     else:
-        kernel_name, dom_tag, alg_dom, avg_ms, dom_launches = spmv_name, spmv_tag, alg_spmv, spmv_avg_ms, launches.value
-    achieved = alg_dom / (avg_ms * 1e-3) / 1e9 if dom_launches else 0.0
-    traffic = None
-    spmv_traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            ent = tj.get("%dx%dx%d" % shape, {})
-            # only quote a PMC figure taken for the very kernel this run is using
-            traffic = ent.get(dom_tag, {}).get("hbm_bytes_per_launch")
-            spmv_traffic = ent.get(spmv_tag, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    # the plain-CSR kernel on the same matrix (variant 6), timed on its own: the figure the
-    # north_star's ">= 60 % of the HBM roofline on the local CSR SpMV" refers to
-    csr_plain = None
-    if rank == 0 and dict_coded:
-        xs, _ = sd.vector(2)
-        ys, _ = sd.vector(1)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        stream = torch.cuda.current_stream().cuda_stream
-        keep = torch.empty(sd.local_size_x, dtype=torch.float64, device="cuda")
-        for _ in range(3):
-            schwz.capi.check(schwz.capi.lib.schwz_csr_spmv(sd_csr(sd, schwz), 1.0, xs, 0.0, keep.data_ptr(), 6, stream))
-        e0.record()
-        for _ in range(20):
-            schwz.capi.check(schwz.capi.lib.schwz_csr_spmv(sd_csr(sd, schwz), 1.0, xs, 0.0, keep.data_ptr(), 6, stream))
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 20
-        csr_plain = {"kernel": "spmv_tiled2_kernel<kSpmvPlain> (plain CSR, y = A x)", "bound": "hbm",
-                     "achieved": alg_spmv / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": alg_spmv / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": ms,
-                     "algorithmic_bytes_per_launch": alg_spmv}
+        kernel_name, dom_tag, avg_ms, dom_launches = spmv_name, spmv_tag, spmv_avg_ms, launches.value
+        dom_fmt_bytes, dom_csr_bytes = spmv_fmt_bytes, csr_spmv_bytes
+    achieved = dom_fmt_bytes / (avg_ms * 1e-3) / 1e9 if dom_launches else 0.0
+    spmv_achieved = spmv_fmt_bytes / (spmv_avg_ms * 1e-3) / 1e9 if launches.value else 0.0
+    traffic, traffic_src = pmc_traffic(shape if N == 1 else tuple(int(t) for t in a.slab.split(",")),
+                                       (dom_tag, spmv_tag))
+
+    def roof(name, fmt_bytes, csr_bytes, ach, ms, n_launch, tag):
+        tr = traffic[tag]
+        return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS,
+                # HBM bytes per launch the PMC counters saw (None unless taken on these kernel sources)
+                "traffic": tr, "traffic_source": traffic_src,
+                "traffic_over_algorithmic": (tr / fmt_bytes) if tr else None,
+                "algorithmic_bytes_per_launch": fmt_bytes,
+                "algorithmic_bytes_note": "bytes the launched format needs: %s matrix (%d B) + every vector "
+                                          "of the launch once" % (fmt_name, mat_bytes),
+                # the same launch priced on uncoded CSR bytes: not a roofline fraction
+                "csr_equivalent_bytes_per_launch": csr_bytes,
+                "csr_equivalent_x": (csr_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms else None,
+                "launches": n_launch, "avg_launch_ms": ms}
+
     line = {
         # BASELINE.json's metric string; `value` is its first half (outer RAS iterations per second,
         # counted per subdomain and summed over the GPUs), the time-to-residual half is reported in
@@ -297,51 +436,60 @@ def main():
         "config": {"workload": workload, "inner_cg_iters": a.inner, "precond": "jacobi",
                    "local_tol": 0.0, "overlap": 2, "partition": "regular",
                    "rows_per_gpu": sd.local_size_x, "nnz_per_gpu": sd.nnz_local,
-                   "spmv_variant": a.spmv_variant,
+                   "spmv_variant": a.spmv_variant, "matrix_format": fmt_name,
                    "exchange": ("one-sided overlapped, decentralised stop" if a.overlapped
                                 else "two-sided, all-gathered residual norms") +
-                               (", fp32 halos" if a.mixed_halo else "")},
+                               (", fp32 halos" if a.mixed_halo else ""),
+                   "exchange_backend": (None if backend is None else
+                                        ("nccl (RCCL, one GPU per rank)" if backend == "nccl" else
+                                         backend + " (ranks share %d GPU(s), halos staged through host: "
+                                                   "rehearsal, not a scaling measurement)" %
+                                         torch.cuda.device_count()))},
         "ras_iters_per_s": iters_per_s,
         "setup_s": setup_s,
         "residual_reduction_in_timed_steps": (sum(h[-1] for h in hist) / sum(h[0] for h in hist))
         if hist and hist[0] else None,
-        "roofline": {"kernel": kernel_name, "bound": "hbm",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     # bytes the counters saw, over the same launch time: the HBM utilisation proper
-                     # (the lossless matrix coding is why it is far below `frac`)
-                     "traffic_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and avg_ms else None,
-                     "algorithmic_bytes_per_launch": alg_dom, "launches": dom_launches,
-                     "avg_launch_ms": avg_ms,
-                     "ms_per_step_instrumented": 1e3 * elapsed_instrumented / a.steps},
-        "roofline_spmv": {"kernel": spmv_name, "bound": "hbm",
-                          "achieved": alg_spmv / (spmv_avg_ms * 1e-3) / 1e9 if launches.value else 0.0,
-                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": (alg_spmv / (spmv_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if launches.value else 0.0,
-                          "traffic": spmv_traffic,
-                          "traffic_frac": (spmv_traffic / (spmv_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
-                          if spmv_traffic and spmv_avg_ms else None,
-                          "algorithmic_bytes_per_launch": alg_spmv,
-                          "launches": launches.value, "avg_launch_ms": spmv_avg_ms},
-        "roofline_csr_plain": csr_plain,
+        "roofline": dict(roof(kernel_name, dom_fmt_bytes, dom_csr_bytes, achieved, avg_ms, dom_launches, dom_tag),
+                         ms_per_step_instrumented=1e3 * elapsed_instrumented / a.steps),
+        "roofline_spmv": roof(spmv_name, spmv_fmt_bytes, csr_spmv_bytes, spmv_achieved, spmv_avg_ms,
+                              launches.value, spmv_tag),
     }
+    stream = torch.cuda.current_stream().cuda_stream
+    # the plain-CSR kernel on the same matrix (variant 6), timed on its own: the figure the
+    # north_star's ">= 60 % of the HBM roofline on the local CSR SpMV" refers to
+    if rank == 0 and (coded or a.spmv_variant == 0):
+        xs, _ = sd.vector(2)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        keep = torch.empty(sd.local_size_x, dtype=torch.float64, device="cuda")
+        for _ in range(3):
+            check(lib.schwz_csr_spmv(csr_h, 1.0, xs, 0.0, keep.data_ptr(), 6, stream))
+        e0.record()
+        for _ in range(20):
+            check(lib.schwz_csr_spmv(csr_h, 1.0, xs, 0.0, keep.data_ptr(), 6, stream))
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        line["roofline_csr_plain"] = {
+            "kernel": "spmv_tiled2_kernel<kSpmvPlain> (plain CSR, y = A x)", "bound": "hbm",
+            "achieved": csr_spmv_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": csr_spmv_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": ms,
+            "algorithmic_bytes_per_launch": csr_spmv_bytes,
+            "note": "north_star: >= 0.60 of the HBM roofline on the local CSR SpMV"}
+        del keep
     # the box's own HBM ceilings (STREAM-style kernels of the library, 2 GiB), quoted beside the
     # 8 TB/s spec the roofline fractions are priced against
     if rank == 0:
         try:
             big = torch.empty(1 << 28, dtype=torch.float64, device="cuda")
             dst = torch.empty_like(big)
-            stream = torch.cuda.current_stream().cuda_stream
             meas = {}
             for mode, name, factor in ((1, "read", 1), (0, "copy", 2)):
                 for _ in range(2):
-                    schwz.capi.check(schwz.capi.lib.schwz_stream_probe(big.numel(), mode, big.data_ptr(),
-                                                                       dst.data_ptr(), stream))
+                    check(lib.schwz_stream_probe(big.numel(), mode, big.data_ptr(), dst.data_ptr(), stream))
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(10):
-                    schwz.capi.check(schwz.capi.lib.schwz_stream_probe(big.numel(), mode, big.data_ptr(),
-                                                                       dst.data_ptr(), stream))
+                    check(lib.schwz_stream_probe(big.numel(), mode, big.data_ptr(), dst.data_ptr(), stream))
                 e1.record()
                 torch.cuda.synchronize()
                 meas[name] = factor * big.numel() * 8 / (e0.elapsed_time(e1) / 10) / 1e6
@@ -350,17 +498,36 @@ def main():
             del big, dst
         except Exception as exc:  # never let the side measurement break the bench line
             line["hbm_measured"] = {"error": str(exc)}
+    del solver, sd
+    torch.cuda.empty_cache()
+    # the whole step with every matrix coding off (spmv_variant 6: plain CSR, stored-q CG): what a
+    # matrix that does not pattern-code (FEM, < 90 % coverage) runs at.  Same workload, same K steps.
+    if N == 1 and not a.no_plain_loop and a.spmv_variant == 0 and coded:
+        s6, _ = make_solver(schwz, comm, shape, a.inner, 1e-30, a.warmup + a.steps + 2, 0.0, 6)
+        el6 = timed_steps(s6, comm, torch, a.warmup, a.steps)
+        line["csr_plain_loop"] = {"value": a.steps / el6, "unit": "subdomain-iter/s",
+                                  "ms_per_step": 1e3 * el6 / a.steps, "spmv_variant": 6,
+                                  "note": "same workload and steps with the lossless matrix codings switched off: "
+                                          "plain CSR SpMV kernel, CG with a stored q (the general-matrix path)"}
+        del s6
+        torch.cuda.empty_cache()
     # time-to-residual(1e-6) at the authors' inexact setting (SURVEY 8d ii)
     if not a.no_ttr:
-        del solver
-        torch.cuda.empty_cache()
-        s2, m2 = make_solver(schwz, comm, shape, 70, 1e-6, 3000, 0.1, a.spmv_variant)
-        out = s2.run(gather_solution=False)
-        line["time_to_residual_1e-6_s"] = out["elapsed"]
-        line["time_to_residual_iters"] = out["iter_count"]
-        line["time_to_residual_converged"] = out["converged"]
-        line["true_relative_residual"] = out["residual_norm"] / out["rhs_norm"]
-        del s2
+        r1 = time_to_residual(schwz, torch, comm, shape, a.spmv_variant, 1e9 if N > 1 else 4 * a.ttr_budget_s)
+        line["time_to_residual_1e-6_s"] = r1["seconds"]
+        line["time_to_residual_iters"] = r1["outer_iters"]
+        line["time_to_residual_converged"] = r1["converged"]
+        line["true_relative_residual"] = r1["true_relative_residual"]
+        if N == 1:
+            # the iterations-vs-subdomains half of the metric on ONE GPU: the same grid cut into P z-slabs
+            # (overlap 2), all P subdomains held by this process, halo messages = device copies
+            by_p = {"1": r1}
+            for P in [int(t) for t in a.ttr_subdomains.split(",") if t.strip()]:
+                if P <= 1 or shape[2] // P < 4:
+                    continue
+                by_p[str(P)] = time_to_residual(schwz, torch, schwz.InProcessComm(P), shape, a.spmv_variant,
+                                                a.ttr_budget_s)
+            line["time_to_residual_by_subdomains"] = by_p
     if rank == 0 and N == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(shape, a.inner, a.cpu_iters)
     sys.stdout.flush()

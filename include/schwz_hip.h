@@ -101,6 +101,10 @@ int schwz_csr_format(const schwz_csr *A);
  * launch); such a matrix need not come from the reference's symmetric problems -- nothing is
  * assumed, the check runs on every upload.  0 otherwise. */
 int schwz_csr_symmetric(const schwz_csr *A);
+/* bytes of MATRIX data one SpMV pass reads in the coding `variant` launches (0: the coding the upload
+ * chose, schwz_csr_format; anything else: plain CSR = 12 nnz + 4 (rows + 1), the figure of SURVEY 8(d)).
+ * bench.py prices its roofline fraction on these bytes (+ the vector bytes of the launch). */
+int64_t schwz_csr_matrix_bytes(const schwz_csr *A, int variant);
 
 /* y = alpha*A*x + beta*y : gko Csr::apply(alpha,x,beta,y), call sites
  * source/restricted_schwarz.cpp:1014-1015, source/solve.cpp:834-835,1079-1080.
@@ -365,6 +369,11 @@ int schwz_ras_restrict(schwz_subdomain *sd, schwz_stream stream);
 int schwz_ras_vector(schwz_subdomain *sd, int which, double **d_ptr, int64_t *len);
 /* the HBM-resident local_matrix of the subdomain (borrowed handle, owned by sd) */
 int schwz_ras_local_csr(schwz_subdomain *sd, schwz_csr **out);
+/* how the scalar-Jacobi diagonal of the local CG reaches its vector kernels: 0 no Jacobi scaling,
+ * 1 a full 1/diag vector (8 B per row and launch), 2 one-byte codes into a small dictionary, 3 one
+ * scalar (every stencil matrix).  Same values, same bits; bench.py needs it to count the bytes of a
+ * launch.  Replaces nothing in the reference (gko::preconditioner::Jacobi stores blocks). */
+int schwz_ras_jacobi_form(const schwz_subdomain *sd);
 /* copy x~[0:local_size] to the host (synchronous) -- the rank's piece of the
  * solution assembled in Solve::compute_residual_norm (solve.cpp:1025-1085) */
 int schwz_ras_get_interior(schwz_subdomain *sd, double *h_out, schwz_stream stream);

@@ -366,6 +366,21 @@ int schwz_csr_format(const schwz_csr *A)
 
 int schwz_csr_symmetric(const schwz_csr *A) { return A && A->v.pair_id && A->v.pair_sym_base > 0 ? 1 : 0; }
 
+// Bytes of matrix data one pass of the default (variant 0) SpMV launch has to read in the coding the
+// upload chose: what "algorithmic bytes of the launched format" means in bench.py's roofline.
+int64_t schwz_csr_matrix_bytes(const schwz_csr *A, int variant)
+{
+    if (!A) return 0;
+    const int64_t n = A->v.nrows, nnz = A->v.nnz;
+    const int64_t plain = 12 * nnz + 4 * (n + 1);
+    if (variant != 0) return plain;
+    if (A->v.pair_id) return A->pair_code_bytes + (int64_t)((1.0 - A->pair_fraction) * (double)plain);
+    if (A->v.pat_id) return n + 4 * (int64_t)A->v.ntiles + (int64_t)((1.0 - A->pattern_fraction) * (double)plain);
+    if (A->v.code) return (int64_t)(2.0 * A->dict_fraction * (double)nnz) + 4 * (n + 1) +
+                          (int64_t)((1.0 - A->dict_fraction) * 12.0 * (double)nnz);
+    return plain;
+}
+
 int schwz_csr_spmv(const schwz_csr *A, double alpha, const double *d_x, double beta, double *d_y,
                    int variant, schwz_stream stream)
 {

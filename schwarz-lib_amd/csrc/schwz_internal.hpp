@@ -239,6 +239,7 @@ struct schwz_csr {
     double dict_fraction = 0.0;  // share of the nonzeros that are dictionary coded
     double pattern_fraction = 0.0;  // share of the nonzeros in row-pattern coded tiles
     double pair_fraction = 0.0;     // share of the nonzeros in row-pair coded tiles
+    int64_t pair_code_bytes = 0;    // pattern ids (run-length or byte form) + chunk table ids + tables of the pair coding
 };
 
 struct schwz_pcg {

@@ -842,8 +842,9 @@ int build_spmv_pair(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, con
     A->v.pair_id = (const uint8_t *)A->d_pair_id;
     // run-length form of the ids, chunk by chunk (SCHWZ_SPMV_RLE=0: byte ids only)
     const char *rle_env = std::getenv("SCHWZ_SPMV_RLE");
+    std::vector<uint16_t> rle;
     if (!(rle_env && rle_env[0] == '0')) {
-        std::vector<uint16_t> rle((size_t)nchunks * 8, 0xffffu);
+        rle.assign((size_t)nchunks * 8, 0xffffu);
         for (int c = 0; c < nchunks; ++c) {
             if (chunk_ptable[(size_t)c] < 0) continue;
             const int64_t p0 = (int64_t)c * (kPairRows / 2), p1 = std::min<int64_t>(p0 + kPairRows / 2, (nrows + 1) / 2);
@@ -908,6 +909,22 @@ int build_spmv_pair(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, con
         }
     }
     A->v.pair_sym_base = sym_base;
+    {
+        // what a pass over the coded matrix reads: per chunk its 16-byte run-length record, or one byte per
+        // pair where the ids do not run-length code; the chunk's table id unless one table serves the whole
+        // matrix; the tables themselves (one set; the upper-triangle twins are read INSTEAD by kSpmvDotSym)
+        int64_t bytes = 0;
+        const uint16_t *rle_h = rle.empty() ? nullptr : rle.data();
+        for (int c = 0; c < nchunks; ++c) {
+            if (chunk_ptable[(size_t)c] < 0) continue;
+            const bool runs = rle_h && rle_h[(size_t)c * 8] != 0xffffu;
+            bytes += runs ? 16 : (rle_h ? 16 : 0) + kPairRows / 2;
+            if (!single) bytes += 4;
+        }
+        const size_t ntab = sym_base ? (size_t)sym_base : tables.size();
+        for (size_t t = 0; t < ntab; ++t) bytes += (int64_t)tables[t].ent.size() * 24 + tables[t].npat;
+        A->pair_code_bytes = bytes;
+    }
     // the XCD deal of the chunks: the tile deal's run length in rows, in chunks (a power of two)
     int sh = A->v.xcd_shift;
     const int64_t rows_per_tile = std::max<int64_t>(1, nrows / std::max<int64_t>(1, (int64_t)tiles.size() - 1));

@@ -28,7 +28,7 @@ PRECOND_NONE, PRECOND_JACOBI, PRECOND_BLOCK_JACOBI, PRECOND_ILU, PRECOND_ISAI = 
 SYMBOLS = [
     "schwz_last_error", "schwz_version", "schwz_device_count", "schwz_set_device",
     "schwz_gather", "schwz_scatter",
-    "schwz_csr_create", "schwz_csr_destroy", "schwz_csr_nnz", "schwz_csr_format", "schwz_csr_symmetric", "schwz_csr_spmv",
+    "schwz_csr_create", "schwz_csr_destroy", "schwz_csr_nnz", "schwz_csr_format", "schwz_csr_symmetric", "schwz_csr_matrix_bytes", "schwz_csr_spmv",
     "schwz_pcg_create", "schwz_pcg_create_ex", "schwz_pcg_destroy", "schwz_pcg_solve",
     "schwz_gmres_create", "schwz_gmres_destroy", "schwz_gmres_solve", "schwz_gmres_last_stats",
     "schwz_profile_begin", "schwz_profile_end", "schwz_profile_kind", "schwz_stream_probe",
@@ -49,7 +49,7 @@ SYMBOLS = [
     "schwz_ras_local_residual_wait", "schwz_ras_local_solve", "schwz_ras_set_local_max_iters",
     "schwz_ras_last_inner_stats",
     "schwz_ras_check_and_solve_launch",
-    "schwz_ras_restrict", "schwz_ras_vector", "schwz_ras_local_csr", "schwz_ras_get_interior",
+    "schwz_ras_restrict", "schwz_ras_vector", "schwz_ras_local_csr", "schwz_ras_jacobi_form", "schwz_ras_get_interior",
     "schwz_ras_true_residual_sq", "schwz_ras_algorithmic_bytes",
 ]
 
@@ -108,6 +108,7 @@ _sig("schwz_csr_destroy", None, [vp])
 _sig("schwz_csr_nnz", i64, [vp])
 _sig("schwz_csr_format", i32, [vp])
 _sig("schwz_csr_symmetric", i32, [vp])
+_sig("schwz_csr_matrix_bytes", i64, [vp, i32])
 _sig("schwz_csr_spmv", i32, [vp, dbl, vp, dbl, vp, i32, vp])
 _sig("schwz_pcg_create", i32, [vp, i32, pvp])
 _sig("schwz_pcg_create_ex", i32, [vp, i32, i32, pvp])
@@ -167,6 +168,7 @@ _sig("schwz_ras_last_inner_stats", i32, [vp, C.POINTER(C.c_int), C.POINTER(dbl)]
 _sig("schwz_ras_restrict", i32, [vp, vp])
 _sig("schwz_ras_vector", i32, [vp, i32, pvp, C.POINTER(i64)])
 _sig("schwz_ras_local_csr", i32, [vp, pvp])
+_sig("schwz_ras_jacobi_form", i32, [vp])
 _sig("schwz_ras_get_interior", i32, [vp, vp, vp])
 _sig("schwz_ras_true_residual_sq", i32, [vp, C.POINTER(dbl), vp])
 _sig("schwz_ras_algorithmic_bytes", i64, [vp, i32])

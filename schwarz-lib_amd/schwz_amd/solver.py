@@ -164,6 +164,15 @@ class HipBackend:
         return core.Subdomain(problem, P, me, overlap, first_row)
 
 
+def _ratio(a, b):
+    """a / b as the reference's double arithmetic gives it (solve.cpp:906-915): a zero initial
+    residual yields NaN (0/0) or inf, never an exception, and NaN compares false against the
+    tolerance, so such a run simply keeps iterating like the reference and the C++ mirror."""
+    if b == 0.0:
+        return float("nan") if a == 0.0 or a != a else float("inf")
+    return a / b
+
+
 def _local_solver_code(settings):
     ls = settings.local_solver
     if ls == SOLVER_ITERATIVE_GINKGO:
@@ -275,6 +284,15 @@ class SolverRAS:
                 part = prob.partition_graph(P) if P > 1 else None
             else:
                 part = s.partition_vector
+                if P > 1:
+                    if part is None:
+                        raise capi.SchwzError(capi.ERR_INVALID,
+                                              "partition 'custom' needs settings.partition_vector")
+                    part = np.asarray(part)
+                    if part.shape != (prob.N,) or part.min() < 0 or part.max() >= P:
+                        raise capi.SchwzError(capi.ERR_INVALID,
+                                              "partition_vector must hold one part id in [0, %d) per row "
+                                              "(%d rows)" % (P, prob.N))
             if P > 1:
                 prob, perm, first_row = prob.permute(part, P)
         else:
@@ -407,6 +425,12 @@ class SolverRAS:
         if cs.enable_onesided and not (cv.enable_global_simple_tree or
                                        cv.enable_decentralized_leader_election):
             raise capi.SchwzError(capi.ERR_INVALID, "Global Convergence check type unspecified")
+        if cs.enable_onesided and cs.enable_overlap and P > 62:
+            # the flooded state carries one bit per subdomain in an int64 (the mirror refuses the
+            # same, host/src/schwarz_base.cpp)
+            raise capi.NotImplementedSchwz(capi.ERR_NOT_IMPLEMENTED,
+                                           "overlapped one-sided mode supports at most 62 subdomains")
+        self._announce_protocol()
         self._lres0 = {me: -1.0 for me in self.subdomains}
         self._flags = {me: False for me in self.subdomains}
         self._gres, self._gres0 = 0.0, -1.0
@@ -426,6 +450,36 @@ class SolverRAS:
             ppd[k] = []
         ppd["global_residual_vector_out"] = [[] for _ in range(P)]
         m.iter_count = 0
+
+    def _announce_protocol(self):
+        """Says once per run which exchange / termination protocol actually runs: several of the
+        reference's flags select variants of MPI RMA that have no counterpart over RCCL and are
+        accepted as aliases (INTEGRATION.md section 1 lists them)."""
+        cs, cv = self.settings.comm_settings, self.settings.convergence_settings
+        if not cs.enable_onesided:
+            return
+        notes = []
+        if cs.enable_put or cs.enable_one_by_one or cs.enable_flush_local or cs.enable_lock_local \
+                or not cs.enable_get or not cs.enable_flush_all or not cs.enable_lock_all:
+            notes.append("RMA flavour flags (put/get, one_by_one, flush/lock) select no different code: "
+                         "halos travel as RCCL send/recv pairs")
+        if cs.enable_overlap:
+            proto = getattr(self, "_termination", "flood")
+            notes.append("termination protocol: " + {
+                "flood": "decentralised flooding of (converged mask, stop iteration) over neighbour messages "
+                         "(conv_tools.hpp:213-275)",
+                "tree": "centralised tree: converged counts reduced to subdomain 0 along a binary tree, the "
+                        "verdict broadcast down it (conv_tools.hpp:147-209)"}[proto])
+            if cv.enable_accumulate:
+                notes.append("enable_accumulate (MPI_Accumulate(MIN) of the norms) has no RCCL counterpart: "
+                             "the flags travel with the halo messages")
+        else:
+            notes.append("one-sided without enable_overlap: local tests, flags all-gathered per iteration "
+                         "(a host collective stands in for the window reads)")
+        if not cv.put_all_local_residual_norms:
+            notes.append("put_all_local_residual_norms=false changes nothing: norms never travel in one-sided mode")
+        for n in notes:
+            self._print(" [schwz] " + n)
 
     def _step_overlapped(self):
         """`enable_onesided` + `enable_overlap`: the asynchronous flavour of the iteration as
@@ -483,7 +537,7 @@ class SolverRAS:
                 raise capi.SchwzError(capi.ERR_DIVERGED, "local residual is NaN")
             ppd["local_residual_vector_out"].append(lres)
             m.current_residual_norm = lres
-            if tol > 0.0 and lres / self._lres0[me] <= tol:
+            if tol > 0.0 and _ratio(lres, self._lres0[me]) <= tol:
                 self._mask[me] |= 1 << me
             if self._mask[me] == full and self._stop[me] == NEVER:
                 self._stop[me] = it + P
@@ -574,11 +628,11 @@ class SolverRAS:
                 self._gres = gres
                 if self._gres0 < 0.0:
                     self._gres0 = gres
-                self._num_converged = P if gres / self._gres0 <= tol else 0
+                self._num_converged = P if _ratio(gres, self._gres0) <= tol else 0
             elif cs.enable_onesided:
                 # local test (solve.cpp:913-915) + monotone flags (conv_tools.hpp:249-251)
                 for me, _ in locals_:
-                    if lres[me] / self._lres0[me] <= tol:
+                    if _ratio(lres[me], self._lres0[me]) <= tol:
                         self._flags[me] = True
                 allflags = comm.allgather_scalars(
                     {me: float(self._flags[me]) for me, _ in locals_})

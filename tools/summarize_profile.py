@@ -15,6 +15,7 @@ for 16-byte-per-lane streaming stores.
 """
 import csv
 import glob
+import hashlib
 import json
 import os
 import shutil
@@ -23,6 +24,18 @@ from collections import defaultdict
 
 TRACKED = ("spmv_pair_kernel<6,", "spmv_pair_kernel<7,", "spmv_pair_kernel<5,", "spmv_pair_kernel<1,", "spmv_pattern_kernel<1,",
            "spmv_dict_kernel<1>", "spmv_tiled2_kernel<1>", "cg_update_kernel", "cg_direction_kernel")
+
+
+def kernel_source_hash(root):
+    """The same hash bench.py computes: traffic figures are only quoted for the kernel sources
+    they were measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(root, "schwarz-lib_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def read_counter(dirname, counter):
@@ -69,6 +82,7 @@ def main():
                              source=tag + "_summary.json",
                              note="(2*FETCH_SIZE + WRITE_SIZE) KiB per launch, separate --pmc passes")
     if ent:
+        ent["kernel_source_hash"] = kernel_source_hash(root)
         allent = {}
         if os.path.exists(tpath):  # one entry per grid shape: keep the others
             try:
