@@ -101,6 +101,11 @@ int schwz_csr_format(const schwz_csr *A);
  * launch); such a matrix need not come from the reference's symmetric problems -- nothing is
  * assumed, the check runs on every upload.  0 otherwise. */
 int schwz_csr_symmetric(const schwz_csr *A);
+/* > 0 when the upload found the matrix to be a 3-D stencil in the canonical row-pair layout
+ * {-PL, -NX, -1, 0, +1, +NX, +PL} and prepared the z-sweep walk of the CG update launch (bands of rows
+ * swept through consecutive planes, operands from an LDS ring of plane windows; csrc/spmv_pair.hip):
+ * the number of workgroup slots of that walk.  0: chunk-by-chunk gathers. */
+int schwz_csr_sweep_slots(const schwz_csr *A);
 /* bytes of MATRIX data one SpMV pass reads in the coding `variant` launches (0: the coding the upload
  * chose, schwz_csr_format; anything else: plain CSR = 12 nnz + 4 (rows + 1), the figure of SURVEY 8(d)).
  * bench.py prices its roofline fraction on these bytes (+ the vector bytes of the launch). */

@@ -99,6 +99,16 @@ struct CsrView {
     // patterns inside the layout gather its 6 outer slots and take the operands of the offset-0 slot
     // from the -1 and +1 gathers.
     int pair_canon[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // z-sweep ("brick") walk of a canonical 3-D stencil layout {-PL, -NX, -1, 0, +1, +NX, +PL} (spmv_pair.hip):
+    // a workgroup keeps a band of sweep_T rows and walks it through consecutive planes (stride PL), the
+    // window [band - NX, band + T + NX) of each plane staged once in an LDS ring.  sweep_seg: one
+    // {band, z0, z1, 0} per workgroup slot (z0 == z1: empty); sweep_gen: the chunks of 512 rows no segment
+    // covers (boundary planes of a subdomain, overlap rows), walked the generic way by sweep_gen_blocks more
+    // workgroups of the same launch.  sweep_nslots == 0: not built.
+    int sweep_T = 0, sweep_nx = 0, sweep_nslots = 0, sweep_ngen = 0, sweep_gen_blocks = 0;
+    int64_t sweep_pl = 0;
+    const int4 *sweep_seg = nullptr;
+    const schwz_idx *sweep_gen = nullptr;
 };
 
 // epilogues of the tiled SpMV kernel
@@ -149,6 +159,7 @@ struct SpmvArgs {
     double cg_rtol = 0.0;       // kSpmvDirDotSym: relative tolerance of the stopping test
     // kSpmvCgUpdate with cg_x == nullptr: x is not touched, alpha is stored here instead (workgroup 0)
     double *alpha_out = nullptr;
+    int sweep = 0;  // set by launch_spmv_pair: this launch walks the matrix in z-sweeps (CsrView::sweep_*)
 };
 
 // launch grid of the streaming vector kernels: one lane per element up to kMaxGrid workgroups
@@ -232,6 +243,7 @@ struct schwz_csr {
     void *d_pat_id = nullptr, *d_tile_table = nullptr, *d_tbl_desc = nullptr, *d_tbl_len = nullptr, *d_tbl_val = nullptr,
          *d_tbl_delta = nullptr;
     void *d_pair_rle = nullptr;
+    void *d_sweep_seg = nullptr, *d_sweep_gen = nullptr;
     void *d_pair_id = nullptr, *d_tile_ptable = nullptr, *d_ptbl_desc = nullptr, *d_ptbl_len = nullptr,
          *d_ptbl_val = nullptr, *d_ptbl_meta = nullptr, *d_chunk_dual = nullptr;
     void *d_tile_dual = nullptr;

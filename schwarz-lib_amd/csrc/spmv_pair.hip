@@ -32,6 +32,8 @@ namespace schwz {
 constexpr int kPairPats = 64;      // patterns per table
 constexpr int kPairEntries = 512;  // staged entries per table (npat * stride)
 constexpr int kPairChunk = 8;      // gathers issued back to back per lane
+// dynamic shared memory of every launch: values (16 B), offsets (4 B) per staged entry, group masks
+constexpr int kPairTableLds = kPairEntries * 16 + kPairEntries * 4 + (kPairEntries / 4) * 4;
 
 __host__ __device__ inline int pair_stride(int lmax, int ch = kPairChunk) { return (lmax + ch - 1) / ch * ch; }
 
@@ -60,15 +62,18 @@ template <int MODE, bool WIDE, bool SINGLE>
 __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a)
 {
 #pragma clang fp contract(off)
-    __shared__ PairVal pv[kPairEntries];
-    __shared__ int poff[kPairEntries];             // col - row of the entry
+    // the staged table lives in dynamic shared memory (kPairTableLds bytes, every launch passes them): the
+    // z-sweep walk lays its ring of plane windows over it once the canonical slots have been derived
+    extern __shared__ __attribute__((aligned(16))) char pair_lds[];
+    PairVal *const pv = reinterpret_cast<PairVal *>(pair_lds);
+    int *const poff = reinterpret_cast<int *>(pair_lds + kPairEntries * sizeof(PairVal));  // col - row of the entry
+    int *const pmask = poff + kPairEntries;  // per group of CH entries: bit k = row r has entry k, bit 8+k = row r+1
     // gathers issued back to back per lane; the upper-triangle tables of kSpmvDotSym are about half as long
     constexpr bool kDirVec = MODE == kSpmvDirDotSymVec;
     constexpr bool kDir = MODE == kSpmvDirDotSym || kDirVec;
     constexpr bool kSym = MODE == kSpmvDotSym || kDir;
     constexpr int CH = kSym ? kPairChunk / 2 : kPairChunk;
     constexpr bool kDotOnly = MODE == kSpmvDotOnly || kSym;
-    __shared__ int pmask[kPairEntries / CH];  // per group of CH entries: bit k = row r has entry k, bit 8+k = row r+1
     __shared__ int plen[kPairPats];            // length | (a gathered entry has col - row == 0) << 16
     __shared__ int pmin[kPairPats], pmax[kPairPats];  // smallest / largest col - row the pattern gathers at
     // canonical stencil layout (CsrView::pair_canon): every pattern expanded to the 7 fixed slots, with
@@ -349,11 +354,142 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
         }
     };
 
+    // pattern id of the pair starting at row ra of `chunk` (workgroup-uniform)
+    auto pair_pid = [&](int chunk, int ra) -> int {
+        int pid;
+        uint4 rle = {0xffffu, 0u, 0u, 0u};
+        if (A.pair_rle) {
+            // chunk is workgroup-uniform and the table is never written by a kernel: read it through
+            // the constant address space, i.e. with a scalar load that costs no vector-memory slot
+            typedef const unsigned __attribute__((address_space(4))) *const_words;
+            const const_words q = (const_words)(uintptr_t)(A.pair_rle + chunk);
+            rle.x = q[0];
+            rle.y = q[1];
+            rle.z = q[2];
+            rle.w = q[3];
+        }
+        if ((rle.x & 0xffffu) != 0xffffu) {
+            // the id of the last run that starts at or before this lane's pair (runs ascending,
+            // unused slots repeat the last run)
+            const unsigned w[4] = {rle.x, rle.y, rle.z, rle.w};
+            pid = (int)((w[0] >> 8) & 0xffu);
+#pragma unroll
+            for (int k = 1; k < 8; ++k) {
+                const unsigned e = (w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+                if ((unsigned)tid >= (e & 0xffu)) pid = (int)(e >> 8);
+            }
+        } else {
+            pid = A.pair_id[ra >> 1];
+        }
+        return pid;
+    };
     // Fixed chunks of 512 consecutive rows, one pair per lane: nothing but the chunk's table id has
     // to be looked up before the pattern ids and the gathers can be requested.
     if (SINGLE) stage_table(0);
-    for (int j = slot; j < slots; j += per_xcd) {
-        const int chunk = xcd_chunk(nchunks, sh, xcd, j);
+    // z-sweep walk (CsrView::sweep_*): the first sweep_nslots workgroups each take one segment -- a band
+    // of T rows through the planes z0 <= z < z1 -- and read every operand of the canonical stencil layout
+    // from an LDS ring of plane windows [band - NX, band + T + NX), each window fetched ONCE with
+    // coalesced 16-byte loads, two planes ahead of its use.  Same products, same order, same masks as
+    // accumulate_canon: same bits.  The next sweep_gen_blocks workgroups walk the chunks no segment
+    // covers the generic way (loop below); the rest of the grid only writes its zero partial sums.
+    constexpr bool kSweepMode = SINGLE && MODE == kSpmvCgUpdate;
+    const bool listed = kSweepMode && a.sweep != 0;
+    if (kSweepMode && listed && (int)blockIdx.x < A.sweep_nslots) {
+        double *ring = reinterpret_cast<double *>(pair_lds);  // over the staged table: only cpv / cmask are used from here on
+        const int4 sg = A.sweep_seg[blockIdx.x];
+        const int T = A.sweep_T, NX = A.sweep_nx, W = T + 2 * NX, npieces = W / 2;
+        const int64_t PL = A.sweep_pl;
+        const int band = sg.x, z0 = sg.y, z1 = sg.z;
+        constexpr int NL = 4;  // 16-byte pieces of a window per lane (W <= 2048)
+        constexpr int kSlots = 4;
+        const int nplanes = (int)(A.nrows / PL);
+        auto load_window = [&](int z, pvd2 (&reg)[NL]) {
+            const int64_t base = (int64_t)z * PL + (int64_t)band * T - NX;
+#pragma unroll
+            for (int k = 0; k < NL; ++k) {
+                const int pc = tid + k * kBlock;
+                const int64_t g = base + 2 * pc;
+                pvd2 v = {0.0, 0.0};
+                if (pc < npieces && z >= 0 && z <= nplanes && g >= 0 && g + 2 <= A.ncols) __builtin_memcpy(&v, a.x + g, 16);
+                reg[k] = v;
+            }
+        };
+        auto store_window = [&](int z, const pvd2 (&reg)[NL]) {
+            double *slot_p = ring + (size_t)((z + kSlots) % kSlots) * W;
+#pragma unroll
+            for (int k = 0; k < NL; ++k) {
+                const int pc = tid + k * kBlock;
+                if (pc < npieces) *reinterpret_cast<pvd2 *>(slot_p + 2 * pc) = reg[k];
+            }
+        };
+        if (z0 < z1) {
+            pvd2 reg[NL];
+            load_window(z0 - 1, reg);
+            store_window(z0 - 1, reg);
+            load_window(z0, reg);
+            store_window(z0, reg);
+            load_window(z0 + 1, reg);
+            for (int z = z0; z < z1; ++z) {
+                store_window(z + 1, reg);
+                lds_barrier();
+                if (z + 1 < z1) load_window(z + 2, reg);  // in flight while plane z is computed
+                const double *cur = ring + (size_t)((z + kSlots) % kSlots) * W;
+                const double *prv = ring + (size_t)((z - 1 + kSlots) % kSlots) * W;
+                const double *nxt = ring + (size_t)((z + 1 + kSlots) % kSlots) * W;
+                for (int h = 0; h < T / kPairRows; ++h) {
+                    const int64_t row0 = (int64_t)z * PL + (int64_t)band * T + h * kPairRows;
+                    const int chunk = (int)(row0 / kPairRows);
+                    const int ra = (int)row0 + 2 * tid;
+                    const int i0 = NX + h * kPairRows + 2 * tid;
+                    // r (and x) only stream through: non-temporal, requested ahead of the LDS reads
+                    const pvd2 rr = __builtin_nontemporal_load(reinterpret_cast<const pvd2 *>(a.cg_r + ra));
+                    pvd2 cgx = {0.0, 0.0};
+                    if (a.cg_x) cgx = __builtin_nontemporal_load(reinterpret_cast<const pvd2 *>(a.cg_x + ra));
+                    double od0 = 1.0, od1 = 1.0;
+                    if (a.diag_mode == 1) {
+                        const pvd2 dd = __builtin_nontemporal_load(reinterpret_cast<const pvd2 *>(a.dinv + ra));
+                        od0 = dd.x;
+                        od1 = dd.y;
+                    } else if (a.diag_mode == 3) {
+                        od0 = od1 = a.diag_uniform;
+                    }
+                    const int pid = pair_pid(chunk, ra);
+                    const int mask = cmask[pid];
+                    pvd2 t[7];
+                    t[3] = *reinterpret_cast<const pvd2 *>(cur + i0);
+                    t[2].x = cur[i0 - 1];
+                    t[2].y = t[3].x;
+                    t[4].x = t[3].y;
+                    t[4].y = cur[i0 + 2];
+                    t[1] = *reinterpret_cast<const pvd2 *>(cur + i0 - NX);
+                    t[5] = *reinterpret_cast<const pvd2 *>(cur + i0 + NX);
+                    t[0] = *reinterpret_cast<const pvd2 *>(prv + i0);
+                    t[6] = *reinterpret_cast<const pvd2 *>(nxt + i0);
+                    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) {
+                        const PairVal v = cpv[pid * 8 + k];
+                        if ((mask >> k) & 1) s0 += v.a * t[k].x;
+                        if ((mask >> (kPairChunk + k)) & 1) s1 += v.b * t[k].y;
+                    }
+                    double y0, y1, p0, p1;
+                    finish(ra, s0, 0.0, false, t[3].x, rr.x, od0, y0, p0);
+                    finish(ra + 1, s1, 0.0, false, t[3].y, rr.y, od1, y1, p1);
+                    const pvd2 rn = {y0, y1};
+                    __builtin_nontemporal_store(rn, reinterpret_cast<pvd2 *>(a.cg_r + ra));
+                    if (a.cg_x) {
+                        const pvd2 xx = {cgx.x + p0, cgx.y + p1};
+                        __builtin_nontemporal_store(xx, reinterpret_cast<pvd2 *>(a.cg_x + ra));
+                    }
+                }
+            }
+        }
+    }
+    const int gen_first = listed ? (int)blockIdx.x - A.sweep_nslots : slot;
+    const int gen_count = listed ? ((int)blockIdx.x < A.sweep_nslots + A.sweep_gen_blocks ? A.sweep_ngen : 0) : slots;
+    const int gen_stride = listed ? A.sweep_gen_blocks : per_xcd;
+    for (int j = gen_first; j >= 0 && j < gen_count; j += gen_stride) {
+        const int chunk = listed ? A.sweep_gen[j] : xcd_chunk(nchunks, sh, xcd, j);
         if (chunk < 0) continue;
         const int tb = SINGLE ? 0 : A.chunk_ptable[chunk];
         const bool dual_t = dual && (!A.chunk_dual || A.chunk_dual[chunk]);
@@ -425,31 +561,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
         pvd2 own = {0.0, 0.0};
         bool own_from_gathers = false;
         if (tb >= 0) {
-            int pid;
-            uint4 rle = {0xffffu, 0u, 0u, 0u};
-            if (A.pair_rle) {
-                // chunk is workgroup-uniform and the table is never written by a kernel: read it through
-                // the constant address space, i.e. with a scalar load that costs no vector-memory slot
-                typedef const unsigned __attribute__((address_space(4))) *const_words;
-                const const_words q = (const_words)(uintptr_t)(A.pair_rle + chunk);
-                rle.x = q[0];
-                rle.y = q[1];
-                rle.z = q[2];
-                rle.w = q[3];
-            }
-            if ((rle.x & 0xffffu) != 0xffffu) {
-                // the id of the last run that starts at or before this lane's pair (runs ascending,
-                // unused slots repeat the last run)
-                const unsigned w[4] = {rle.x, rle.y, rle.z, rle.w};
-                pid = (int)((w[0] >> 8) & 0xffu);
-#pragma unroll
-                for (int k = 1; k < 8; ++k) {
-                    const unsigned e = (w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
-                    if ((unsigned)tid >= (e & 0xffu)) pid = (int)(e >> 8);
-                }
-            } else {
-                pid = A.pair_id[ra >> 1];
-            }
+            const int pid = pair_pid(chunk, ra);
             const int lenz = plen[pid];
             const int len = lenz & 0xffff;
             const int base = pid * ls;
@@ -551,13 +663,29 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
 int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s)
 {
     const bool wide = A.ncols >= (int64_t(1) << 28);  // byte offsets of x beyond 32 bits
+    if (mode == kSpmvCgUpdate && !wide && A.pair_single && A.sweep_nslots > 0 &&
+        A.sweep_nslots + A.sweep_gen_blocks <= grid) {
+        // z-sweep walk: the LDS ring of plane windows is dynamic shared memory (only this launch form pays for it)
+        const char *sweep_env = std::getenv("SCHWZ_CG_SWEEP");  // read per launch: tests switch it
+        if (!(sweep_env && sweep_env[0] == '0')) {
+            static const hipError_t attr = hipFuncSetAttribute((const void *)spmv_pair_kernel<kSpmvCgUpdate, false, true>,
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);
+            (void)attr;
+            SpmvArgs b = a;
+            b.sweep = 1;
+            const size_t lds = std::max<size_t>(kPairTableLds, (size_t)4 * (A.sweep_T + 2 * A.sweep_nx) * sizeof(double));
+            hipLaunchKernelGGL((spmv_pair_kernel<kSpmvCgUpdate, false, true>), dim3(grid), dim3(kBlock), lds, s, A, b);
+            SCHWZ_HIP_TRY(hipGetLastError());
+            return SCHWZ_OK;
+        }
+    }
 #define SCHWZ_PAIR_LAUNCH(M)                                                                          \
     if (wide)                                                                                         \
-        hipLaunchKernelGGL((spmv_pair_kernel<M, true, false>), dim3(grid), dim3(kBlock), 0, s, A, a);  \
+        hipLaunchKernelGGL((spmv_pair_kernel<M, true, false>), dim3(grid), dim3(kBlock), kPairTableLds, s, A, a);  \
     else if (A.pair_single)                                                                           \
-        hipLaunchKernelGGL((spmv_pair_kernel<M, false, true>), dim3(grid), dim3(kBlock), 0, s, A, a);  \
+        hipLaunchKernelGGL((spmv_pair_kernel<M, false, true>), dim3(grid), dim3(kBlock), kPairTableLds, s, A, a);  \
     else                                                                                              \
-        hipLaunchKernelGGL((spmv_pair_kernel<M, false, false>), dim3(grid), dim3(kBlock), 0, s, A, a);
+        hipLaunchKernelGGL((spmv_pair_kernel<M, false, false>), dim3(grid), dim3(kBlock), kPairTableLds, s, A, a);
     switch (mode) {
     case kSpmvPlain: SCHWZ_PAIR_LAUNCH(kSpmvPlain) break;
     case kSpmvDot: SCHWZ_PAIR_LAUNCH(kSpmvDot) break;
@@ -909,6 +1037,140 @@ int build_spmv_pair(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, con
         }
     }
     A->v.pair_sym_base = sym_base;
+    // z-sweep segments (CsrView::sweep_*) for a canonical layout {-PL, -NX, -1, 0, +1, +NX, +PL} with
+    // PL a multiple of the band length: SCHWZ_SPMV_SWEEP=0 off, =2 also below a million rows (tests);
+    // SCHWZ_SWEEP_T (512 / 1024 rows per band), SCHWZ_SWEEP_L (planes per segment) override the defaults.
+    {
+        const char *sw_env = std::getenv("SCHWZ_SPMV_SWEEP");
+        const int sw_mode = sw_env ? std::atoi(sw_env) : 1;
+        const int *cn = A->v.pair_canon;
+        const int64_t NX = cn[5], PL = cn[6];
+        const bool shape_ok = single && cn[7] && cn[0] == -PL && cn[1] == -NX && NX >= 2 && PL > NX && NX % 2 == 0 &&
+                              PL % kPairRows == 0;
+        if (sw_mode != 0 && shape_ok && (nrows >= (int64_t(1) << 20) || sw_mode == 2) && nrows >= 3 * PL) {
+            const PairTable &tb = tables[0];
+            // a pattern fits the layout when each of its entries has one of the seven offsets (the device
+            // stages cmask the same way, stage_table)
+            std::vector<uint8_t> pat_ok((size_t)tb.npat, 1);
+            for (int q = 0; q < tb.npat; ++q) {
+                if ((int)tb.len[(size_t)q] > kPairChunk) pat_ok[(size_t)q] = 0;
+                for (int k = 0; k < (int)tb.len[(size_t)q]; ++k) {
+                    const schwz_idx off = tb.ent[(size_t)q * tb.lmax + k].off;
+                    bool in = false;
+                    for (int t = 0; t < 7; ++t) in = in || cn[t] == off;
+                    if (!in) pat_ok[(size_t)q] = 0;
+                }
+            }
+            std::vector<uint8_t> chunk_ok((size_t)nchunks, 0);
+            for (int c = 0; c < nchunks; ++c) {
+                const int64_t p0 = (int64_t)c * (kPairRows / 2), p1 = p0 + kPairRows / 2;
+                if (p1 * 2 > nrows) continue;  // a partial chunk stays generic
+                bool ok = true;
+                for (int64_t q = p0; q < p1 && ok; ++q) ok = pat_ok[(size_t)pair_id[(size_t)q]] != 0;
+                chunk_ok[(size_t)c] = ok ? 1 : 0;
+            }
+            const char *t_env = std::getenv("SCHWZ_SWEEP_T"), *l_env = std::getenv("SCHWZ_SWEEP_L");
+            int T = t_env ? std::atoi(t_env) : (NX >= 512 ? 1024 : 512);
+            if (T != 512 && T != 1024) T = 512;
+            if (PL % T) T = 512;
+            const int64_t W = T + 2 * NX;
+            const int nplanes = (int)(nrows / PL), bands = (int)(PL / T), cpb = T / kPairRows, cpp = (int)(PL / kPairRows);
+            const int grid = ((std::min<int64_t>((int64_t)tiles.size() - 1, kMaxGrid) + kXcds - 1) / kXcds) * kXcds;
+            if (W <= 2048 && bands >= 1 && nplanes >= 3) {
+                // maximal runs of planes in which every chunk of the band is canonical
+                struct Run { int band, z0, z1; };
+                std::vector<Run> runs;
+                int64_t steps = 0;
+                for (int b = 0; b < bands; ++b) {
+                    int z = 0;
+                    while (z < nplanes) {
+                        auto okz = [&](int zz) {
+                            for (int h = 0; h < cpb; ++h)
+                                if (!chunk_ok[(size_t)((int64_t)zz * cpp + (int64_t)b * cpb + h)]) return false;
+                            return true;
+                        };
+                        if (!okz(z)) {
+                            ++z;
+                            continue;
+                        }
+                        int e = z;
+                        while (e < nplanes && okz(e)) ++e;
+                        if (e - z >= 2) {
+                            runs.push_back({b, z, e});
+                            steps += e - z;
+                        }
+                        z = e;
+                    }
+                }
+                std::vector<uint8_t> covered((size_t)nchunks, 0);
+                int L = l_env ? std::atoi(l_env) : 16;
+                if (L < 2) L = 16;
+                // the segments and the workgroups of the generic walk must fit the launch grid
+                auto count = [&](int len) {
+                    int64_t n = 0;
+                    for (const Run &r : runs) n += (r.z1 - r.z0 + len - 1) / len;
+                    return n;
+                };
+                for (const Run &r : runs)
+                    for (int z = r.z0; z < r.z1; ++z)
+                        for (int h = 0; h < cpb; ++h) covered[(size_t)((int64_t)z * cpp + (int64_t)r.band * cpb + h)] = 1;
+                std::vector<schwz_idx> gen;
+                for (int c = 0; c < nchunks; ++c)
+                    if (!covered[(size_t)c]) gen.push_back(c);
+                const int gen_blocks = (int)std::min<size_t>(gen.size(), 256);
+                while (count(L) + kXcds > grid - gen_blocks && L < (1 << 20)) L += 4;
+                // deal: XCD x takes the bands [x * bands / 8, (x + 1) * bands / 8) (a band's window shares its
+                // NX-row halos with the neighbouring bands: the same L2), segment by segment of the z range
+                std::vector<std::vector<int4>> per_xcd(kXcds);
+                struct Seg { int band, z0, z1; };
+                std::vector<Seg> segs;
+                for (const Run &r : runs) {
+                    const int nseg = (r.z1 - r.z0 + L - 1) / L, len = (r.z1 - r.z0 + nseg - 1) / nseg;
+                    for (int z = r.z0; z < r.z1; z += len) segs.push_back({r.band, z, std::min(z + len, r.z1)});
+                }
+                std::stable_sort(segs.begin(), segs.end(), [](const Seg &x, const Seg &y) {
+                    return x.z0 != y.z0 ? x.z0 < y.z0 : x.band < y.band;
+                });
+                for (const Seg &sgm : segs) {
+                    const int x = bands >= 2 * kXcds ? (int)((int64_t)sgm.band * kXcds / bands) : -1;
+                    int4 v;
+                    v.x = sgm.band;
+                    v.y = sgm.z0;
+                    v.z = sgm.z1;
+                    v.w = 0;
+                    if (x >= 0) {
+                        per_xcd[(size_t)x].push_back(v);
+                    } else {  // few bands: round robin
+                        size_t best = 0;
+                        for (size_t k = 1; k < (size_t)kXcds; ++k)
+                            if (per_xcd[k].size() < per_xcd[best].size()) best = k;
+                        per_xcd[best].push_back(v);
+                    }
+                }
+                size_t depth = 0;
+                for (const auto &l : per_xcd) depth = std::max(depth, l.size());
+                std::vector<int4> slots_v(depth * kXcds);
+                for (size_t q = 0; q < depth; ++q)
+                    for (int x = 0; x < kXcds; ++x) {
+                        int4 v;
+                        v.x = v.y = v.z = v.w = 0;
+                        if (q < per_xcd[(size_t)x].size()) v = per_xcd[(size_t)x][q];
+                        slots_v[q * kXcds + x] = v;
+                    }
+                if (!segs.empty() && (int64_t)slots_v.size() + gen_blocks <= grid && steps * T * 2 >= nrows) {
+                    if ((rc = upv(slots_v, &A->d_sweep_seg)) || (rc = upv(gen, &A->d_sweep_gen))) return rc;
+                    A->v.sweep_T = T;
+                    A->v.sweep_nx = (int)NX;
+                    A->v.sweep_pl = PL;
+                    A->v.sweep_nslots = (int)slots_v.size();
+                    A->v.sweep_ngen = (int)gen.size();
+                    A->v.sweep_gen_blocks = gen_blocks;
+                    A->v.sweep_seg = (const int4 *)A->d_sweep_seg;
+                    A->v.sweep_gen = (const schwz_idx *)A->d_sweep_gen;
+                }
+            }
+        }
+    }
     {
         // what a pass over the coded matrix reads: per chunk its 16-byte run-length record, or one byte per
         // pair where the ids do not run-length code; the chunk's table id unless one table serves the whole
@@ -956,6 +1218,10 @@ int pair_set_dual_split(schwz_csr *A, const schwz_idx *h_rp, const schwz_idx *h_
 
 void free_spmv_pair(schwz_csr *A)
 {
+    (void)hipFree(A->d_sweep_seg);
+    (void)hipFree(A->d_sweep_gen);
+    A->d_sweep_seg = A->d_sweep_gen = nullptr;
+    A->v.sweep_nslots = 0;
     (void)hipFree(A->d_pair_rle);
     A->d_pair_rle = nullptr;
     A->v.pair_rle = nullptr;

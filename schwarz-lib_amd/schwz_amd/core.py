@@ -57,6 +57,10 @@ class Csr:
         """True when the upload found the (row-pair coded) matrix symmetric bit for bit."""
         return bool(lib.schwz_csr_symmetric(self.h))
 
+    def sweep_slots(self):
+        """Workgroup slots of the z-sweep walk of the CG update launch (0: not a canonical 3-D stencil)."""
+        return int(lib.schwz_csr_sweep_slots(self.h))
+
     def algorithmic_bytes(self):
         # SURVEY 8(d): 12 nnz + 4 (rows+1) + 16 rows
         return 12 * self.nnz + 4 * (self.nrows + 1) + 16 * self.nrows

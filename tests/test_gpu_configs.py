@@ -117,9 +117,9 @@ def test_config4_per_gpu_size_overlapped_properties(schwz, oracle, torch_cuda):
     10 CG iterations + Jacobi per local solve.  The oracle cannot run this size; checked instead:
     sizes of SURVEY Appendix B (C5 end slab); the run does not stop early and every subdomain
     records every iteration; the reported true residual equals an independent recomputation (plain
-    torch stencil on the assembled solution); the solution is positive, below the discrete maximum
-    principle's bound and symmetric under reversal of the ordering (the two slabs mirror each
-    other); and the stop agreement of the flooding protocol fires at the iteration the oracle
+    torch stencil on the assembled solution); the solution is finite, bounded by the discrete
+    maximum principle's bound and symmetric under reversal of the ordering (the two slabs mirror
+    each other); and the stop agreement of the flooding protocol fires at the iteration the oracle
     predicts for the same number of subdomains."""
     torch = torch_cuda
     free, _ = torch.cuda.mem_get_info()
@@ -149,7 +149,10 @@ def test_config4_per_gpu_size_overlapped_properties(schwz, oracle, torch_cuda):
     res = _stencil_residual_norm(torch, x, shape)
     assert abs(res - out["residual_norm"]) <= 1e-8 * out["rhs_norm"]
     assert abs(out["rhs_norm"] - np.sqrt(N)) <= 1e-9 * np.sqrt(N)
-    assert x.min() > 0.0 and x.max() <= 3.0 * (shape[0] + 1) ** 2 / 8.0
+    # (eight outer iterations of ten CG steps are far from converged at this size: the iterate still
+    # carries a sawtooth of ~2e-4 of the solution scale next to the boundary -- the oracle shows the
+    # same relative amplitude at 128 x 128 x 32 -- so positivity is NOT a property to assert here)
+    assert np.isfinite(x).all() and np.abs(x).max() <= 3.0 * (shape[0] + 1) ** 2 / 8.0
     assert np.abs(x - x[::-1]).max() <= 1e-6 * np.abs(x).max()
     del x
     torch.cuda.empty_cache()

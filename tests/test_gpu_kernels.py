@@ -648,6 +648,69 @@ def test_deferred_x_update_is_bit_identical(schwz, oracle, torch_cuda, monkeypat
         assert np.array_equal(x_plain, x_def), rtol
 
 
+def _slab_local_matrix(schwz, shape, P, me):
+    """local_matrix of subdomain `me` of a z-slab partition: interior planes in natural order, the
+    overlap planes appended at the end (rows next to them carry one far-away column)."""
+    prob = schwz.Problem.laplacian(3, *shape)
+    sd = schwz.Subdomain(prob, P, me, 2, schwz.partition_regular(prob.N, P))
+    return sd.local_matrix()
+
+
+@pytest.mark.parametrize("case", [("cube", (32, 16, 20), "512"), ("cube", (64, 32, 12), "512"), ("cube", (64, 32, 12), "1024"),
+                                  ("cube", (16, 32, 9), "512"), ("slab", (32, 32, 30), "512"), ("slab", (32, 32, 30), "1024"),
+                                  ("end", (32, 16, 24), "512")])
+def test_z_sweep_update_launch_matches_the_gather_walk(schwz, oracle, torch_cuda, monkeypatch, case):
+    """The z-sweep walk of the q-free update launch (a band of rows swept through consecutive planes,
+    every operand of the canonical stencil layout read from an LDS ring of plane windows) against the
+    chunk-by-chunk gather walk of the same launch: forced on small matrices (SCHWZ_SPMV_SWEEP=2), cubes
+    with one / two / four bands and 512- or 1024-row bands, the local matrices of a middle and an end
+    slab (appended overlap planes, boundary planes walked the generic way in the same launch), with
+    the in-launch and the deferred x update.  Every row sees the same products in the same order, so
+    one CG iteration is bit identical; later ones differ only through the order in which the
+    per-workgroup partial sums of r.z are folded."""
+    torch = torch_cuda
+    kind, shape, T = case
+    monkeypatch.setenv("SCHWZ_SPMV_PAIR", "2")
+    monkeypatch.setenv("SCHWZ_SPMV_SWEEP", "2")
+    monkeypatch.setenv("SCHWZ_SWEEP_T", T)
+    monkeypatch.setenv("SCHWZ_SWEEP_L", "4")
+    if kind == "cube":
+        rp, col, val = oracle.laplacian3d(*shape)
+    else:
+        rp, col, val = _slab_local_matrix(schwz, shape, 3, 1 if kind == "slab" else 2)
+    n = len(rp) - 1
+    rng = np.random.default_rng(11)
+    b = rng.standard_normal(n)
+    x0 = 0.1 * rng.standard_normal(n)
+    A = schwz.Csr(rp, col, val)
+    assert A.format() == 3 and A.symmetric() and A.sweep_slots() > 0
+    cg = schwz.Pcg(A, 1)
+
+    def solve(sweep, defer, iters, rtol=0.0):
+        monkeypatch.setenv("SCHWZ_CG_SWEEP", sweep)
+        monkeypatch.setenv("SCHWZ_CG_DEFERX", defer)
+        d_b, d_x = _dev(torch, b), _dev(torch, x0)
+        it, rn = cg.solve(d_b.data_ptr(), d_x.data_ptr(), rtol, iters)
+        return it, rn, d_x.cpu().numpy()
+
+    for defer in ("0", "2"):
+        it0, rn0, x_ref = solve("0", defer, 1)
+        it1, rn1, x_sw = solve("1", defer, 1)
+        assert it0 == it1 == 1
+        assert np.array_equal(x_ref, x_sw)
+        assert abs(rn0 - rn1) <= 1e-14 * rn0
+        for iters in (2, 7, 20):
+            _, rn0, x_ref = solve("0", defer, iters)
+            _, rn1, x_sw = solve("1", defer, iters)
+            assert np.abs(x_ref - x_sw).max() <= 1e-12 * np.abs(x_ref).max(), (defer, iters)
+            assert abs(rn0 - rn1) <= 1e-10 * rn0
+    exp, _, _ = oracle.pcg(rp, col, val, b, x0, 1, 0.0, 20)
+    assert np.abs(solve("1", "2", 20)[2] - exp).max() <= RTOL_CG * np.abs(exp).max()
+    it0, _, x_ref = solve("0", "2", n, 1e-9)
+    it1, _, x_sw = solve("1", "2", n, 1e-9)
+    assert abs(it0 - it1) <= 1 and np.abs(x_ref - x_sw).max() <= 1e-8 * np.abs(x_ref).max()
+
+
 def test_pcg_accepts_a_right_hand_side_that_is_only_8_byte_aligned(schwz, oracle, torch_cuda):
     """The CG start residual reads b with 16-byte loads; the caller's b need only be aligned like
     a double (x must be 16-byte aligned, which the entry point checks)."""
