@@ -358,6 +358,7 @@ def main():
     mat_bytes = int(lib.schwz_csr_matrix_bytes(csr_h, a.spmv_variant))  # matrix bytes of the launched format
     coded = fmt != 0
     qfree = upd_launches.value > 0
+    csr_spmv_equiv = csr_spmv_bytes
     spmv_avg_ms = tot_ms.value / max(launches.value, 1)
     fmt_name = {3: "row-pair coded", 2: "row-pattern coded", 1: "dictionary coded", 0: "plain CSR"}[fmt]
     spmv_name = {3: "spmv_pair_kernel<kSpmvDot> (q = A p, fused p.q; row-pair pattern coded CSR)",
@@ -390,6 +391,19 @@ def main():
             "spmv_pair_kernel<kSpmvDotOnly> (partial sums of p.(A p), nothing stored; row-pair coded CSR)"
         spmv_tag = "spmv_pair_kernel<7," if sym else "spmv_pair_kernel<5,"
         spmv_fmt_bytes = mat_bytes + 8 * n_rows  # the pair codes and p once; nothing is stored
+        flav = int(lib.schwz_ras_cg_flavour(sd.h))
+        if flav & 8:
+            kernel_name = kernel_name.replace("spmv_pair_kernel<kSpmvCgUpdate>", "spmv_pair_sweep_kernel (z-sweep walk of kSpmvCgUpdate)")
+            dom_tag = "spmv_pair_sweep_kernel<"
+        if flav & 3 == 2:
+            # two launches per iteration: the direction update is fused into the next iteration's p.(A p)
+            # launch (r and p read once each, p' written: 24 n + the pair codes)
+            spmv_name = ("spmv_pair_dirdot_sweep_kernel (z-sweep walk)" if flav & 16 else "spmv_pair_kernel<kSpmvDirDotSym>") + \
+                " (p' = z + beta p and the partial sums of p'.(A p') from the upper triangle of the symmetric " \
+                "row-pair coded matrix in one launch)"
+            spmv_tag = "spmv_pair_dirdot_sweep_kernel<" if flav & 16 else "spmv_pair_kernel<8,"
+            spmv_fmt_bytes = mat_bytes + 24 * n_rows
+            csr_spmv_equiv = csr_spmv_bytes + 24 * n_rows
     else:
         kernel_name, dom_tag, avg_ms, dom_launches = spmv_name, spmv_tag, spmv_avg_ms, launches.value
         dom_fmt_bytes, dom_csr_bytes = spmv_fmt_bytes, csr_spmv_bytes
@@ -437,6 +451,7 @@ def main():
                    "local_tol": 0.0, "overlap": 2, "partition": "regular",
                    "rows_per_gpu": sd.local_size_x, "nnz_per_gpu": sd.nnz_local,
                    "spmv_variant": a.spmv_variant, "matrix_format": fmt_name,
+                   "cg_launches_per_iteration": (2 if int(lib.schwz_ras_cg_flavour(sd.h)) & 3 == 2 else 3),
                    "exchange": ("one-sided overlapped, decentralised stop" if a.overlapped
                                 else "two-sided, all-gathered residual norms") +
                                (", fp32 halos" if a.mixed_halo else ""),
@@ -451,7 +466,7 @@ def main():
         if hist and hist[0] else None,
         "roofline": dict(roof(kernel_name, dom_fmt_bytes, dom_csr_bytes, achieved, avg_ms, dom_launches, dom_tag),
                          ms_per_step_instrumented=1e3 * elapsed_instrumented / a.steps),
-        "roofline_spmv": roof(spmv_name, spmv_fmt_bytes, csr_spmv_bytes, spmv_achieved, spmv_avg_ms,
+        "roofline_spmv": roof(spmv_name, spmv_fmt_bytes, csr_spmv_equiv, spmv_achieved, spmv_avg_ms,
                               launches.value, spmv_tag),
     }
     stream = torch.cuda.current_stream().cuda_stream

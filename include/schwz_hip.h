@@ -136,6 +136,11 @@ int schwz_pcg_create(const schwz_csr *A, int precond, schwz_pcg **out);
  * 1..32) */
 int schwz_pcg_create_ex(const schwz_csr *A, int precond, int block_size, schwz_pcg **out);
 void schwz_pcg_destroy(schwz_pcg *s);
+/* how the last solve iterated (bench.py needs it to name and price its launches): bits 0-1: 0 = q = A p
+ * stored, 1 = q-free, three launches per iteration, 2 = q-free with the direction update fused into the
+ * next iteration's p.(A p) launch (two launches); 4: x += sum alpha_k p_k deferred; 8 / 16: the update /
+ * the fused launch walked the matrix in z-sweeps (csrc/spmv_pair.hip) */
+int schwz_pcg_flavour(const schwz_pcg *s);
 int schwz_pcg_solve(schwz_pcg *s, const double *d_b, double *d_x, double rtol,
                     int max_iters, int *h_iters, double *h_resnorm,
                     schwz_stream stream);
@@ -379,6 +384,8 @@ int schwz_ras_local_csr(schwz_subdomain *sd, schwz_csr **out);
  * scalar (every stencil matrix).  Same values, same bits; bench.py needs it to count the bytes of a
  * launch.  Replaces nothing in the reference (gko::preconditioner::Jacobi stores blocks). */
 int schwz_ras_jacobi_form(const schwz_subdomain *sd);
+/* schwz_pcg_flavour of the subdomain's local CG (0 for the other local solvers) */
+int schwz_ras_cg_flavour(const schwz_subdomain *sd);
 /* copy x~[0:local_size] to the host (synchronous) -- the rank's piece of the
  * solution assembled in Solve::compute_residual_norm (solve.cpp:1025-1085) */
 int schwz_ras_get_interior(schwz_subdomain *sd, double *h_out, schwz_stream stream);

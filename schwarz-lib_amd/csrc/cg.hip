@@ -398,6 +398,8 @@ int schwz_profile_kind(int kind, double *h_total_ms, int64_t *h_launches)
 
 // ---- PCG --------------------------------------------------------------------
 
+int schwz_pcg_flavour(const schwz_pcg *s) { return s ? s->last_flavour : 0; }
+
 int schwz_pcg_create(const schwz_csr *A, int precond, schwz_pcg **out)
 {
     return schwz_pcg_create_ex(A, precond, 1, out);
@@ -793,7 +795,15 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
     }();
     const char *dx_env = std::getenv("SCHWZ_CG_DEFERX");  // read per solve: tests switch it
     const int dx_mode = dx_env ? std::atoi(dx_env) : 1;
-    const bool fusedir = dot_mode == kSpmvDotSym && (fusedir_mode == 2 || (fusedir_mode == 1 && n <= kGraphRows));
+    // ... unless the matrix takes the z-sweep walk (spmv_pair.hip): there the fused launch loads every
+    // element of r and p once instead of gathering both at every entry, and replaces 32 n bytes of the
+    // two launches by 24 n (SCHWZ_CG_SWEEP=0: chunk-by-chunk launches only).
+    const char *sweep_env = std::getenv("SCHWZ_CG_SWEEP");
+    const bool sweep_on = !(sweep_env && sweep_env[0] == '0') && A.sweep_nslots > 0 && s->variant == 0 &&
+                          A.ncols < (int64_t(1) << 28) && A.sweep_nslots + A.sweep_gen_blocks <= gs;
+    const bool sweep_dirdot = sweep_on && A.canon_sym_val && (s->diag.mode == 0 || s->diag.mode == 3);
+    const bool fusedir = dot_mode == kSpmvDotSym &&
+                         (fusedir_mode == 2 || (fusedir_mode == 1 && (n <= kGraphRows || sweep_dirdot)));
     const int flavour = !qfree ? 0 : (fusedir ? 2 : 1);
     // Large systems: x is not touched inside the iteration.  The search directions of up to
     // kDeferDepth iterations stay in a ring (slots 0 and 1 are s->p and the otherwise unused s->q),
@@ -813,6 +823,8 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
             deferx = false;
         }
     }
+    s->last_flavour = flavour | (deferx ? 4 : 0) | (sweep_on && deferx && s->diag.mode != 2 ? 8 : 0) |
+                      (sweep_dirdot && fusedir ? 16 : 0);
     PRing ring;
     const int64_t n_pad = (n + 1) & ~int64_t(1);
     for (int k = 0; k < kDeferDepth; ++k)

@@ -109,6 +109,14 @@ struct CsrView {
     int64_t sweep_pl = 0;
     const int4 *sweep_seg = nullptr;
     const schwz_idx *sweep_gen = nullptr;
+    // per pattern of table 0: its entries expanded to the 7 slots of pair_canon (8 PairVal, slot 7 unused)
+    // and the presence mask (bit k: row r has slot k, bit 8 + k: row r + 1), as stage_table derives them
+    const double *canon_val = nullptr;
+    const int *canon_mask = nullptr;
+    int canon_npat = 0;
+    // the same for the upper-triangle twin of the table (symmetric matrices): slots {0, +1, +NX, +PL}, 4 PairVal
+    const double *canon_sym_val = nullptr;
+    const int *canon_sym_mask = nullptr;
 };
 
 // epilogues of the tiled SpMV kernel
@@ -159,7 +167,10 @@ struct SpmvArgs {
     double cg_rtol = 0.0;       // kSpmvDirDotSym: relative tolerance of the stopping test
     // kSpmvCgUpdate with cg_x == nullptr: x is not touched, alpha is stored here instead (workgroup 0)
     double *alpha_out = nullptr;
-    int sweep = 0;  // set by launch_spmv_pair: this launch walks the matrix in z-sweeps (CsrView::sweep_*)
+    // set by launch_spmv_pair for the companion launch of the z-sweep walk: walk the chunks listed in
+    // CsrView::sweep_gen only; partial sums at [part_offset + blockIdx.x] of banks part_stride apart
+    int sweep = 0;
+    int part_offset = 0, part_stride = 0;
 };
 
 // launch grid of the streaming vector kernels: one lane per element up to kMaxGrid workgroups
@@ -243,7 +254,8 @@ struct schwz_csr {
     void *d_pat_id = nullptr, *d_tile_table = nullptr, *d_tbl_desc = nullptr, *d_tbl_len = nullptr, *d_tbl_val = nullptr,
          *d_tbl_delta = nullptr;
     void *d_pair_rle = nullptr;
-    void *d_sweep_seg = nullptr, *d_sweep_gen = nullptr;
+    void *d_sweep_seg = nullptr, *d_sweep_gen = nullptr, *d_canon_val = nullptr, *d_canon_mask = nullptr,
+         *d_canon_sym_val = nullptr, *d_canon_sym_mask = nullptr;
     void *d_pair_id = nullptr, *d_tile_ptable = nullptr, *d_ptbl_desc = nullptr, *d_ptbl_len = nullptr,
          *d_ptbl_val = nullptr, *d_ptbl_meta = nullptr, *d_chunk_dual = nullptr;
     void *d_tile_dual = nullptr;
@@ -289,6 +301,9 @@ struct schwz_pcg {
     double *p_ring = nullptr;      // kDeferDepth - 2 vectors; slots 0 and 1 of the ring are p and q
     double *alpha_hist = nullptr;  // kDeferDepth
     bool ring_failed = false;
+    // how the last solve iterated: bits 0-1: 0 stored q, 1 q-free (three launches), 2 q-free with the fused
+    // direction + p.(A p) launch; 4: deferred x update; 8: z-sweep walk of the update launch; 16: of the fused launch
+    int last_flavour = 0;
 };
 
 struct schwz_trs {

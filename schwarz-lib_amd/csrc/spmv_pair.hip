@@ -354,13 +354,12 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
         }
     };
 
-    // pattern id of the pair starting at row ra of `chunk` (workgroup-uniform)
-    auto pair_pid = [&](int chunk, int ra) -> int {
-        int pid;
+    // run-length record of a chunk's pattern ids (first word 0xffff: none, the ids are bytes per pair).
+    // chunk is workgroup-uniform and the table is never written by a kernel: read through the constant
+    // address space, i.e. with a scalar load that costs no vector-memory slot
+    auto load_rle = [&](int chunk) -> uint4 {
         uint4 rle = {0xffffu, 0u, 0u, 0u};
         if (A.pair_rle) {
-            // chunk is workgroup-uniform and the table is never written by a kernel: read it through
-            // the constant address space, i.e. with a scalar load that costs no vector-memory slot
             typedef const unsigned __attribute__((address_space(4))) *const_words;
             const const_words q = (const_words)(uintptr_t)(A.pair_rle + chunk);
             rle.x = q[0];
@@ -368,9 +367,13 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
             rle.z = q[2];
             rle.w = q[3];
         }
+        return rle;
+    };
+    // pattern id of the pair starting at row ra: the id of the last run that starts at or before this
+    // lane's pair (runs ascending, unused slots repeat the last run)
+    auto pid_of = [&](const uint4 rle, int ra) -> int {
+        int pid;
         if ((rle.x & 0xffffu) != 0xffffu) {
-            // the id of the last run that starts at or before this lane's pair (runs ascending,
-            // unused slots repeat the last run)
             const unsigned w[4] = {rle.x, rle.y, rle.z, rle.w};
             pid = (int)((w[0] >> 8) & 0xffu);
 #pragma unroll
@@ -383,112 +386,17 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
         }
         return pid;
     };
+    auto pair_pid = [&](int chunk, int ra) -> int { return pid_of(load_rle(chunk), ra); };
     // Fixed chunks of 512 consecutive rows, one pair per lane: nothing but the chunk's table id has
     // to be looked up before the pattern ids and the gathers can be requested.
     if (SINGLE) stage_table(0);
-    // z-sweep walk (CsrView::sweep_*): the first sweep_nslots workgroups each take one segment -- a band
-    // of T rows through the planes z0 <= z < z1 -- and read every operand of the canonical stencil layout
-    // from an LDS ring of plane windows [band - NX, band + T + NX), each window fetched ONCE with
-    // coalesced 16-byte loads, two planes ahead of its use.  Same products, same order, same masks as
-    // accumulate_canon: same bits.  The next sweep_gen_blocks workgroups walk the chunks no segment
-    // covers the generic way (loop below); the rest of the grid only writes its zero partial sums.
-    constexpr bool kSweepMode = SINGLE && MODE == kSpmvCgUpdate;
-    const bool listed = kSweepMode && a.sweep != 0;
-    if (kSweepMode && listed && (int)blockIdx.x < A.sweep_nslots) {
-        double *ring = reinterpret_cast<double *>(pair_lds);  // over the staged table: only cpv / cmask are used from here on
-        const int4 sg = A.sweep_seg[blockIdx.x];
-        const int T = A.sweep_T, NX = A.sweep_nx, W = T + 2 * NX, npieces = W / 2;
-        const int64_t PL = A.sweep_pl;
-        const int band = sg.x, z0 = sg.y, z1 = sg.z;
-        constexpr int NL = 4;  // 16-byte pieces of a window per lane (W <= 2048)
-        constexpr int kSlots = 4;
-        const int nplanes = (int)(A.nrows / PL);
-        auto load_window = [&](int z, pvd2 (&reg)[NL]) {
-            const int64_t base = (int64_t)z * PL + (int64_t)band * T - NX;
-#pragma unroll
-            for (int k = 0; k < NL; ++k) {
-                const int pc = tid + k * kBlock;
-                const int64_t g = base + 2 * pc;
-                pvd2 v = {0.0, 0.0};
-                if (pc < npieces && z >= 0 && z <= nplanes && g >= 0 && g + 2 <= A.ncols) __builtin_memcpy(&v, a.x + g, 16);
-                reg[k] = v;
-            }
-        };
-        auto store_window = [&](int z, const pvd2 (&reg)[NL]) {
-            double *slot_p = ring + (size_t)((z + kSlots) % kSlots) * W;
-#pragma unroll
-            for (int k = 0; k < NL; ++k) {
-                const int pc = tid + k * kBlock;
-                if (pc < npieces) *reinterpret_cast<pvd2 *>(slot_p + 2 * pc) = reg[k];
-            }
-        };
-        if (z0 < z1) {
-            pvd2 reg[NL];
-            load_window(z0 - 1, reg);
-            store_window(z0 - 1, reg);
-            load_window(z0, reg);
-            store_window(z0, reg);
-            load_window(z0 + 1, reg);
-            for (int z = z0; z < z1; ++z) {
-                store_window(z + 1, reg);
-                lds_barrier();
-                if (z + 1 < z1) load_window(z + 2, reg);  // in flight while plane z is computed
-                const double *cur = ring + (size_t)((z + kSlots) % kSlots) * W;
-                const double *prv = ring + (size_t)((z - 1 + kSlots) % kSlots) * W;
-                const double *nxt = ring + (size_t)((z + 1 + kSlots) % kSlots) * W;
-                for (int h = 0; h < T / kPairRows; ++h) {
-                    const int64_t row0 = (int64_t)z * PL + (int64_t)band * T + h * kPairRows;
-                    const int chunk = (int)(row0 / kPairRows);
-                    const int ra = (int)row0 + 2 * tid;
-                    const int i0 = NX + h * kPairRows + 2 * tid;
-                    // r (and x) only stream through: non-temporal, requested ahead of the LDS reads
-                    const pvd2 rr = __builtin_nontemporal_load(reinterpret_cast<const pvd2 *>(a.cg_r + ra));
-                    pvd2 cgx = {0.0, 0.0};
-                    if (a.cg_x) cgx = __builtin_nontemporal_load(reinterpret_cast<const pvd2 *>(a.cg_x + ra));
-                    double od0 = 1.0, od1 = 1.0;
-                    if (a.diag_mode == 1) {
-                        const pvd2 dd = __builtin_nontemporal_load(reinterpret_cast<const pvd2 *>(a.dinv + ra));
-                        od0 = dd.x;
-                        od1 = dd.y;
-                    } else if (a.diag_mode == 3) {
-                        od0 = od1 = a.diag_uniform;
-                    }
-                    const int pid = pair_pid(chunk, ra);
-                    const int mask = cmask[pid];
-                    pvd2 t[7];
-                    t[3] = *reinterpret_cast<const pvd2 *>(cur + i0);
-                    t[2].x = cur[i0 - 1];
-                    t[2].y = t[3].x;
-                    t[4].x = t[3].y;
-                    t[4].y = cur[i0 + 2];
-                    t[1] = *reinterpret_cast<const pvd2 *>(cur + i0 - NX);
-                    t[5] = *reinterpret_cast<const pvd2 *>(cur + i0 + NX);
-                    t[0] = *reinterpret_cast<const pvd2 *>(prv + i0);
-                    t[6] = *reinterpret_cast<const pvd2 *>(nxt + i0);
-                    double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-                    for (int k = 0; k < 7; ++k) {
-                        const PairVal v = cpv[pid * 8 + k];
-                        if ((mask >> k) & 1) s0 += v.a * t[k].x;
-                        if ((mask >> (kPairChunk + k)) & 1) s1 += v.b * t[k].y;
-                    }
-                    double y0, y1, p0, p1;
-                    finish(ra, s0, 0.0, false, t[3].x, rr.x, od0, y0, p0);
-                    finish(ra + 1, s1, 0.0, false, t[3].y, rr.y, od1, y1, p1);
-                    const pvd2 rn = {y0, y1};
-                    __builtin_nontemporal_store(rn, reinterpret_cast<pvd2 *>(a.cg_r + ra));
-                    if (a.cg_x) {
-                        const pvd2 xx = {cgx.x + p0, cgx.y + p1};
-                        __builtin_nontemporal_store(xx, reinterpret_cast<pvd2 *>(a.cg_x + ra));
-                    }
-                }
-            }
-        }
-    }
-    const int gen_first = listed ? (int)blockIdx.x - A.sweep_nslots : slot;
-    const int gen_count = listed ? ((int)blockIdx.x < A.sweep_nslots + A.sweep_gen_blocks ? A.sweep_ngen : 0) : slots;
-    const int gen_stride = listed ? A.sweep_gen_blocks : per_xcd;
-    for (int j = gen_first; j >= 0 && j < gen_count; j += gen_stride) {
+    // listed walk: the chunks no z-sweep segment covers (CsrView::sweep_gen), the companion launch of
+    // spmv_pair_sweep_kernel below; its partial sums go behind that kernel's (a.part_offset)
+    const bool listed = SINGLE && (MODE == kSpmvCgUpdate || MODE == kSpmvDirDotSym) && a.sweep != 0;
+    const int gen_first = listed ? (int)blockIdx.x : slot;
+    const int gen_count = listed ? A.sweep_ngen : slots;
+    const int gen_stride = listed ? (int)gridDim.x : per_xcd;
+    for (int j = gen_first; j < gen_count; j += gen_stride) {
         const int chunk = listed ? A.sweep_gen[j] : xcd_chunk(nchunks, sh, xcd, j);
         if (chunk < 0) continue;
         const int tb = SINGLE ? 0 : A.chunk_ptable[chunk];
@@ -641,17 +549,387 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
         const double s0 = block_sum(acc0, red);
         const double s1 = block_sum(acc1, red);
         if (tid == 0) {
-            a.partials[blockIdx.x] = s0;
-            a.partials[gridDim.x + blockIdx.x] = s1;
+            const int stride = a.part_stride ? a.part_stride : (int)gridDim.x;
+            a.partials[a.part_offset + blockIdx.x] = s0;
+            a.partials[stride + a.part_offset + blockIdx.x] = s1;
         }
         if (MODE == kSpmvResidDual) {
             const double s2v = block_sum(acc2, red);
             if (tid == 0) a.partials[2 * gridDim.x + blockIdx.x] = s2v;
         }
     }
-    if (kDir && blockIdx.x == 0 && tid == 0) {
+    if (kDir && blockIdx.x == 0 && tid == 0 && !a.sweep) {  // (the z-sweep kernel does it for its companion launch)
         // what cg_direction_kernel's workgroup 0 does: the rho slot written is the one no launch of
         // this iteration reads; stop_iter = 0 makes every later launch leave at once
+        CgState *st = const_cast<CgState *>(a.cg_state);
+        st->rho[(a.it + 1) & 1] = cg_rho_new;
+        st->rr = cg_rr;
+        st->iters = st->iters + 1;
+        if (sqrt(cg_rr) <= a.cg_rtol * st->r0) st->stop_iter = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// z-sweep ("brick") walk of the q-free CG update launch for matrices in the canonical 3-D stencil layout
+// {-PL, -NX, -1, 0, +1, +NX, +PL} (CsrView::sweep_*).  tools/probes/brick_probe.hip priced the memory
+// structure first: with six 16-byte gathers per row pair the launch is bound by vector-memory
+// instructions and, on wide planes, re-fetches the +-PL lines the 4 MiB L2s cannot hold; here a
+// workgroup takes a band of T rows through the planes z0 <= z < z1, fetches each plane's window
+// [band - NX, band + T + NX) of p ONCE with coalesced 16-byte loads two planes ahead of its use, and
+// reads all seven operands of a row pair from an LDS ring of four windows.  r (and 1/diag) of the
+// lane's pairs and the chunk's pattern-id record are requested one plane ahead.  The loop body is
+// straight-line code (addresses are clamped instead of guarded, every count is a template
+// parameter), so the compiler can give each wait its own vmcnt instead of draining the queue.
+// Products, order and presence masks are those of accumulate_canon: the same bits per row.
+// NL: 16-byte pieces of a window per lane; NH: chunks of 512 rows per band; DIAGVEC: Jacobi diagonal
+// as a full vector.  x is not touched (deferred x update only).
+// ---------------------------------------------------------------------------------------------------
+template <int NHL, int NH, bool DIAGVEC>
+__global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, SpmvArgs a)
+{
+#pragma clang fp contract(off)
+    // dynamic LDS: own parts of four planes [4][T], the +-NX halos of two planes [2][2 NX] (only the plane
+    // being computed needs its halo, which is why it is requested one plane ahead, not two: its lines are
+    // the own lines of the neighbouring bands, i.e. L2 hits), the canonical tables of the matrix
+    extern __shared__ __attribute__((aligned(16))) char sweep_lds[];
+    constexpr int T = NH * kPairRows;
+    const int NX = A.sweep_nx;
+    double *const own_ring = reinterpret_cast<double *>(sweep_lds);
+    double *const halo_ring = own_ring + 4 * T;
+    PairVal *const cpv = reinterpret_cast<PairVal *>(halo_ring + 4 * NX);
+    int *const cmask = reinterpret_cast<int *>(cpv + A.canon_npat * 8);
+    __shared__ double red[4];
+    if (a.it >= a.cg_state->stop_iter) return;
+    const double cg_alpha = a.cg_state->rho[a.it & 1] / fold_partials(a.pq_partials, a.pq_nparts, red);
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid == 0 && a.alpha_out) *a.alpha_out = cg_alpha;
+    for (int i = tid; i < A.canon_npat * 8; i += kBlock) cpv[i] = PairVal{A.canon_val[2 * i], A.canon_val[2 * i + 1]};
+    if (tid < A.canon_npat) cmask[tid] = A.canon_mask[tid];
+    // partial-sum slots no workgroup of this launch or of its companion writes
+    if (blockIdx.x == 0)
+        for (int i = (int)gridDim.x + a.part_offset + tid; i < a.part_stride; i += kBlock)
+            a.partials[i] = a.partials[a.part_stride + i] = 0.0;
+    lds_barrier();
+    const int4 sg = A.sweep_seg[blockIdx.x];
+    const int64_t PL = A.sweep_pl;
+    const int band = sg.x, z0 = sg.y, z1 = sg.z;
+    const int64_t gmax = A.ncols - 2;
+    double acc0 = 0.0, acc1 = 0.0;
+    typedef const unsigned __attribute__((address_space(4))) *const_words;
+    if (z0 < z1) {
+        // Pieces beyond the vector's ends (first / last plane, first / last band) are clamped to a valid
+        // address: no row has an entry there, the masks drop what they deliver.
+        auto clampg = [&](int64_t g) -> int64_t { return g < 0 ? 0 : (g > gmax ? gmax : g); };
+        auto load_own = [&](int z, pvd2 (&reg)[NH]) {
+            const int64_t base = (int64_t)z * PL + (int64_t)band * T;
+#pragma unroll
+            for (int k = 0; k < NH; ++k) __builtin_memcpy(&reg[k], a.x + clampg(base + 2 * (tid + k * kBlock)), 16);
+        };
+        auto store_own = [&](int z, const pvd2 (&reg)[NH]) {
+            double *slot_p = own_ring + (size_t)((z + 4) & 3) * T;
+#pragma unroll
+            for (int k = 0; k < NH; ++k) *reinterpret_cast<pvd2 *>(slot_p + 2 * (tid + k * kBlock)) = reg[k];
+        };
+        // halo of plane z: the NX rows below the band (pieces 0 .. NX/2) and the NX rows above it
+        auto load_halo = [&](int z, pvd2 (&reg)[NHL]) {
+            const int64_t lo = (int64_t)z * PL + (int64_t)band * T - NX, up = lo + NX + T;
+#pragma unroll
+            for (int k = 0; k < NHL; ++k) {
+                const int pc = min(tid + k * kBlock, NX - 1);  // NX pieces: NX/2 below, NX/2 above
+                const int64_t g = pc < NX / 2 ? lo + 2 * pc : up + 2 * (pc - NX / 2);
+                __builtin_memcpy(&reg[k], a.x + clampg(g), 16);
+            }
+        };
+        auto store_halo = [&](int z, const pvd2 (&reg)[NHL]) {
+            double *slot_p = halo_ring + (size_t)(z & 1) * 2 * NX;
+#pragma unroll
+            for (int k = 0; k < NHL; ++k) {
+                const int pc = min(tid + k * kBlock, NX - 1);
+                *reinterpret_cast<pvd2 *>(slot_p + 2 * pc) = reg[k];
+            }
+        };
+        struct Ahead {
+            pvd2 r, d;
+            unsigned w0, w1, w2, w3;
+        };
+        auto fetch = [&](int z, int h) -> Ahead {
+            Ahead f;
+            const int64_t row0 = (int64_t)z * PL + (int64_t)band * T + h * kPairRows;
+            const int ra = (int)row0 + 2 * tid;
+            const const_words q = (const_words)(uintptr_t)(A.pair_rle + (row0 / kPairRows));
+            f.w0 = q[0];
+            f.w1 = q[1];
+            f.w2 = q[2];
+            f.w3 = q[3];
+            f.r = __builtin_nontemporal_load(reinterpret_cast<const pvd2 *>(a.cg_r + ra));
+            if (DIAGVEC) f.d = __builtin_nontemporal_load(reinterpret_cast<const pvd2 *>(a.dinv + ra));
+            return f;
+        };
+        // Software pipeline, two steps deep, without register copies (the loop is unrolled by two and the
+        // register sets alternate): own(z + 3) is requested while plane z is computed, into the set whose
+        // content -- own(z + 1) -- has just gone to LDS; r(z + 2) at the end of step z, into the set step z
+        // has just consumed; the halo of plane z + 1 (L2 hits) first thing in step z.
+        pvd2 own_a[NH], own_b[NH], hreg[NHL];
+        Ahead r_a[NH], r_b[NH];
+        load_own(z0 - 1, own_a);
+        store_own(z0 - 1, own_a);
+        load_own(z0, own_a);
+        store_own(z0, own_a);
+        load_halo(z0, hreg);
+        load_own(z0 + 1, own_b);
+        load_own(z0 + 2, own_a);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            r_a[h] = fetch(z0, h);
+            r_b[h] = fetch(z0 + 1 < z1 ? z0 + 1 : z0, h);
+        }
+        // one plane: `own_next` holds own(z + 1) on entry and own(z + 3) on exit, `rr` r(z) / r(z + 2)
+        auto step = [&](int z, pvd2 (&own_next)[NH], Ahead (&rr)[NH]) {
+            store_own(z + 1, own_next);
+            store_halo(z, hreg);
+            lds_barrier();
+            load_halo(z + 1, hreg);
+            load_own(z + 3, own_next);
+            const double *cur = own_ring + (size_t)((z + 4) & 3) * T;
+            const double *prv = own_ring + (size_t)((z + 3) & 3) * T;
+            const double *nxt = own_ring + (size_t)((z + 5) & 3) * T;
+            const double *hlo = halo_ring + (size_t)(z & 1) * 2 * NX, *hup = hlo + NX;
+            const int zn = z + 2 < z1 ? z + 2 : z1 - 1;  // past the segment: a valid plane, never used
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                const Ahead f = rr[h];
+                const int i0 = h * kPairRows + 2 * tid;  // position inside the band
+                const int ra = (int)((int64_t)z * PL + (int64_t)band * T) + i0;
+                // the id of the last run that starts at or before this lane's pair
+                const unsigned w[4] = {f.w0, f.w1, f.w2, f.w3};
+                int pid = (int)((w[0] >> 8) & 0xffu);
+#pragma unroll
+                for (int k = 1; k < 8; ++k) {
+                    const unsigned e = (w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+                    if ((unsigned)tid >= (e & 0xffu)) pid = (int)(e >> 8);
+                }
+                const int mask = cmask[pid];
+                pvd2 t[7];
+                t[3] = *reinterpret_cast<const pvd2 *>(cur + i0);
+                t[2].x = i0 > 0 ? cur[i0 - 1] : hlo[NX - 1];
+                t[2].y = t[3].x;
+                t[4].x = t[3].y;
+                t[4].y = i0 + 2 < T ? cur[i0 + 2] : hup[0];
+                t[1] = *reinterpret_cast<const pvd2 *>(i0 >= NX ? cur + (i0 - NX) : hlo + i0);
+                t[5] = *reinterpret_cast<const pvd2 *>(i0 + NX < T ? cur + (i0 + NX) : hup + (i0 + NX - T));
+                t[0] = *reinterpret_cast<const pvd2 *>(prv + i0);
+                t[6] = *reinterpret_cast<const pvd2 *>(nxt + i0);
+                // masked sums without branches: an absent entry adds +0.0, which leaves a sum that began
+                // at +0.0 unchanged bit for bit (such a sum is never -0.0)
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    const PairVal v = cpv[pid * 8 + k];
+                    const double p0 = v.a * t[k].x, p1 = v.b * t[k].y;
+                    s0 += ((mask >> k) & 1) ? p0 : 0.0;
+                    s1 += ((mask >> (kPairChunk + k)) & 1) ? p1 : 0.0;
+                }
+                // r -= alpha q ; z = D^-1 r ; partial r.z and r.r  (kSpmvCgUpdate's epilogue, x deferred)
+                const double r0 = f.r.x - cg_alpha * s0;
+                const double zz0 = a.diag_mode ? (DIAGVEC ? f.d.x : a.diag_uniform) * r0 : r0;
+                acc0 += r0 * zz0;
+                acc1 += r0 * r0;
+                const double r1 = f.r.y - cg_alpha * s1;
+                const double zz1 = a.diag_mode ? (DIAGVEC ? f.d.y : a.diag_uniform) * r1 : r1;
+                acc0 += r1 * zz1;
+                acc1 += r1 * r1;
+                const pvd2 rn = {r0, r1};
+                __builtin_nontemporal_store(rn, reinterpret_cast<pvd2 *>(a.cg_r + ra));
+                rr[h] = fetch(zn, h);
+            }
+        };
+        int z = z0;
+        for (; z + 1 < z1; z += 2) {
+            step(z, own_b, r_a);
+            step(z + 1, own_a, r_b);
+        }
+        if (z < z1) step(z, own_b, r_a);
+    }
+    const double s0 = block_sum(acc0, red);
+    const double s1 = block_sum(acc1, red);
+    if (tid == 0) {
+        a.partials[blockIdx.x] = s0;
+        a.partials[a.part_stride + blockIdx.x] = s1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same walk for the fused direction update + p.(A p) launch of symmetric matrices (kSpmvDirDotSym):
+// beta from the folded partials, p' = z + beta p (z = D^-1 r, uniform or no Jacobi scaling) computed ONCE
+// per element from coalesced loads of r and p -- into the LDS ring, and into the output buffer for the
+// planes of the segment -- and the upper-triangle sum p'.(A p') = sum_i p'_i (a_ii p'_i + 2 sum_{j>i}
+// a_ij p'_j) read from LDS: own and +1 from the band's plane, +NX from it or its upper halo, +PL from the
+// next plane.  The chunk-by-chunk form of this launch gathers r AND p at every entry; here every
+// element of r and p is loaded once (plus the NX-row halo, L2 hits).  Same expression for p' everywhere,
+// same products in the same order: the same bits per row.  Workgroup 0 advances CgState like
+// cg_direction_kernel.  NHL / NH as above.
+// ---------------------------------------------------------------------------------------------------
+template <int NHL, int NH>
+__global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView A, SpmvArgs a)
+{
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) char sweep_lds[];
+    constexpr int T = NH * kPairRows;
+    const int NX = A.sweep_nx;
+    double *const own_ring = reinterpret_cast<double *>(sweep_lds);  // p' of three planes [3][T]
+    double *const halo_ring = own_ring + 3 * T;                       // p' of the NX rows above the band [2][NX]
+    PairVal *const cpv = reinterpret_cast<PairVal *>(halo_ring + 2 * NX);
+    int *const cmask = reinterpret_cast<int *>(cpv + A.canon_npat * 4);
+    __shared__ double red[4];
+    if (a.it >= a.cg_state->stop_iter) return;
+    const double cg_rho_new = fold_partials(a.pq_partials, a.pq_nparts, red);
+    const double cg_rr = fold_partials(a.pq_partials + a.pq_nparts, a.pq_nparts, red);
+    const double cg_beta = cg_rho_new / a.cg_state->rho[a.it & 1];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < A.canon_npat * 4; i += kBlock) cpv[i] = PairVal{A.canon_sym_val[2 * i], A.canon_sym_val[2 * i + 1]};
+    if (tid < A.canon_npat) cmask[tid] = A.canon_sym_mask[tid];
+    if (blockIdx.x == 0)
+        for (int i = (int)gridDim.x + a.part_offset + tid; i < a.part_stride; i += kBlock)
+            a.partials[i] = a.partials[a.part_stride + i] = 0.0;
+    lds_barrier();
+    const int4 sg = A.sweep_seg[blockIdx.x];
+    const int64_t PL = A.sweep_pl;
+    const int band = sg.x, z0 = sg.y, z1 = sg.z;
+    const int64_t gmax = A.ncols - 2;
+    const pvd2 du = {a.diag_uniform, a.diag_uniform};
+    double acc0 = 0.0;
+    typedef const unsigned __attribute__((address_space(4))) *const_words;
+    if (z0 < z1) {
+        auto clampg = [&](int64_t g) -> int64_t { return g < 0 ? 0 : (g > gmax ? gmax : g); };
+        // p' at one 16-byte piece: the expression of dir2 / cg_direction_kernel
+        auto newp = [&](pvd2 rv, pvd2 pv) -> pvd2 {
+            const pvd2 zv = a.diag_mode ? du * rv : rv;
+            pvd2 o;
+            o.x = __builtin_fma(cg_beta, pv.x, zv.x);
+            o.y = __builtin_fma(cg_beta, pv.y, zv.y);
+            return o;
+        };
+        struct Own {
+            pvd2 r[NH], p[NH];
+        };
+        struct Halo {
+            pvd2 r[NHL], p[NHL];
+        };
+        auto load_own = [&](int z, Own &o) {
+            const int64_t base = (int64_t)z * PL + (int64_t)band * T;
+#pragma unroll
+            for (int k = 0; k < NH; ++k) {
+                const int64_t g = clampg(base + 2 * (tid + k * kBlock));
+                o.r[k] = __builtin_nontemporal_load(reinterpret_cast<const pvd2 *>(a.cg_r + g));
+                __builtin_memcpy(&o.p[k], a.x + g, 16);
+            }
+        };
+        // p'(z) of the band: to the ring, and to the output vector where the plane belongs to the segment
+        auto store_own = [&](int z, const Own &o, bool out) {
+            double *slot_p = own_ring + (size_t)((z + 3) % 3) * T;
+            const int64_t base = (int64_t)z * PL + (int64_t)band * T;
+#pragma unroll
+            for (int k = 0; k < NH; ++k) {
+                const pvd2 v = newp(o.r[k], o.p[k]);
+                *reinterpret_cast<pvd2 *>(slot_p + 2 * (tid + k * kBlock)) = v;
+                if (out) __builtin_memcpy(a.y + base + 2 * (tid + k * kBlock), &v, 16);
+            }
+        };
+        auto load_halo = [&](int z, Halo &hh) {
+            const int64_t up = (int64_t)z * PL + (int64_t)band * T + T;
+#pragma unroll
+            for (int k = 0; k < NHL; ++k) {
+                const int pc = min(tid + k * kBlock, NX / 2 - 1);
+                const int64_t g = clampg(up + 2 * pc);
+                __builtin_memcpy(&hh.r[k], a.cg_r + g, 16);
+                __builtin_memcpy(&hh.p[k], a.x + g, 16);
+            }
+        };
+        auto store_halo = [&](int z, const Halo &hh) {
+            double *slot_p = halo_ring + (size_t)(z & 1) * NX;
+#pragma unroll
+            for (int k = 0; k < NHL; ++k) {
+                const int pc = min(tid + k * kBlock, NX / 2 - 1);
+                *reinterpret_cast<pvd2 *>(slot_p + 2 * pc) = newp(hh.r[k], hh.p[k]);
+            }
+        };
+        struct Rle {
+            unsigned w0, w1, w2, w3;
+        };
+        auto fetch_rle = [&](int z, int h) -> Rle {
+            const int64_t row0 = (int64_t)z * PL + (int64_t)band * T + h * kPairRows;
+            const const_words q = (const_words)(uintptr_t)(A.pair_rle + (row0 / kPairRows));
+            return Rle{q[0], q[1], q[2], q[3]};
+        };
+        Own own_a, own_b;
+        Halo hreg;
+        Rle rle_a[NH], rle_b[NH];
+        load_own(z0, own_a);
+        store_own(z0, own_a, true);
+        load_halo(z0, hreg);
+        load_own(z0 + 1, own_b);
+        load_own(z0 + 2, own_a);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            rle_a[h] = fetch_rle(z0, h);
+            rle_b[h] = fetch_rle(z0 + 1 < z1 ? z0 + 1 : z0, h);
+        }
+        // one plane: `own_next` holds r, p of plane z + 1 on entry and of plane z + 3 on exit
+        auto step = [&](int z, Own &own_next, Rle (&rl)[NH]) {
+            store_own(z + 1, own_next, z + 1 < z1);
+            store_halo(z, hreg);
+            lds_barrier();
+            load_halo(z + 1, hreg);
+            load_own(z + 3, own_next);
+            const double *cur = own_ring + (size_t)((z + 3) % 3) * T;
+            const double *nxt = own_ring + (size_t)((z + 4) % 3) * T;
+            const double *hup = halo_ring + (size_t)(z & 1) * NX;
+            const int zn = z + 2 < z1 ? z + 2 : z1 - 1;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                const Rle f = rl[h];
+                const int i0 = h * kPairRows + 2 * tid;
+                const unsigned w[4] = {f.w0, f.w1, f.w2, f.w3};
+                int pid = (int)((w[0] >> 8) & 0xffu);
+#pragma unroll
+                for (int k = 1; k < 8; ++k) {
+                    const unsigned e = (w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+                    if ((unsigned)tid >= (e & 0xffu)) pid = (int)(e >> 8);
+                }
+                const int mask = cmask[pid];
+                pvd2 t[4];
+                t[0] = *reinterpret_cast<const pvd2 *>(cur + i0);
+                t[1].x = t[0].y;
+                t[1].y = i0 + 2 < T ? cur[i0 + 2] : hup[0];
+                t[2] = *reinterpret_cast<const pvd2 *>(i0 + NX < T ? cur + (i0 + NX) : hup + (i0 + NX - T));
+                t[3] = *reinterpret_cast<const pvd2 *>(nxt + i0);
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const PairVal v = cpv[pid * 4 + k];
+                    const double p0 = v.a * t[k].x, p1 = v.b * t[k].y;
+                    s0 += ((mask >> k) & 1) ? p0 : 0.0;
+                    s1 += ((mask >> (kPairChunk + k)) & 1) ? p1 : 0.0;
+                }
+                acc0 += t[0].x * s0;
+                acc0 += t[0].y * s1;
+                rl[h] = fetch_rle(zn, h);
+            }
+        };
+        int z = z0;
+        for (; z + 1 < z1; z += 2) {
+            step(z, own_b, rle_a);
+            step(z + 1, own_a, rle_b);
+        }
+        if (z < z1) step(z, own_b, rle_a);
+    }
+    const double s0 = block_sum(acc0, red);
+    if (tid == 0) {
+        a.partials[blockIdx.x] = s0;
+        a.partials[a.part_stride + blockIdx.x] = 0.0;
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        // what cg_direction_kernel's workgroup 0 does (see the chunk-by-chunk kernel's epilogue)
         CgState *st = const_cast<CgState *>(a.cg_state);
         st->rho[(a.it + 1) & 1] = cg_rho_new;
         st->rr = cg_rr;
@@ -663,20 +941,90 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
 int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s)
 {
     const bool wide = A.ncols >= (int64_t(1) << 28);  // byte offsets of x beyond 32 bits
-    if (mode == kSpmvCgUpdate && !wide && A.pair_single && A.sweep_nslots > 0 &&
+    if (mode == kSpmvCgUpdate && !wide && A.pair_single && A.sweep_nslots > 0 && !a.cg_x && a.diag_mode != 2 &&
         A.sweep_nslots + A.sweep_gen_blocks <= grid) {
-        // z-sweep walk: the LDS ring of plane windows is dynamic shared memory (only this launch form pays for it)
         const char *sweep_env = std::getenv("SCHWZ_CG_SWEEP");  // read per launch: tests switch it
         if (!(sweep_env && sweep_env[0] == '0')) {
-            static const hipError_t attr = hipFuncSetAttribute((const void *)spmv_pair_kernel<kSpmvCgUpdate, false, true>,
-                                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);
-            (void)attr;
+            // z-sweep walk + (where boundary planes or overlap rows exist) the listed walk of the chunks it
+            // leaves out; the consumer folds `grid` partial sums per bank, as after a chunk-by-chunk launch
+            const int nhl = (A.sweep_nx + kBlock - 1) / kBlock, nh = A.sweep_T / kPairRows;  // halo / own pieces per lane
+            const size_t lds = (size_t)(4 * A.sweep_T + 4 * A.sweep_nx) * sizeof(double) + (size_t)A.canon_npat * (8 * 16 + 4);
             SpmvArgs b = a;
-            b.sweep = 1;
-            const size_t lds = std::max<size_t>(kPairTableLds, (size_t)4 * (A.sweep_T + 2 * A.sweep_nx) * sizeof(double));
-            hipLaunchKernelGGL((spmv_pair_kernel<kSpmvCgUpdate, false, true>), dim3(grid), dim3(kBlock), lds, s, A, b);
-            SCHWZ_HIP_TRY(hipGetLastError());
-            return SCHWZ_OK;
+            b.part_stride = grid;
+            b.part_offset = A.sweep_gen_blocks;  // slots of the companion launch follow this one's
+            const bool dv = a.diag_mode == 1;
+#define SCHWZ_SWEEP_LAUNCH(L_, H_)                                                                                        \
+    {                                                                                                                    \
+        static const hipError_t e0 = hipFuncSetAttribute((const void *)spmv_pair_sweep_kernel<L_, H_, false>,            \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);          \
+        static const hipError_t e1 = hipFuncSetAttribute((const void *)spmv_pair_sweep_kernel<L_, H_, true>,             \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);          \
+        (void)e0;                                                                                                        \
+        (void)e1;                                                                                                        \
+        if (dv)                                                                                                          \
+            hipLaunchKernelGGL((spmv_pair_sweep_kernel<L_, H_, true>), dim3(A.sweep_nslots), dim3(kBlock), lds, s, A, b); \
+        else                                                                                                             \
+            hipLaunchKernelGGL((spmv_pair_sweep_kernel<L_, H_, false>), dim3(A.sweep_nslots), dim3(kBlock), lds, s, A, b); \
+    }
+            bool launched = true;
+            if (nh == 1 && nhl == 1) SCHWZ_SWEEP_LAUNCH(1, 1)
+            else if (nh == 1 && nhl == 2) SCHWZ_SWEEP_LAUNCH(2, 1)
+            else if (nh == 2 && nhl == 1) SCHWZ_SWEEP_LAUNCH(1, 2)
+            else if (nh == 2 && nhl == 2) SCHWZ_SWEEP_LAUNCH(2, 2)
+            else if (nh == 1 && nhl <= 4) SCHWZ_SWEEP_LAUNCH(4, 1)
+            else if (nh == 2 && nhl <= 4) SCHWZ_SWEEP_LAUNCH(4, 2)
+            else launched = false;
+#undef SCHWZ_SWEEP_LAUNCH
+            if (launched) {
+                SCHWZ_HIP_TRY(hipGetLastError());
+                if (A.sweep_gen_blocks > 0) {
+                    SpmvArgs c = a;
+                    c.sweep = 1;
+                    c.part_stride = grid;
+                    c.part_offset = A.sweep_nslots;
+                    hipLaunchKernelGGL((spmv_pair_kernel<kSpmvCgUpdate, false, true>), dim3(A.sweep_gen_blocks), dim3(kBlock),
+                                       kPairTableLds, s, A, c);
+                    SCHWZ_HIP_TRY(hipGetLastError());
+                }
+                return SCHWZ_OK;
+            }
+        }
+    }
+    if (mode == kSpmvDirDotSym && !wide && A.pair_single && A.sweep_nslots > 0 && A.canon_sym_val && a.diag_mode != 1 &&
+        a.diag_mode != 2 && A.sweep_nslots + A.sweep_gen_blocks <= grid) {
+        const char *sweep_env = std::getenv("SCHWZ_CG_SWEEP");
+        if (!(sweep_env && sweep_env[0] == '0')) {
+            const int nhl = (A.sweep_nx / 2 + kBlock - 1) / kBlock, nh = A.sweep_T / kPairRows;
+            const size_t lds = (size_t)(3 * A.sweep_T + 2 * A.sweep_nx) * sizeof(double) + (size_t)A.canon_npat * (4 * 16 + 4);
+            if (nhl <= 2) {
+                // the companion first: the z-sweep kernel's workgroup 0 advances CgState for both
+                if (A.sweep_gen_blocks > 0) {
+                    SpmvArgs c = a;
+                    c.sweep = 1;
+                    c.part_stride = grid;
+                    c.part_offset = A.sweep_nslots;
+                    hipLaunchKernelGGL((spmv_pair_kernel<kSpmvDirDotSym, false, true>), dim3(A.sweep_gen_blocks), dim3(kBlock),
+                                       kPairTableLds, s, A, c);
+                    SCHWZ_HIP_TRY(hipGetLastError());
+                }
+                SpmvArgs b = a;
+                b.part_stride = grid;
+                b.part_offset = A.sweep_gen_blocks;
+#define SCHWZ_DIRDOT_LAUNCH(L_, H_)                                                                                      \
+    {                                                                                                                    \
+        static const hipError_t e0 = hipFuncSetAttribute((const void *)spmv_pair_dirdot_sweep_kernel<L_, H_>,            \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);          \
+        (void)e0;                                                                                                        \
+        hipLaunchKernelGGL((spmv_pair_dirdot_sweep_kernel<L_, H_>), dim3(A.sweep_nslots), dim3(kBlock), lds, s, A, b);    \
+    }
+                if (nh == 1 && nhl == 1) SCHWZ_DIRDOT_LAUNCH(1, 1)
+                else if (nh == 1) SCHWZ_DIRDOT_LAUNCH(2, 1)
+                else if (nhl == 1) SCHWZ_DIRDOT_LAUNCH(1, 2)
+                else SCHWZ_DIRDOT_LAUNCH(2, 2)
+#undef SCHWZ_DIRDOT_LAUNCH
+                SCHWZ_HIP_TRY(hipGetLastError());
+                return SCHWZ_OK;
+            }
         }
     }
 #define SCHWZ_PAIR_LAUNCH(M)                                                                          \
@@ -1047,24 +1395,37 @@ int build_spmv_pair(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, con
         const int64_t NX = cn[5], PL = cn[6];
         const bool shape_ok = single && cn[7] && cn[0] == -PL && cn[1] == -NX && NX >= 2 && PL > NX && NX % 2 == 0 &&
                               PL % kPairRows == 0;
-        if (sw_mode != 0 && shape_ok && (nrows >= (int64_t(1) << 20) || sw_mode == 2) && nrows >= 3 * PL) {
+        if (sw_mode != 0 && shape_ok && (nrows >= (int64_t(1) << 20) || sw_mode == 2) && nrows >= 3 * PL && nrows % 2 == 0 &&
+            A->v.ncols == nrows) {
             const PairTable &tb = tables[0];
             // a pattern fits the layout when each of its entries has one of the seven offsets (the device
             // stages cmask the same way, stage_table)
             std::vector<uint8_t> pat_ok((size_t)tb.npat, 1);
+            std::vector<double> cval((size_t)tb.npat * 16, 0.0);
+            std::vector<int> cmsk((size_t)tb.npat, 0);
             for (int q = 0; q < tb.npat; ++q) {
                 if ((int)tb.len[(size_t)q] > kPairChunk) pat_ok[(size_t)q] = 0;
                 for (int k = 0; k < (int)tb.len[(size_t)q]; ++k) {
-                    const schwz_idx off = tb.ent[(size_t)q * tb.lmax + k].off;
-                    bool in = false;
-                    for (int t = 0; t < 7; ++t) in = in || cn[t] == off;
-                    if (!in) pat_ok[(size_t)q] = 0;
+                    const PairEntryH &e = tb.ent[(size_t)q * tb.lmax + k];
+                    int slot = -1;  // the first layout slot with the entry's offset
+                    for (int t = 6; t >= 0; --t)
+                        if (cn[t] == e.off) slot = t;
+                    if (slot < 0) {
+                        pat_ok[(size_t)q] = 0;
+                        continue;
+                    }
+                    std::memcpy(&cval[((size_t)q * 8 + slot) * 2], &e.va, 8);
+                    std::memcpy(&cval[((size_t)q * 8 + slot) * 2 + 1], &e.vb, 8);
+                    cmsk[(size_t)q] |= (e.flags & 1) << slot;
+                    cmsk[(size_t)q] |= ((e.flags >> 1) & 1) << (kPairChunk + slot);
                 }
+                if (!pat_ok[(size_t)q]) cmsk[(size_t)q] = -1;
             }
             std::vector<uint8_t> chunk_ok((size_t)nchunks, 0);
             for (int c = 0; c < nchunks; ++c) {
                 const int64_t p0 = (int64_t)c * (kPairRows / 2), p1 = p0 + kPairRows / 2;
                 if (p1 * 2 > nrows) continue;  // a partial chunk stays generic
+                if (rle.empty() || rle[(size_t)c * 8] == 0xffffu) continue;  // ids must run-length code (scalar loads only)
                 bool ok = true;
                 for (int64_t q = p0; q < p1 && ok; ++q) ok = pat_ok[(size_t)pair_id[(size_t)q]] != 0;
                 chunk_ok[(size_t)c] = ok ? 1 : 0;
@@ -1076,7 +1437,7 @@ int build_spmv_pair(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, con
             const int64_t W = T + 2 * NX;
             const int nplanes = (int)(nrows / PL), bands = (int)(PL / T), cpb = T / kPairRows, cpp = (int)(PL / kPairRows);
             const int grid = ((std::min<int64_t>((int64_t)tiles.size() - 1, kMaxGrid) + kXcds - 1) / kXcds) * kXcds;
-            if (W <= 2048 && bands >= 1 && nplanes >= 3) {
+            if (NX <= 1024 && W > 0 && bands >= 1 && nplanes >= 3) {
                 // maximal runs of planes in which every chunk of the band is canonical
                 struct Run { int band, z0, z1; };
                 std::vector<Run> runs;
@@ -1103,7 +1464,17 @@ int build_spmv_pair(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, con
                     }
                 }
                 std::vector<uint8_t> covered((size_t)nchunks, 0);
-                int L = l_env ? std::atoi(l_env) : 16;
+                // segment length: about three segments per CU in ONE round of workgroups (measured on MI355X,
+                // 256^3 and 512 x 512 x 64: 2 and 5 per CU are both slower; tools/sweep_ab.sh)
+                int cus = 256;
+                {
+                    int dev = 0;
+                    hipDeviceProp_t prop;
+                    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+                        prop.multiProcessorCount > 0)
+                        cus = prop.multiProcessorCount;
+                }
+                int L = l_env ? std::atoi(l_env) : (int)std::max<int64_t>(8, (steps + 3 * cus - 1) / (3 * cus));
                 if (L < 2) L = 16;
                 // the segments and the workgroups of the generic walk must fit the launch grid
                 auto count = [&](int len) {
@@ -1158,7 +1529,40 @@ int build_spmv_pair(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, con
                         slots_v[q * kXcds + x] = v;
                     }
                 if (!segs.empty() && (int64_t)slots_v.size() + gen_blocks <= grid && steps * T * 2 >= nrows) {
-                    if ((rc = upv(slots_v, &A->d_sweep_seg)) || (rc = upv(gen, &A->d_sweep_gen))) return rc;
+                    if ((rc = upv(slots_v, &A->d_sweep_seg)) || (rc = upv(gen, &A->d_sweep_gen)) ||
+                        (rc = upv(cval, &A->d_canon_val)) || (rc = upv(cmsk, &A->d_canon_mask)))
+                        return rc;
+                    A->v.canon_val = (const double *)A->d_canon_val;
+                    A->v.canon_mask = (const int *)A->d_canon_mask;
+                    A->v.canon_npat = tb.npat;
+                    if (sym_base > 0) {
+                        // the upper-triangle twin of the table in the slots {0, +1, +NX, +PL}
+                        const PairTable &ts = tables[(size_t)sym_base];
+                        const schwz_idx lay[4] = {0, 1, (schwz_idx)NX, (schwz_idx)PL};
+                        std::vector<double> sval((size_t)ts.npat * 8, 0.0);
+                        std::vector<int> smsk((size_t)ts.npat, 0);
+                        bool sym_ok = ts.npat == tb.npat;
+                        for (int q = 0; q < ts.npat && sym_ok; ++q)
+                            for (int k = 0; k < (int)ts.len[(size_t)q]; ++k) {
+                                const PairEntryH &e = ts.ent[(size_t)q * ts.lmax + k];
+                                int slot = -1;
+                                for (int t = 3; t >= 0; --t)
+                                    if (lay[t] == e.off) slot = t;
+                                if (slot < 0) {
+                                    if (pat_ok[(size_t)q]) sym_ok = false;  // cannot happen for a pattern inside the layout
+                                    continue;
+                                }
+                                std::memcpy(&sval[((size_t)q * 4 + slot) * 2], &e.va, 8);
+                                std::memcpy(&sval[((size_t)q * 4 + slot) * 2 + 1], &e.vb, 8);
+                                smsk[(size_t)q] |= (e.flags & 1) << slot;
+                                smsk[(size_t)q] |= ((e.flags >> 1) & 1) << (kPairChunk + slot);
+                            }
+                        if (sym_ok) {
+                            if ((rc = upv(sval, &A->d_canon_sym_val)) || (rc = upv(smsk, &A->d_canon_sym_mask))) return rc;
+                            A->v.canon_sym_val = (const double *)A->d_canon_sym_val;
+                            A->v.canon_sym_mask = (const int *)A->d_canon_sym_mask;
+                        }
+                    }
                     A->v.sweep_T = T;
                     A->v.sweep_nx = (int)NX;
                     A->v.sweep_pl = PL;
@@ -1220,7 +1624,12 @@ void free_spmv_pair(schwz_csr *A)
 {
     (void)hipFree(A->d_sweep_seg);
     (void)hipFree(A->d_sweep_gen);
-    A->d_sweep_seg = A->d_sweep_gen = nullptr;
+    (void)hipFree(A->d_canon_val);
+    (void)hipFree(A->d_canon_mask);
+    (void)hipFree(A->d_canon_sym_val);
+    (void)hipFree(A->d_canon_sym_mask);
+    A->d_sweep_seg = A->d_sweep_gen = A->d_canon_val = A->d_canon_mask = A->d_canon_sym_val = A->d_canon_sym_mask = nullptr;
+    A->v.canon_sym_val = nullptr;
     A->v.sweep_nslots = 0;
     (void)hipFree(A->d_pair_rle);
     A->d_pair_rle = nullptr;

@@ -337,6 +337,8 @@ int schwz_ras_local_csr(schwz_subdomain *sd, schwz_csr **out)
 // 0 none, 1 full 1/diag vector, 2 one-byte codes into a dictionary, 3 one scalar (schwz::DiagView)
 int schwz_ras_jacobi_form(const schwz_subdomain *sd) { return sd && sd->cg ? sd->cg->diag.mode : 0; }
 
+int schwz_ras_cg_flavour(const schwz_subdomain *sd) { return sd && sd->cg ? schwz_pcg_flavour(sd->cg) : 0; }
+
 int schwz_ras_get_interior(schwz_subdomain *sd, double *h_out, schwz_stream stream)
 {
     REQUIRE_DEVICE(sd, "schwz_ras_get_interior");

@@ -29,7 +29,7 @@ SYMBOLS = [
     "schwz_last_error", "schwz_version", "schwz_device_count", "schwz_set_device",
     "schwz_gather", "schwz_scatter",
     "schwz_csr_create", "schwz_csr_destroy", "schwz_csr_nnz", "schwz_csr_format", "schwz_csr_symmetric", "schwz_csr_matrix_bytes", "schwz_csr_sweep_slots", "schwz_csr_spmv",
-    "schwz_pcg_create", "schwz_pcg_create_ex", "schwz_pcg_destroy", "schwz_pcg_solve",
+    "schwz_pcg_create", "schwz_pcg_create_ex", "schwz_pcg_destroy", "schwz_pcg_flavour", "schwz_pcg_solve",
     "schwz_gmres_create", "schwz_gmres_destroy", "schwz_gmres_solve", "schwz_gmres_last_stats",
     "schwz_profile_begin", "schwz_profile_end", "schwz_profile_kind", "schwz_stream_probe",
     "schwz_trs_create", "schwz_trs_destroy", "schwz_trs_solve",
@@ -49,7 +49,7 @@ SYMBOLS = [
     "schwz_ras_local_residual_wait", "schwz_ras_local_solve", "schwz_ras_set_local_max_iters",
     "schwz_ras_last_inner_stats",
     "schwz_ras_check_and_solve_launch",
-    "schwz_ras_restrict", "schwz_ras_vector", "schwz_ras_local_csr", "schwz_ras_jacobi_form", "schwz_ras_get_interior",
+    "schwz_ras_restrict", "schwz_ras_vector", "schwz_ras_local_csr", "schwz_ras_jacobi_form", "schwz_ras_cg_flavour", "schwz_ras_get_interior",
     "schwz_ras_true_residual_sq", "schwz_ras_algorithmic_bytes",
 ]
 
@@ -114,6 +114,7 @@ _sig("schwz_csr_spmv", i32, [vp, dbl, vp, dbl, vp, i32, vp])
 _sig("schwz_pcg_create", i32, [vp, i32, pvp])
 _sig("schwz_pcg_create_ex", i32, [vp, i32, i32, pvp])
 _sig("schwz_pcg_destroy", None, [vp])
+_sig("schwz_pcg_flavour", i32, [vp])
 _sig("schwz_gmres_create", i32, [vp, i32, i32, i32, pvp])
 _sig("schwz_gmres_destroy", None, [vp])
 _sig("schwz_gmres_last_stats", i32, [vp, C.POINTER(C.c_int), C.POINTER(dbl)])
@@ -170,6 +171,7 @@ _sig("schwz_ras_restrict", i32, [vp, vp])
 _sig("schwz_ras_vector", i32, [vp, i32, pvp, C.POINTER(i64)])
 _sig("schwz_ras_local_csr", i32, [vp, pvp])
 _sig("schwz_ras_jacobi_form", i32, [vp])
+_sig("schwz_ras_cg_flavour", i32, [vp])
 _sig("schwz_ras_get_interior", i32, [vp, vp, vp])
 _sig("schwz_ras_true_residual_sq", i32, [vp, C.POINTER(dbl), vp])
 _sig("schwz_ras_algorithmic_bytes", i64, [vp, i32])

@@ -91,6 +91,10 @@ class Pcg:
                                   C.byref(rn) if want_stats else None, _stream_arg(stream)))
         return it.value, rn.value
 
+    def flavour(self):
+        """How the last solve iterated (schwz_pcg_flavour)."""
+        return int(lib.schwz_pcg_flavour(self.h))
+
     def close(self):
         if getattr(self, "h", None) and lib is not None:
             lib.schwz_pcg_destroy(self.h)

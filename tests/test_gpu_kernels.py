@@ -656,20 +656,23 @@ def _slab_local_matrix(schwz, shape, P, me):
     return sd.local_matrix()
 
 
-@pytest.mark.parametrize("case", [("cube", (32, 16, 20), "512"), ("cube", (64, 32, 12), "512"), ("cube", (64, 32, 12), "1024"),
-                                  ("cube", (16, 32, 9), "512"), ("slab", (32, 32, 30), "512"), ("slab", (32, 32, 30), "1024"),
-                                  ("end", (32, 16, 24), "512")])
+@pytest.mark.parametrize("case", [("cube", (256, 4, 12), "512"), ("cube", (256, 4, 10), "1024"), ("cube", (512, 4, 8), "512"),
+                                  ("cube", (512, 4, 8), "1024"), ("cube", (256, 8, 7), "512"), ("slab", (256, 4, 30), "512"),
+                                  ("slab", (256, 4, 30), "1024"), ("end", (256, 4, 24), "512")])
 def test_z_sweep_update_launch_matches_the_gather_walk(schwz, oracle, torch_cuda, monkeypatch, case):
     """The z-sweep walk of the q-free update launch (a band of rows swept through consecutive planes,
     every operand of the canonical stencil layout read from an LDS ring of plane windows) against the
     chunk-by-chunk gather walk of the same launch: forced on small matrices (SCHWZ_SPMV_SWEEP=2), cubes
     with one / two / four bands and 512- or 1024-row bands, the local matrices of a middle and an end
     slab (appended overlap planes, boundary planes walked the generic way in the same launch), with
-    the in-launch and the deferred x update.  Every row sees the same products in the same order, so
-    one CG iteration is bit identical; later ones differ only through the order in which the
-    per-workgroup partial sums of r.z are folded."""
+    the deferred x update the walk is built for (with the in-launch update the launch falls back to
+    the gather walk: also run).  x lines of 256 and 512 entries: a chunk's pattern ids must run-length
+    code for the walk.  Every row sees the same products in the same order, so one CG iteration is bit
+    identical; later ones differ only through the order in which the per-workgroup partial sums of
+    r.z are folded."""
     torch = torch_cuda
     kind, shape, T = case
+    monkeypatch.setenv("SCHWZ_SPMV_PATTERN", "2")
     monkeypatch.setenv("SCHWZ_SPMV_PAIR", "2")
     monkeypatch.setenv("SCHWZ_SPMV_SWEEP", "2")
     monkeypatch.setenv("SCHWZ_SWEEP_T", T)
@@ -695,7 +698,10 @@ def test_z_sweep_update_launch_matches_the_gather_walk(schwz, oracle, torch_cuda
 
     for defer in ("0", "2"):
         it0, rn0, x_ref = solve("0", defer, 1)
+        assert cg.flavour() & 24 == 0
         it1, rn1, x_sw = solve("1", defer, 1)
+        # 16: the fused direction + p.(A p) launch walked in z-sweeps, 8: the update launch (deferred x only)
+        assert cg.flavour() & 24 == (24 if defer == "2" else 16), cg.flavour()
         assert it0 == it1 == 1
         assert np.array_equal(x_ref, x_sw)
         assert abs(rn0 - rn1) <= 1e-14 * rn0

@@ -166,6 +166,75 @@ __global__ __launch_bounds__(256) void sweep_kernel(const double *__restrict__ p
 
 // one launch at a time behind a 600 MB memset: p and r are not in the Infinity Cache when the launch
 // starts, as in the CG loop, where four more vectors move between two launches of the same kind
+// ---- z-sweep with a REGISTER queue ---------------------------------------------------------------
+// a lane keeps its row pair's p of the planes z-1 .. z+PF in registers (the +-plane operands are its
+// own earlier / later loads), takes the +-1 operands from the neighbouring lanes (wave shuffles, two
+// one-lane loads per wave at the wave's ends) and gathers only the +-nx operands: no LDS, no barrier.
+// PF = planes of own loads kept in flight ahead of the plane being computed.
+template <int MODE, int PF>
+__global__ __launch_bounds__(256) void queue_kernel(const double *__restrict__ p, double *__restrict__ r, long n, int nx,
+                                                    long plane, int nz, int L, double alpha,
+                                                    double *__restrict__ part)
+{
+    __shared__ double red[4];
+    const int bands = (int)(plane / 512);
+    const int nseg = (nz + L - 1) / L;
+    const int xcd = blockIdx.x % 8, q = blockIdx.x / 8;
+    const int bpx = bands / 8;
+    const int band = xcd * bpx + q % bpx, seg = q / bpx;
+    double acc = 0.0;
+    if (seg < nseg) {
+        const int z0 = seg * L, z1 = min(nz, z0 + L);
+        const int tid = threadIdx.x, lane = tid & 63;
+        const long col0 = (long)band * 512 + 2 * tid;  // position inside the plane
+        auto own_at = [&](int z) -> vd2 {
+            vd2 v = {0.0, 0.0};
+            if (z >= 0 && z < nz) v = ld2(p, (long)z * plane + col0);
+            return v;
+        };
+        constexpr int Q = PF + 2;  // z-1, z, z+1 .. z+PF
+        vd2 qv[Q];
+#pragma unroll
+        for (int k = 0; k < Q; ++k) qv[k] = own_at(z0 - 1 + k);
+        for (int z = z0; z < z1; ++z) {
+            const long ra = (long)z * plane + col0;
+            const vd2 bk = qv[0], own = qv[1], fw = qv[2];
+            // the newest plane of the queue, requested first
+            const vd2 newest = own_at(z + PF + 1);
+            vd2 up = {0.0, 0.0}, dn = {0.0, 0.0};
+            if (ra + nx + 2 <= n) up = ld2(p, ra + nx);
+            double right = __shfl_down(own.x, 1, 64);
+            if (lane == 63 && ra + 3 <= n) right = p[ra + 2];
+            if (MODE == 0) {
+                vd2 a;
+                a.x = own.y;
+                a.y = right;
+                const vd2 s = 6.0 * own - 2.0 * (a + up + fw);
+                acc += own.x * s.x + own.y * s.y;
+            } else {
+                if (ra - nx >= 0) dn = ld2(p, ra - nx);
+                double left = __shfl_up(own.y, 1, 64);
+                if (lane == 0 && ra >= 1) left = p[ra - 1];
+                const vd2 rr = __builtin_nontemporal_load(reinterpret_cast<const vd2 *>(r + ra));
+                vd2 t2, t4;
+                t2.x = left;
+                t2.y = own.x;
+                t4.x = own.y;
+                t4.y = right;
+                const vd2 s = 6.0 * own - (bk + dn + t2 + t4 + up + fw);
+                const vd2 rn = rr - alpha * s;
+                __builtin_nontemporal_store(rn, reinterpret_cast<vd2 *>(r + ra));
+                acc += rn.x * rn.x + rn.y * rn.y;
+            }
+#pragma unroll
+            for (int k = 0; k + 1 < Q; ++k) qv[k] = qv[k + 1];
+            qv[Q - 1] = newest;
+        }
+    }
+    const double s = block_sum(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
 template <typename F>
 static float cold_time(F launch, void *junk, int reps)
 {
@@ -243,6 +312,28 @@ int main(int argc, char **argv)
             const float ms = timeit(launch, 30), cold = cold_time(launch, junk, 10);
             printf("mode %d gathers                 grid %5d          : %.4f / %.4f ms (%.2f TB/s cold on %d n bytes)  sum %.6e\n", mode, grid,
                    ms, cold, bytes / cold / 1e9, mode == 0 ? 8 : 24, total(grid));
+        }
+        for (int pf : {1, 2, 3}) {
+            if (plane % 512 || (plane / 512) % 8) continue;
+            for (int L : {8, 16, 32, 64}) {
+                if (L > nz) continue;
+                const int bands = (int)(plane / 512), nseg = (nz + L - 1) / L;
+                const int grid = bands * nseg;
+                if (grid > 65536) continue;
+                auto launch = [&] {
+#define QL(M, P) hipLaunchKernelGGL((queue_kernel<M, P>), dim3(grid), dim3(256), 0, 0, p, r, n, nx, plane, nz, L, 1e-9, part)
+                    if (mode == 0 && pf == 1) QL(0, 1);
+                    if (mode == 0 && pf == 2) QL(0, 2);
+                    if (mode == 0 && pf == 3) QL(0, 3);
+                    if (mode == 1 && pf == 1) QL(1, 1);
+                    if (mode == 1 && pf == 2) QL(1, 2);
+                    if (mode == 1 && pf == 3) QL(1, 3);
+#undef QL
+                };
+                const float ms = timeit(launch, 30), cold = cold_time(launch, junk, 10);
+                printf("mode %d queue PF=%d     L=%2d grid %5d          : %.4f / %.4f ms (%.2f TB/s cold)  sum %.6e\n", mode, pf, L, grid, ms,
+                       cold, bytes / cold / 1e9, total(grid));
+            }
         }
         for (int rpl : {2, 4}) {
             const int T = 256 * rpl;
