@@ -1528,7 +1528,12 @@ int build_spmv_pair(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, con
                         if (q < per_xcd[(size_t)x].size()) v = per_xcd[(size_t)x][q];
                         slots_v[q * kXcds + x] = v;
                     }
-                if (!segs.empty() && (int64_t)slots_v.size() + gen_blocks <= grid && steps * T * 2 >= nrows) {
+                // Rows the walk leaves out (a subdomain's boundary planes and appended overlap planes) cost a
+                // companion launch per CG launch: measured with 256 x 256 planes, 8 / 4 / 1 slabs on one GPU
+                // (tools/sweep_sizes.sh, bench.py --ttr-subdomains): +13 % time at 2.2 M rows, +2 % at 4.3 M,
+                // -18 % at 16.8 M; without left-out rows the walk wins from 1 M rows on.
+                const bool worth = gen.empty() || nrows >= 6000000 || sw_mode == 2;
+                if (worth && !segs.empty() && (int64_t)slots_v.size() + gen_blocks <= grid && steps * T * 2 >= nrows) {
                     if ((rc = upv(slots_v, &A->d_sweep_seg)) || (rc = upv(gen, &A->d_sweep_gen)) ||
                         (rc = upv(cval, &A->d_canon_val)) || (rc = upv(cmsk, &A->d_canon_mask)))
                         return rc;
