@@ -334,6 +334,15 @@ struct schwz_trs {
     std::vector<Captured> graphs;
     hipStream_t capture_stream = nullptr;
     bool graphs_failed = false;  // capture / instantiate refused once: launch by launch from then on
+    // flag-driven sweeps (trs_flag_kernel): the two solution vectors that double as per-row flags
+    bool flags = false;
+    unsigned long long *f0 = nullptr, *f1 = nullptr;
+    int *d_err = nullptr;
+    // the factors in level order (rows at their position in the level-sorted order, columns = positions)
+    schwz_idx *fl_rp = nullptr, *fl_col = nullptr, *fu_rp = nullptr, *fu_col = nullptr;
+    double *fl_val = nullptr, *fu_val = nullptr;
+    schwz_idx *fl_src = nullptr, *fu_src = nullptr, *fu_dst = nullptr;  // rhs gather / y scatter per position
+    int flag_grid = 0;
 };
 
 // host-side global problem (explicit CSR or analytic stencil)

@@ -139,6 +139,123 @@ __global__ __launch_bounds__(kTrsBlock) void trs_narrow_kernel(int lv0, int lv1,
     }
 }
 
+// ---- the same solves WITHOUT level-by-level launches: one persistent launch per sweep ---------------
+// The launch plan above spends ~6.6 us per level on dependent-kernel spacing (760 levels for the ILU(0)
+// factors of a 128^3 grid: 5.1 ms per application).  Here every row of the level-sorted order is taken by
+// one lane of a resident wave (chunks of 64 positions dealt round robin to the waves), and a lane waits
+// for its dependencies row by row: the solution vector itself is the flag.  It starts out as a NaN no
+// arithmetic produces (kTrsUnset), every finished row is stored with ONE 8-byte agent-scope store
+// (write-through, MI355X_MICROARCH.md "R2 granule": the data is the flag, no fence), and waiting lanes
+// poll with agent-scope loads that bypass their L1.  Progress: the chunk holding the smallest unfinished
+// position is being worked on by its wave (every wave takes its chunks in ascending order and the whole
+// grid is resident), its rows depend on smaller positions only, and lanes whose dependencies are met
+// finish INSIDE the wait loop, so no lane waits for a lane of its own wave.  Each row sums its entries
+// in CSR order like trs_level_kernel: the same bits.  A wait that exceeds kTrsTimeoutTicks gives up with
+// a NaN (the CG's residual check then fails loudly) instead of hanging the GPU.
+#ifndef SCHWZ_TRS_SLEEP_EVERY
+#define SCHWZ_TRS_SLEEP_EVERY 4  // a power of two, 0: never sleep between polls
+#endif
+constexpr unsigned long long kTrsUnset = 0x7ff8dead7ff8deadull;
+constexpr unsigned long long kTrsTimeoutTicks = 300000000ull;  // 3 s of the 100 MHz constant clock
+typedef unsigned long long u64;
+
+// The factor is stored a second time in LEVEL ORDER (rows permuted to their position in the level-sorted
+// order, columns translated to positions, entries of a row in their original order): lane k of the grid
+// owns position k, its dependencies sit at smaller positions, and the 64 lanes of a wave read row data,
+// poll and publish at (nearly) consecutive addresses -- polls that would otherwise touch up to 64 lines
+// per instruction are what limits how many waves may wait at once.  rhs / y are gathered / scattered
+// through one index per row (src / dst).
+template <bool LOWER>
+__global__ __launch_bounds__(kBlock) void trs_flag_kernel(int64_t n, const schwz_idx *__restrict__ rp,
+                                                          const schwz_idx *__restrict__ col,
+                                                          const double *__restrict__ val, const double *rhs,
+                                                          const schwz_idx *__restrict__ src, u64 *out, u64 *reset,
+                                                          double *y_out, const schwz_idx *__restrict__ dst, int *err)
+{
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x & 63;
+    const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+    const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const u64 t_start = __builtin_amdgcn_s_memrealtime();
+    for (int64_t c = wave; c * 64 < n; c += nwaves) {
+        const int64_t k = c * 64 + lane;
+        bool done = k >= n;
+        int j = 0, jend = 0;
+        double s = 0.0, diag = 1.0;
+        if (!done) {
+            const int s0 = rp[k], e = rp[k + 1];
+            if (LOWER) {
+                j = s0;
+                jend = e - 1;
+                diag = val[e - 1];
+            } else {
+                j = s0 + 1;
+                jend = e;
+                diag = val[s0];
+            }
+            s = rhs[src[k]];
+        }
+        unsigned spins = 0;
+        // the dependencies are requested four at a time and consumed in the row's entry order; their
+        // positions and values are fetched once per group, only the polls repeat
+        int cc[4] = {0, 0, 0, 0};
+        double vv[4] = {0.0, 0.0, 0.0, 0.0};
+        int loaded_at = -1;
+        while (true) {
+            if (!done) {
+                if (loaded_at != j) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool in = j + q < jend;
+                        cc[q] = in ? col[j + q] : (int)k;
+                        vv[q] = in ? val[j + q] : 0.0;
+                    }
+                    loaded_at = j;
+                }
+                u64 got[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    got[q] = j + q < jend ? __hip_atomic_load(out + cc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                bool ok = true;
+                int used = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (j + q < jend && ok) {
+                        if (got[q] != kTrsUnset) {
+                            s -= vv[q] * __longlong_as_double((long long)got[q]);
+                            ++used;
+                        } else {
+                            ok = false;
+                        }
+                    }
+                }
+                j += used;  // a group that moved on is fetched anew (loaded_at != j)
+                if (j == jend) {
+                    const double res = s / diag;
+                    __hip_atomic_store(out + k, (u64)__double_as_longlong(res), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // the other sweep's vector, ready for the next solve: the upper sweep clears the entry it
+                    // took its right-hand side from (nobody else reads it), the lower sweep any one entry
+                    reset[LOWER ? k : (int64_t)src[k]] = kTrsUnset;
+                    if (!LOWER) y_out[dst[k]] = res;
+                    done = true;
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+            if ((++spins & 255u) == 0 && __builtin_amdgcn_s_memrealtime() - t_start > kTrsTimeoutTicks) {
+                if (!done) {
+                    __hip_atomic_store(out + k, 0x7ff8000000000000ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    reset[LOWER ? k : (int64_t)src[k]] = kTrsUnset;
+                    if (!LOWER) y_out[dst[k]] = __longlong_as_double(0x7ff8000000000000ll);
+                    *err = 1;
+                    done = true;
+                }
+            } else if (SCHWZ_TRS_SLEEP_EVERY && (spins & (SCHWZ_TRS_SLEEP_EVERY - 1)) == 0) {
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+    }
+}
+
 }  // namespace schwz
 
 using namespace schwz;
@@ -249,6 +366,84 @@ int schwz_trs_create(int64_t n, const schwz_idx *l_rp, const schwz_idx *l_col, c
     }
     SCHWZ_HIP_TRY(hipMalloc((void **)&t->w0, sizeof(double) * (size_t)(n ? n : 1)));
     SCHWZ_HIP_TRY(hipMalloc((void **)&t->w1, sizeof(double) * (size_t)(n ? n : 1)));
+    // flag-driven sweeps (one persistent launch per factor) for factors beyond the one-workgroup kernel
+    // whose rows are short enough for one lane each; SCHWZ_TRS_FLAGS=0: the level-by-level plan
+    {
+        const char *fenv = std::getenv("SCHWZ_TRS_FLAGS");
+        int64_t longest = 0;
+        for (int64_t i = 0; i < n; ++i)
+            longest = std::max<int64_t>(longest, std::max<int64_t>(l_rp[i + 1] - l_rp[i], u_rp[i + 1] - u_rp[i]));
+        if (!t->fused && !(fenv && fenv[0] == '0') && longest <= 64) {
+            // the factors in level order (see trs_flag_kernel)
+            std::vector<schwz_idx> lpos((size_t)n), upos((size_t)n);
+            for (int64_t k = 0; k < n; ++k) {
+                lpos[(size_t)lo[(size_t)k]] = (schwz_idx)k;
+                upos[(size_t)uo[(size_t)k]] = (schwz_idx)k;
+            }
+            auto permuted = [&](const schwz_idx *rp0, const schwz_idx *col0, const double *val0,
+                                const std::vector<schwz_idx> &ord, const std::vector<schwz_idx> &pos,
+                                std::vector<schwz_idx> &rp1, std::vector<schwz_idx> &col1, std::vector<double> &val1) {
+                rp1.assign((size_t)n + 1, 0);
+                col1.resize((size_t)rp0[n]);
+                val1.resize((size_t)rp0[n]);
+                for (int64_t k = 0; k < n; ++k) {
+                    const schwz_idx r = ord[(size_t)k];
+                    schwz_idx w = rp1[(size_t)k];
+                    for (schwz_idx j = rp0[r]; j < rp0[r + 1]; ++j, ++w) {
+                        col1[(size_t)w] = pos[(size_t)col0[j]];
+                        val1[(size_t)w] = val0[j];
+                    }
+                    rp1[(size_t)k + 1] = w;
+                }
+            };
+            std::vector<schwz_idx> prp, pcol, lsrc((size_t)n), usrc((size_t)n), udst((size_t)n);
+            std::vector<double> pval;
+            int rc2 = 0;
+            permuted(l_rp, l_col, l_val, lo, lpos, prp, pcol, pval);
+            if (!rc2) rc2 = upload(prp.data(), prp.size(), &d), t->fl_rp = (schwz_idx *)d;
+            if (!rc2) rc2 = upload(pcol.data(), pcol.size(), &d), t->fl_col = (schwz_idx *)d;
+            if (!rc2) rc2 = upload(pval.data(), pval.size(), &d), t->fl_val = (double *)d;
+            permuted(u_rp, u_col, u_val, uo, upos, prp, pcol, pval);
+            if (!rc2) rc2 = upload(prp.data(), prp.size(), &d), t->fu_rp = (schwz_idx *)d;
+            if (!rc2) rc2 = upload(pcol.data(), pcol.size(), &d), t->fu_col = (schwz_idx *)d;
+            if (!rc2) rc2 = upload(pval.data(), pval.size(), &d), t->fu_val = (double *)d;
+            for (int64_t k = 0; k < n; ++k) {
+                lsrc[(size_t)k] = perm ? perm[lo[(size_t)k]] : lo[(size_t)k];
+                usrc[(size_t)k] = lpos[(size_t)uo[(size_t)k]];
+                udst[(size_t)k] = perm ? perm[uo[(size_t)k]] : uo[(size_t)k];
+            }
+            if (!rc2) rc2 = upload(lsrc.data(), lsrc.size(), &d), t->fl_src = (schwz_idx *)d;
+            if (!rc2) rc2 = upload(usrc.data(), usrc.size(), &d), t->fu_src = (schwz_idx *)d;
+            if (!rc2) rc2 = upload(udst.data(), udst.size(), &d), t->fu_dst = (schwz_idx *)d;
+            std::vector<unsigned long long> unset((size_t)n, kTrsUnset);
+            if (!rc2) rc2 = upload(unset.data(), unset.size(), &d), t->f0 = (unsigned long long *)d;
+            if (!rc2) {
+                rc2 = upload(unset.data(), unset.size(), &d);
+                t->f1 = (unsigned long long *)d;
+            }
+            const int zero = 0;
+            if (!rc2) {
+                rc2 = upload(&zero, 1, &d);
+                t->d_err = (int *)d;
+            }
+            if (rc2) {
+                schwz_trs_destroy(t);
+                return rc2;
+            }
+            t->flags = true;
+            int dev = 0, cus = 256;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+                prop.multiProcessorCount > 0)
+                cus = prop.multiProcessorCount;
+            // every workgroup must be resident (the waits are on other workgroups' rows): one per CU, far
+            // below any residency limit of this kernel; SCHWZ_TRS_FLAG_GRID overrides (at most 4 per CU)
+            const char *genv = std::getenv("SCHWZ_TRS_FLAG_GRID");
+            int g = genv ? std::atoi(genv) : cus;
+            g = std::max(1, std::min(g, 4 * cus));
+            t->flag_grid = (int)std::min<int64_t>(g, (n + kBlock - 1) / kBlock);
+        }
+    }
     *out = t;
     return SCHWZ_OK;
 }
@@ -257,7 +452,8 @@ void schwz_trs_destroy(schwz_trs *t)
 {
     if (!t) return;
     void *ptrs[] = {t->l_rp, t->l_col, t->l_val, t->u_rp, t->u_col, t->u_val, t->perm,
-                    t->l_order, t->l_lvl, t->u_order, t->u_lvl, t->w0, t->w1};
+                    t->l_order, t->l_lvl, t->u_order, t->u_lvl, t->w0, t->w1, t->f0, t->f1, t->d_err,
+                    t->fl_rp, t->fl_col, t->fl_val, t->fu_rp, t->fu_col, t->fu_val, t->fl_src, t->fu_src, t->fu_dst};
     for (void *p : ptrs) (void)hipFree(p);
     for (auto &g : t->graphs) (void)hipGraphExecDestroy(g.exec);
     if (t->capture_stream) (void)hipStreamDestroy(t->capture_stream);
@@ -273,6 +469,16 @@ int schwz_trs_solve(schwz_trs *t, const double *d_b, double *d_y, schwz_stream s
         hipLaunchKernelGGL(trs_solve_kernel, dim3(1), dim3(kTrsBlock), 0, st, t->n, t->perm, t->l_rp, t->l_col,
                            t->l_val, t->l_order, t->l_lvl, t->l_nlvl, t->u_rp, t->u_col, t->u_val, t->u_order,
                            t->u_lvl, t->u_nlvl, d_b, d_y, t->w0, t->w1);
+        SCHWZ_HIP_TRY(hipGetLastError());
+        return SCHWZ_OK;
+    }
+    if (t->flags) {
+        // L f1 = P b ; U f0 = f1 ; y = P^T f0 -- two persistent launches, rows hand over through the vectors
+        hipLaunchKernelGGL((trs_flag_kernel<true>), dim3(t->flag_grid), dim3(kBlock), 0, st, t->n, t->fl_rp, t->fl_col,
+                           t->fl_val, d_b, t->fl_src, t->f1, t->f0, (double *)nullptr, (const schwz_idx *)nullptr, t->d_err);
+        hipLaunchKernelGGL((trs_flag_kernel<false>), dim3(t->flag_grid), dim3(kBlock), 0, st, t->n, t->fu_rp, t->fu_col,
+                           t->fu_val, reinterpret_cast<const double *>(t->f1), t->fu_src, t->f0, t->f1, d_y, t->fu_dst,
+                           t->d_err);
         SCHWZ_HIP_TRY(hipGetLastError());
         return SCHWZ_OK;
     }

@@ -260,7 +260,7 @@ def test_gmres_matches_oracle(schwz, oracle, torch_cuda, convdiff, restart, pc):
 
 
 @pytest.mark.parametrize("kind", ["ilu_noperm", "chol_perm"])
-def test_triangular_solves_multi_launch_plan(schwz, oracle, torch_cuda, kind):
+def test_triangular_solves_multi_launch_plan(schwz, oracle, torch_cuda, monkeypatch, kind):
     """n > 8192 rows: the level schedule runs as wide/narrow segment launches instead of the
     single-workgroup kernel; same answer as the oracle's sequential sweeps."""
     torch = torch_cuda
@@ -293,6 +293,15 @@ def test_triangular_solves_multi_launch_plan(schwz, oracle, torch_cuda, kind):
     trs.solve(d_b.data_ptr(), d_b.data_ptr())
     torch.cuda.synchronize()
     assert np.array_equal(d_b.cpu().numpy(), got)
+    # the flag-driven sweeps (one persistent launch per factor, rows hand over through the solution
+    # vector) and the level-by-level launch plan sum every row in the same order: the same bits
+    monkeypatch.setenv("SCHWZ_TRS_FLAGS", "0")
+    plan = schwz.Trs(f["l_rp"], f["l_col"], f["l_val"], f["u_rp"], f["u_col"], f["u_val"], perm)
+    d_b2, d_y2 = _dev(torch, b), torch.zeros(n, dtype=torch.float64, device="cuda")
+    for _ in range(3):
+        plan.solve(d_b2.data_ptr(), d_y2.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_y2.cpu().numpy(), got)
 
 
 @pytest.mark.parametrize("case", ["lap3d", "ragged"])

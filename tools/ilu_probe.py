@@ -29,5 +29,6 @@ t0 = time.perf_counter()
 it, rn = cg.solve(b.data_ptr(), x.data_ptr(), 0.0, 20)
 torch.cuda.synchronize()
 el = time.perf_counter() - t0
+print("SCHWZ_TRS_FLAGS=%s SCHWZ_TRS_FLAG_GRID=%s" % (os.environ.get("SCHWZ_TRS_FLAGS"), os.environ.get("SCHWZ_TRS_FLAG_GRID")))
 print("n=%d^3 precond=%d setup %.2f s, %d iterations, %.3f ms per iteration, resnorm %.3e" %
       (n, pc, setup, it, 1e3 * el / it, rn))
