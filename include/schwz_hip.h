@@ -339,6 +339,31 @@ int schwz_ras_unpack(schwz_subdomain *sd, const double *d_recv, schwz_stream str
  * (restricted_schwarz.cpp:898-903, 929-933, 952-954).  Half the xGMI bytes. */
 int schwz_ras_pack_f32(schwz_subdomain *sd, float *d_send, schwz_stream stream);
 int schwz_ras_unpack_f32(schwz_subdomain *sd, const float *d_recv, schwz_stream stream);
+/* One neighbour's share of step 0, to / from any device address: the one-sided exchange without a
+ * matched receive.  "put" (CommHelpers::transfer_buffer with enable_put, include/comm_helpers.hpp:122-150
+ * after pack_buffer :93-118): the pack kernel of out-neighbour k stores straight into that neighbour's
+ * receive window (mapped with schwz_window_open), over xGMI when it lives on another GPU.  "get": the
+ * unpack kernel of in-neighbour k loads from that neighbour's send window.  single != 0: fp32 wire
+ * format (MixedValueType = float). */
+int schwz_ras_pack_neighbor(schwz_subdomain *sd, int k, void *d_dst, int single, schwz_stream stream);
+int schwz_ras_unpack_neighbor(schwz_subdomain *sd, int k, const void *d_src, int single, schwz_stream stream);
+/* Windows: device buffers that other rank processes of the node map into their address space -- the
+ * MPI_Win_create / MPI_Win_lock_all of Communicate::setup_windows (source/communicate.cpp,
+ * include/communicate.hpp:67-224) over HIP IPC.  alloc: a zeroed allocation of its own; export: its
+ * 64-byte handle (send it to the peers by any host channel); open / close: map / unmap a peer's window. */
+int schwz_window_alloc(int64_t bytes, void **d_ptr);
+int schwz_window_free(void *d_ptr);
+int schwz_window_export(void *d_ptr, unsigned char *h_handle64);
+int schwz_window_open(const unsigned char *h_handle64, void **d_ptr);
+int schwz_window_close(void *d_ptr);
+/* Host-side windows (window_convergence, window_residual_vector of include/conv_tools.hpp:56-275) are
+ * shared-memory segments mapped by every rank of the node; these are the remote update operations on
+ * them: MPI_Accumulate(MPI_SUM) on an int, MPI_Put / local read of an int, MPI_Accumulate(MPI_MIN) on a
+ * double. */
+int32_t schwz_host_atomic_add_i32(int32_t *p, int32_t v);
+int32_t schwz_host_atomic_load_i32(const int32_t *p);
+void schwz_host_atomic_store_i32(int32_t *p, int32_t v);
+double schwz_host_atomic_min_f64(double *p, double v);
 /* step 1: b~ = b_loc - A_Gamma x~ (SolverRAS::update_boundary,
  * restricted_schwarz.cpp:992-1017) */
 int schwz_ras_update_boundary(schwz_subdomain *sd, schwz_stream stream);

@@ -989,3 +989,31 @@ int schwz_ilu0(int64_t n, const schwz_idx *rp, const schwz_idx *col, const doubl
 }
 
 }  // extern "C"
+
+// ---- host-side windows in shared memory: the convergence / residual windows of the one-sided mode ----
+// (MPI_Accumulate / MPI_Put on window_convergence and window_residual_vector, include/conv_tools.hpp:56-275,
+// between rank processes of one node: the "window" is a POSIX shared-memory segment every rank maps)
+extern "C" {
+
+int32_t schwz_host_atomic_add_i32(int32_t *p, int32_t v) { return __atomic_add_fetch(p, v, __ATOMIC_SEQ_CST); }
+
+int32_t schwz_host_atomic_load_i32(const int32_t *p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
+
+void schwz_host_atomic_store_i32(int32_t *p, int32_t v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
+
+// *p = min(*p, v) (MPI_Accumulate with MPI_MIN); returns the value left in place
+double schwz_host_atomic_min_f64(double *p, double v)
+{
+    uint64_t *q = reinterpret_cast<uint64_t *>(p);
+    uint64_t old = __atomic_load_n(q, __ATOMIC_SEQ_CST);
+    for (;;) {
+        double cur;
+        std::memcpy(&cur, &old, 8);
+        if (!(v < cur)) return cur;
+        uint64_t want;
+        std::memcpy(&want, &v, 8);
+        if (__atomic_compare_exchange_n(q, &old, want, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) return v;
+    }
+}
+
+}  // extern "C"

@@ -10,6 +10,8 @@
 //   put / get lists: int32 local ids, packed in neighbour order
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+
 #include <cmath>
 
 #include "schwz_internal.hpp"
@@ -170,6 +172,79 @@ int schwz_ras_unpack_f32(schwz_subdomain *sd, const float *d_recv, schwz_stream 
     if (sd->num_recv == 0) return SCHWZ_OK;
     SCHWZ_REQUIRE(d_recv, "schwz_ras_unpack_f32: null recv buffer");
     return launch_scatter_f32(sd->num_recv, sd->d_get_idx, d_recv, sd->d_x, (hipStream_t)stream);
+}
+
+// One neighbour's part of the halo, to / from ANY device address -- the receiver's window in the
+// free-running one-sided mode ("put": the pack kernel stores straight into the neighbour's receive
+// buffer, mapped through schwz_ipc_open; "get": the unpack kernel loads from the neighbour's send buffer).
+int schwz_ras_pack_neighbor(schwz_subdomain *sd, int k, void *d_dst, int single, schwz_stream stream)
+{
+    REQUIRE_DEVICE(sd, "schwz_ras_pack_neighbor");
+    SCHWZ_REQUIRE(k >= 0 && k < (int)sd->put.size(), "schwz_ras_pack_neighbor: no such out-neighbour");
+    int64_t off = 0;
+    for (int q = 0; q < k; ++q) off += (int64_t)sd->put[(size_t)q].size();
+    const int64_t cnt = (int64_t)sd->put[(size_t)k].size();
+    if (cnt == 0) return SCHWZ_OK;
+    SCHWZ_REQUIRE(d_dst, "schwz_ras_pack_neighbor: null destination");
+    if (single) return launch_gather_f32(cnt, sd->d_put_idx + off, sd->d_x, (float *)d_dst, (hipStream_t)stream);
+    return schwz_gather(cnt, sd->d_put_idx + off, sd->d_x, (double *)d_dst, SCHWZ_OP_COPY, stream);
+}
+
+int schwz_ras_unpack_neighbor(schwz_subdomain *sd, int k, const void *d_src, int single, schwz_stream stream)
+{
+    REQUIRE_DEVICE(sd, "schwz_ras_unpack_neighbor");
+    SCHWZ_REQUIRE(k >= 0 && k < (int)sd->get.size(), "schwz_ras_unpack_neighbor: no such in-neighbour");
+    int64_t off = 0;
+    for (int q = 0; q < k; ++q) off += (int64_t)sd->get[(size_t)q].size();
+    const int64_t cnt = (int64_t)sd->get[(size_t)k].size();
+    if (cnt == 0) return SCHWZ_OK;
+    SCHWZ_REQUIRE(d_src, "schwz_ras_unpack_neighbor: null source");
+    if (single) return launch_scatter_f32(cnt, sd->d_get_idx + off, (const float *)d_src, sd->d_x, (hipStream_t)stream);
+    return schwz_scatter(cnt, sd->d_get_idx + off, (const double *)d_src, sd->d_x, SCHWZ_OP_COPY, stream);
+}
+
+// ---- windows: device buffers other rank processes map (the MPI_Win_create of communicate.hpp:67-224) ----
+
+int schwz_window_alloc(int64_t bytes, void **d_ptr)
+{
+    SCHWZ_REQUIRE(d_ptr && bytes >= 0, "schwz_window_alloc: bad arguments");
+    *d_ptr = nullptr;
+    // an allocation of its own (not a piece of a pooled one): the IPC handle names exactly this buffer
+    SCHWZ_HIP_TRY(hipMalloc(d_ptr, (size_t)(bytes > 0 ? bytes : 16)));
+    SCHWZ_HIP_TRY(hipMemset(*d_ptr, 0, (size_t)(bytes > 0 ? bytes : 16)));
+    return SCHWZ_OK;
+}
+
+int schwz_window_free(void *d_ptr)
+{
+    if (d_ptr) SCHWZ_HIP_TRY(hipFree(d_ptr));
+    return SCHWZ_OK;
+}
+
+int schwz_window_export(void *d_ptr, unsigned char *h_handle64)
+{
+    SCHWZ_REQUIRE(d_ptr && h_handle64, "schwz_window_export: null argument");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    hipIpcMemHandle_t h;
+    SCHWZ_HIP_TRY(hipIpcGetMemHandle(&h, d_ptr));
+    std::memcpy(h_handle64, &h, 64);
+    return SCHWZ_OK;
+}
+
+int schwz_window_open(const unsigned char *h_handle64, void **d_ptr)
+{
+    SCHWZ_REQUIRE(d_ptr && h_handle64, "schwz_window_open: null argument");
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, h_handle64, 64);
+    *d_ptr = nullptr;
+    SCHWZ_HIP_TRY(hipIpcOpenMemHandle(d_ptr, h, hipIpcMemLazyEnablePeerAccess));
+    return SCHWZ_OK;
+}
+
+int schwz_window_close(void *d_ptr)
+{
+    if (d_ptr) SCHWZ_HIP_TRY(hipIpcCloseMemHandle(d_ptr));
+    return SCHWZ_OK;
 }
 
 int schwz_ras_update_boundary(schwz_subdomain *sd, schwz_stream stream)

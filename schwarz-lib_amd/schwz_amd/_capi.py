@@ -44,7 +44,10 @@ SYMBOLS = [
     "schwz_subdomain_send_offset", "schwz_subdomain_recv_offset",
     "schwz_cholesky", "schwz_ilu0", "schwz_isai", "schwz_free",
     "schwz_subdomain_to_device", "schwz_ras_pack", "schwz_ras_unpack", "schwz_ras_pack_f32",
-    "schwz_ras_unpack_f32",
+    "schwz_ras_unpack_f32", "schwz_ras_pack_neighbor", "schwz_ras_unpack_neighbor",
+    "schwz_window_alloc", "schwz_window_free", "schwz_window_export", "schwz_window_open", "schwz_window_close",
+    "schwz_host_atomic_add_i32", "schwz_host_atomic_load_i32", "schwz_host_atomic_store_i32",
+    "schwz_host_atomic_min_f64",
     "schwz_ras_update_boundary", "schwz_ras_local_residual", "schwz_ras_local_residual_launch",
     "schwz_ras_local_residual_wait", "schwz_ras_local_solve", "schwz_ras_set_local_max_iters",
     "schwz_ras_last_inner_stats",
@@ -160,6 +163,17 @@ _sig("schwz_ras_unpack", i32, [vp, vp, vp])
 _sig("schwz_ras_pack_f32", i32, [vp, vp, vp])
 _sig("schwz_ras_unpack_f32", i32, [vp, vp, vp])
 _sig("schwz_ras_update_boundary", i32, [vp, vp])
+_sig("schwz_ras_pack_neighbor", i32, [vp, i32, vp, i32, vp])
+_sig("schwz_ras_unpack_neighbor", i32, [vp, i32, vp, i32, vp])
+_sig("schwz_window_alloc", i32, [i64, pvp])
+_sig("schwz_window_free", i32, [vp])
+_sig("schwz_window_export", i32, [vp, vp])
+_sig("schwz_window_open", i32, [vp, pvp])
+_sig("schwz_window_close", i32, [vp])
+_sig("schwz_host_atomic_add_i32", i32, [vp, i32])
+_sig("schwz_host_atomic_load_i32", i32, [vp])
+_sig("schwz_host_atomic_store_i32", None, [vp, i32])
+_sig("schwz_host_atomic_min_f64", dbl, [vp, dbl])
 _sig("schwz_ras_local_residual", i32, [vp, C.POINTER(dbl), vp])
 _sig("schwz_ras_local_residual_launch", i32, [vp, vp])
 _sig("schwz_ras_local_residual_wait", i32, [vp, C.POINTER(dbl)])

@@ -213,3 +213,71 @@ class TorchDistComm:
 
     def barrier(self):
         self._dist.barrier(group=self.host_group)
+
+
+class WindowComm(TorchDistComm):
+    """TorchDistComm plus what the free-running one-sided mode needs (communicate.cpp's windows,
+    conv_tools.hpp's window_convergence / window_residual_vector), for the rank processes of ONE node:
+
+      * `share(obj)` -- every rank's object to every rank (setup only): the IPC handles and buffer
+        offsets of the halo windows, which live in device memory and are mapped by the neighbours
+        (core.DeviceWindow / PeerWindow), so that a halo "put" is a pack kernel storing over xGMI and
+        a "get" an unpack kernel loading over it -- no matched receive, no collective in the loop;
+      * `host_windows()` -- the convergence and residual windows as numpy arrays on a POSIX
+        shared-memory segment that every rank maps: a remote MPI_Put / MPI_Accumulate becomes a store /
+        an atomic update on the target rank's row.
+    """
+
+    node_windows = True
+
+    def __init__(self, device=None, group=None):
+        super().__init__(device=device, group=group)
+        self._shm = None
+
+    def share(self, obj):
+        out = [None] * self.size
+        self._dist.all_gather_object(out, obj, group=self.host_group)
+        return out
+
+    def host_windows(self):
+        """{'tree': int32 [P][4], 'flags': int32 [P][P], 'count': int32 [P], 'resid': float64 [P][P]},
+        row r = rank r's window.  Created by rank 0, zeroed (resid: max double, conv_tools.hpp:69)."""
+        from multiprocessing import shared_memory
+        P = self.size
+        nint = P * 4 + P * P + P
+        nint += nint % 2
+        nbytes = 4 * nint + 8 * P * P
+        name = [None]
+        if self.is_root:
+            self._shm = shared_memory.SharedMemory(create=True, size=nbytes)
+            self._shm.buf[:nbytes] = bytes(nbytes)
+            name[0] = self._shm.name
+        self._dist.broadcast_object_list(name, src=0, group=self.host_group)
+        if not self.is_root:
+            self._shm = shared_memory.SharedMemory(name=name[0])
+            try:  # the creator unlinks; keep the resource tracker of this process out of it
+                from multiprocessing import resource_tracker
+                resource_tracker.unregister(self._shm._name, "shared_memory")
+            except Exception:
+                pass
+        ints = np.ndarray((nint,), dtype=np.int32, buffer=self._shm.buf, offset=0)
+        resid = np.ndarray((P, P), dtype=np.float64, buffer=self._shm.buf, offset=4 * nint)
+        if self.is_root:
+            resid[:] = np.finfo(np.float64).max
+        self.barrier()
+        return dict(tree=ints[:4 * P].reshape(P, 4), flags=ints[4 * P:4 * P + P * P].reshape(P, P),
+                    count=ints[4 * P + P * P:4 * P + P * P + P], resid=resid)
+
+    def close_windows(self):
+        if self._shm is not None:
+            self.barrier()
+            shm, self._shm = self._shm, None
+            try:
+                shm.close()
+            except BufferError:
+                pass  # numpy views still alive: the mapping goes with the process
+            if self.is_root:
+                try:
+                    shm.unlink()
+                except FileNotFoundError:
+                    pass

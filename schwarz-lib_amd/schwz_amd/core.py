@@ -221,6 +221,64 @@ def cholesky(rp, col, val, natural=False):
     return res
 
 
+class DeviceWindow:
+    """A device buffer other rank processes of the node can map (MPI_Win_create of
+    communicate.hpp:67-224 over HIP IPC).  `handle` travels to the peers over any host channel."""
+
+    def __init__(self, count, single=False):
+        self.count, self.esize = int(count), 4 if single else 8
+        p = C.c_void_p()
+        check(lib.schwz_window_alloc(self.count * self.esize, C.byref(p)))
+        self.ptr = p.value
+        buf = (C.c_ubyte * 64)()
+        check(lib.schwz_window_export(C.c_void_p(self.ptr), buf))
+        self.handle = ("hip-ipc", bytes(buf), self.count, self.esize)
+
+    def at(self, offset):
+        return self.ptr + int(offset) * self.esize
+
+    def close(self):
+        if getattr(self, "ptr", None) and lib is not None:
+            lib.schwz_window_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        self.close()
+
+
+class PeerWindow:
+    """Another rank's DeviceWindow mapped into this process."""
+
+    def __init__(self, handle):
+        kind, raw, self.count, self.esize = handle
+        assert kind == "hip-ipc"
+        buf = (C.c_ubyte * 64).from_buffer_copy(raw)
+        p = C.c_void_p()
+        check(lib.schwz_window_open(buf, C.byref(p)))
+        self.ptr = p.value
+
+    def at(self, offset):
+        return self.ptr + int(offset) * self.esize
+
+    def close(self):
+        if getattr(self, "ptr", None) and lib is not None:
+            lib.schwz_window_close(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        self.close()
+
+
+def host_atomic_add(arr, index, v=1):
+    """MPI_Accumulate(MPI_SUM) on an int32 of a shared-memory window."""
+    return int(lib.schwz_host_atomic_add_i32(C.c_void_p(arr.ctypes.data + 4 * int(index)), int(v)))
+
+
+def host_atomic_min(arr, index, v):
+    """MPI_Accumulate(MPI_MIN) on a float64 of a shared-memory window."""
+    return float(lib.schwz_host_atomic_min_f64(C.c_void_p(arr.ctypes.data + 8 * int(index)), float(v)))
+
+
 # ---------------------------------------------------------------------------
 # host setup
 # ---------------------------------------------------------------------------
@@ -434,6 +492,14 @@ class Subdomain:
 
     def unpack_f32(self, d_recv, stream=0):
         check(lib.schwz_ras_unpack_f32(self.h, ptr(d_recv), _stream_arg(stream)))
+
+    def pack_neighbor(self, k, dst, single=False, stream=0):
+        """Out-neighbour k's halo values to the device address `dst` (its receive window)."""
+        check(lib.schwz_ras_pack_neighbor(self.h, int(k), ptr(dst), int(bool(single)), _stream_arg(stream)))
+
+    def unpack_neighbor(self, k, src, single=False, stream=0):
+        """In-neighbour k's halo values from the device address `src` (its send window)."""
+        check(lib.schwz_ras_unpack_neighbor(self.h, int(k), ptr(src), int(bool(single)), _stream_arg(stream)))
 
     def update_boundary(self, stream=0):
         check(lib.schwz_ras_update_boundary(self.h, _stream_arg(stream)))

@@ -153,6 +153,12 @@ class HipBackend:
     def synchronize(self):
         self._torch.cuda.synchronize()
 
+    # halo windows of the free-running one-sided mode (HIP IPC)
+    window = staticmethod(core.DeviceWindow)
+    open_window = staticmethod(core.PeerWindow)
+    atomic_add = staticmethod(core.host_atomic_add)
+    atomic_min = staticmethod(core.host_atomic_min)
+
     # problem sources / partitions (host code of libschwz_hip.so)
     problem_laplacian = staticmethod(core.Problem.laplacian)
     problem_from_matrix_market = staticmethod(core.Problem.from_matrix_market)
@@ -366,6 +372,10 @@ class SolverRAS:
             (me, [(q, len(ids)) for q, ids in sd.put_lists()],
              [(p, len(ids)) for p, ids in sd.get_lists()], sd.num_send, sd.num_recv)
             for me, sd in self.subdomains.items()]
+        self._win = None
+        if s.comm_settings.enable_onesided and getattr(comm, "node_windows", False) \
+                and not s.comm_settings.enable_overlap:
+            self._setup_windows()
         self._print(" Problem size: %d, subdomains: %d, local size (rank %d): %d (+%d overlap)" %
                     (m.global_size, P, comm.rank, m.local_size, m.overlap_size))
         if solver_code == capi.SOLVER_ITERATIVE:
@@ -441,6 +451,18 @@ class SolverRAS:
         self._stop = {me: NEVER for me in self.subdomains}
         self._pending = None
         self._t_begin = time.perf_counter()
+        if getattr(self, "_win", None) is not None:
+            # a fresh run: the windows go back to their initial state (collectively, before anybody iterates)
+            self.comm.barrier()
+            hw = self._win["host"]
+            if self.comm.is_root:
+                hw["tree"][:] = 0
+                hw["flags"][:] = 0
+                hw["count"][:] = 0
+                hw["resid"][:] = np.finfo(np.float64).max
+            self._win["sent"][:] = 0
+            self._win["counted"] = False
+            self.comm.barrier()
         if getattr(self, "_two_stage_on", False):  # a re-run starts with the first-stage cap again
             for _, sd in self.subdomains.items():
                 sd.set_local_max_iters(m.local_max_iters)
@@ -473,13 +495,193 @@ class SolverRAS:
             if cv.enable_accumulate:
                 notes.append("enable_accumulate (MPI_Accumulate(MIN) of the norms) has no RCCL counterpart: "
                              "the flags travel with the halo messages")
+        elif getattr(self, "_win", None) is not None:
+            notes.append("free-running one-sided exchange: halo %s through peer-mapped device windows, no "
+                         "matched receive, no collective in the loop; termination: %s" %
+                         ("put" if cs.enable_put else "get",
+                          "centralised tree (conv_tools.hpp:147-209)" if cv.enable_global_simple_tree else
+                          ("decentralised, accumulated counters" if cv.enable_accumulate else
+                           "decentralised flag propagation (conv_tools.hpp:213-275)")))
         else:
-            notes.append("one-sided without enable_overlap: local tests, flags all-gathered per iteration "
-                         "(a host collective stands in for the window reads)")
+            notes.append("one-sided without enable_overlap on a communicator without node windows: local "
+                         "tests, flags all-gathered per iteration (a host collective stands in for the "
+                         "window reads)")
         if not cv.put_all_local_residual_norms:
             notes.append("put_all_local_residual_norms=false changes nothing: norms never travel in one-sided mode")
         for n in notes:
             self._print(" [schwz] " + n)
+
+    def _setup_windows(self):
+        """Communicate::setup_windows (source/communicate.cpp; include/communicate.hpp:67-224): every
+        rank exposes its receive and its send buffer as a window the neighbours map, and learns at
+        which offset of a neighbour's window its own values live (put_displacements /
+        get_displacements, restricted_schwarz.cpp:624-658)."""
+        s, be, comm = self.settings, self.backend, self.comm
+        me = comm.rank
+        sd = self.subdomains[me]
+        single = s.use_mixed_precision
+        recv_w = be.window(max(sd.num_recv, 1), single)
+        send_w = be.window(max(sd.num_send, 1), single)
+        roff, soff = sd.recv_offsets(), sd.send_offsets()
+        mine = dict(recv=recv_w.handle, send=send_w.handle,
+                    recv_off={p: roff[k] for k, (p, _) in enumerate(sd.get_lists())},
+                    send_off={q: soff[k] for k, (q, _) in enumerate(sd.put_lists())})
+        everyone = comm.share(mine)
+        peers_recv, peers_send = {}, {}
+        for q, _ in sd.put_lists():   # "put": my values go into q's receive window, where q expects rank me
+            peers_recv[q] = (be.open_window(everyone[q]["recv"]), everyone[q]["recv_off"][me])
+        for p, _ in sd.get_lists():   # "get": p's values for me sit in p's send window
+            peers_send[p] = (be.open_window(everyone[p]["send"]), everyone[p]["send_off"][me])
+        self._win = dict(recv=recv_w, send=send_w, peers_recv=peers_recv, peers_send=peers_send, single=single,
+                         host=comm.host_windows(), sent=np.zeros(comm.size, dtype=np.int32),
+                         puts=[(q, len(ids)) for q, ids in sd.put_lists()],
+                         gets=[(p, len(ids)) for p, ids in sd.get_lists()], roff=roff, soff=soff)
+        comm.barrier()
+
+    def _exchange_free_running(self, sd, stream):
+        """exchange_boundary_onesided (restricted_schwarz.cpp:715-852): put = pack into the neighbours'
+        receive windows, then scatter whatever MY receive window holds; get = pack into my send
+        window, then scatter straight out of the neighbours' send windows.  Nobody waits for anybody."""
+        w, cs = self._win, self.settings.comm_settings
+        single = w["single"]
+        if cs.enable_put:
+            for k, (q, _) in enumerate(w["puts"]):
+                win, off = w["peers_recv"][q]
+                sd.pack_neighbor(k, win.at(off), single, stream)
+            for k, (p, _) in enumerate(w["gets"]):
+                sd.unpack_neighbor(k, w["recv"].at(w["roff"][k]), single, stream)
+        else:
+            for k, (q, _) in enumerate(w["puts"]):
+                sd.pack_neighbor(k, w["send"].at(w["soff"][k]), single, stream)
+            for k, (p, _) in enumerate(w["gets"]):
+                win, off = w["peers_send"][p]
+                sd.unpack_neighbor(k, win.at(off), single, stream)
+
+    def _termination_free_running(self, me, sd, lres, converged_local):
+        """check_global_convergence, one-sided branch (solve.cpp:876-943) on the shared-memory windows.
+        Returns num_converged_procs."""
+        cv, be, m = self.settings.convergence_settings, self.backend, self.metadata
+        P, it = m.num_subdomains, m.iter_count
+        hw = self._win["host"]
+        resid, ppd = hw["resid"], m.post_process_data
+        # window_residual_vector (conv_tools.hpp:56-142): my smallest local residual so far, to everybody
+        # (put_all_local_residual_norms) or min-accumulated along the neighbour graph
+        mine = resid[me]
+        mine[me] = min(mine[me], lres)
+        prev = ppd["global_residual_vector_out"][me][-1] if it > 0 and ppd["global_residual_vector_out"][me] else None
+        if cv.put_all_local_residual_norms:
+            if it > 0 and mine[me] != prev:
+                for j in range(P):
+                    if j != me:
+                        resid[j][me] = mine[me]
+        else:
+            big = np.finfo(np.float64).max
+            for q, cnt_q in self._win["puts"]:
+                if cnt_q == 0:
+                    continue
+                for j in range(P):
+                    if j != q and mine[j] != big:
+                        be.atomic_min(resid[q], j, float(mine[j]))
+        for j in range(P):
+            ppd["global_residual_vector_out"][j].append(float(mine[j]))
+        if cv.enable_global_simple_tree:
+            # Yamazaki et al. 2019 (conv_tools.hpp:147-209): slots 0 / 1 = my children have reported, slot 2 =
+            # the verdict coming down; a node reports once (slot 0 := 2), when its children have and it
+            # passes its own test in this very iteration
+            t = hw["tree"]
+            c = t[me]
+            if (((c[0] == 1 and c[1] == 1) or (c[0] == 1 and me == P // 2 - 1) or (me >= P // 2 and c[0] != 2))
+                    and converged_local):
+                if me == 0:
+                    c[2] = 1
+                else:
+                    t[(me - 1) // 2][1 if me % 2 == 0 else 0] = 1
+                c[0] = 2
+            if c[2] == 1:
+                for child in (2 * me + 1, 2 * me + 2):
+                    if child < P:
+                        t[child][2] = 1
+                c[1] += 1
+                return P
+            return 0
+        if cv.enable_accumulate:
+            # conv_tools.hpp:229-246: +1 on everybody's counter.  The reference adds again in EVERY
+            # iteration a rank passes its test, so its counters overshoot num_subdomains and the
+            # "== num_subdomains" exit can be missed or hit early; here a rank adds once.
+            cnt = hw["count"]
+            if converged_local and not self._win.get("counted"):
+                for j in range(P):
+                    be.atomic_add(cnt, j, 1)
+                self._win["counted"] = True
+            return int(cnt[me])
+        # decentralised flag propagation (conv_tools.hpp:247-273): what I know goes to my out-neighbours, once
+        fl, sent = hw["flags"], self._win["sent"]
+        if converged_local:
+            fl[me][me] = 1
+        local = fl[me].copy()
+        for q, cnt_q in self._win["puts"]:
+            if cnt_q == 0:
+                continue
+            for j in range(P):
+                if sent[j] == 0 and local[j] == 1:
+                    fl[q][j] = 1
+        sent[:] = local
+        return int(local.sum())
+
+    def _step_free_running(self):
+        """`enable_onesided` on a communicator with node windows: the reference's asynchronous
+        iteration (schwarz_base.cpp:387-452 with exchange_boundary_onesided and the one-sided branch
+        of check_global_convergence).  Every rank runs at its own pace: halos are whatever the
+        neighbours' last put left in my window (or what their send window holds when I get), the
+        local test feeds the tree / decentralised termination protocol on shared-memory windows, and
+        a rank leaves the loop when ITS window says all have converged."""
+        s, m, be, comm = self.settings, self.metadata, self.backend, self.comm
+        cv = s.convergence_settings
+        self._two_stage()
+        me = comm.rank
+        sd = self.subdomains[me]
+        ppd, tol, it = m.post_process_data, m.tolerance, m.iter_count
+        stream = be.stream()
+        t0 = time.perf_counter()
+        if it > 0:  # restricted_schwarz.cpp:725
+            self._exchange_free_running(sd, stream)
+        t1 = time.perf_counter()
+        sd.update_boundary(stream)
+        t2 = time.perf_counter()
+        spec = self.speculative_solve and hasattr(sd, "check_and_solve_launch") and tol >= 0.0
+        if spec:
+            sd.check_and_solve_launch(stream)
+            lres = sd.local_residual_wait()
+        else:
+            lres = sd.local_residual(stream) if tol >= 0.0 else -1.0
+        if self._lres0[me] < 0.0:
+            self._lres0[me] = lres
+        if np.isnan(lres):
+            raise capi.SchwzError(capi.ERR_DIVERGED, "local residual is NaN")
+        ppd["local_residual_vector_out"].append(lres)
+        m.current_residual_norm = lres
+        m.min_residual_norm = lres if it == 0 else min(lres, m.min_residual_norm)
+        iter_cond = ((it > m.max_iters * 0.05) or m.max_iters < 1000) \
+            if cv.enable_global_check_iter_offset else True
+        if tol > 0.0 and iter_cond:
+            converged_local = _ratio(lres, self._lres0[me]) <= tol
+            self._num_converged = self._termination_free_running(me, sd, lres, converged_local)
+        t3 = time.perf_counter()
+        tm = self._timings
+        tm[0].append(t1 - t0)
+        tm[1].append(t2 - t1)
+        tm[2].append(t3 - t2)
+        if self._num_converged == m.num_subdomains:
+            return True
+        if not spec:
+            sd.local_solve(stream)
+        self._log_local_solve([(me, sd)])
+        t4 = time.perf_counter()
+        sd.restrict(stream)
+        tm[3].append(t4 - t3)
+        tm[4].append(time.perf_counter() - t4)
+        m.iter_count += 1
+        return False
 
     def _step_overlapped(self):
         """`enable_onesided` + `enable_overlap`: the asynchronous flavour of the iteration as
@@ -574,6 +776,8 @@ class SolverRAS:
         cs, cv = s.comm_settings, s.convergence_settings
         if cs.enable_onesided and cs.enable_overlap:
             return self._step_overlapped()
+        if cs.enable_onesided and getattr(self, "_win", None) is not None:
+            return self._step_free_running()
         self._two_stage()
         P = m.num_subdomains
         locals_ = list(self.subdomains.items())

@@ -30,6 +30,41 @@ class OracleProblem:
         return self.rp, self.col, self.val
 
 
+class ShmWindow:
+    """TEST stand-in for core.DeviceWindow / PeerWindow: a float64 array on a /dev/shm file that
+    several rank processes map (host memory plays the device's part in the CPU tests)."""
+
+    _serial = 0
+
+    def __init__(self, count=None, single=False, handle=None):
+        import os
+        assert not single, "the test backend exchanges fp64 halos only"
+        if handle is None:
+            ShmWindow._serial += 1
+            self.path = "/dev/shm/schwz_test_%d_%d" % (os.getpid(), ShmWindow._serial)
+            self.count = max(int(count), 1)
+            self.arr = np.memmap(self.path, dtype=np.float64, mode="w+", shape=(self.count,))
+            self.arr[:] = 0.0
+            self.owner = True
+        else:
+            _, self.path, self.count = handle
+            self.arr = np.memmap(self.path, dtype=np.float64, mode="r+", shape=(self.count,))
+            self.owner = False
+        self.handle = ("shm-file", self.path, self.count)
+
+    def at(self, offset):
+        return self.arr[int(offset):]
+
+    def close(self):
+        import os
+        if getattr(self, "owner", False) and os.path.exists(self.path):
+            os.unlink(self.path)
+            self.owner = False
+
+    def __del__(self):
+        self.close()
+
+
 class OracleSubdomain:
     def __init__(self, problem, P, me, overlap, first_row):
         self.problem = problem
@@ -101,6 +136,15 @@ class OracleSubdomain:
         for k in range(self.num_neighbors_in):
             self.state.unpack(k, buf[off[k]:off[k + 1]].copy())
 
+    def pack_neighbor(self, k, dst, single=False, stream=0):
+        v = self.state.pack(k)
+        dst[:len(v)] = v
+
+    def unpack_neighbor(self, k, src, single=False, stream=0):
+        off = self.recv_offsets()
+        n = off[k + 1] - off[k]
+        self.state.unpack(k, np.array(src[:n], dtype=np.float64))
+
     def update_boundary(self, stream=0):
         self.state.update_boundary()
 
@@ -145,6 +189,24 @@ class OracleBackend:
 
     def synchronize(self):
         pass
+
+    @staticmethod
+    def window(count, single=False):
+        return ShmWindow(count, single)
+
+    @staticmethod
+    def open_window(handle):
+        return ShmWindow(handle=handle)
+
+    @staticmethod
+    def atomic_add(arr, index, v=1):
+        from schwz_amd import core
+        return core.host_atomic_add(arr, index, v)
+
+    @staticmethod
+    def atomic_min(arr, index, v):
+        from schwz_amd import core
+        return core.host_atomic_min(arr, index, v)
 
     @staticmethod
     def problem_laplacian(dim, nx, ny=None, nz=None):

@@ -616,3 +616,84 @@ def test_initialize_from_csr_arrays_and_rhs(schwz, oracle, torch_cuda, partition
                              _oracle_settings(oracle, m, s))
         assert ref["converged"] and ref["iter_count"] == out["iter_count"]
         assert np.abs(sol - ref["solution"]).max() <= TOL_SOL * np.abs(ref["solution"]).max()
+
+
+_FREE_RUNNING_RANK = r"""
+import json, os, sys
+sys.path.insert(0, %(pkg)r)
+import numpy as np
+import torch, torch.distributed as dist
+import schwz_amd as S
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+comm = S.WindowComm(device=torch.device("cuda", 0))
+s = S.Settings(laplacian_dim=3, laplacian_shape=(24, 20, 30), use_mixed_precision=%(mixed)s)
+s.comm_settings.enable_onesided = True
+s.comm_settings.enable_put = %(put)s
+s.comm_settings.enable_get = not %(put)s
+s.convergence_settings.enable_global_simple_tree = %(tree)s
+s.convergence_settings.enable_decentralized_leader_election = not %(tree)s
+m = S.Metadata(tolerance=%(tol)g, max_iters=3000, local_precond="block-jacobi", precond_max_block_size=1,
+               local_solver_tolerance=1e-10)
+solver = S.SolverRAS(s, m, comm=comm, quiet=True)
+solver.initialize()
+out = solver.run()
+if comm.rank == 0:
+    np.save(%(sol)r, out["solution"])
+print(json.dumps(dict(rank=comm.rank, iters=out["iter_count"], conv=bool(out["converged"]),
+                      rel=out["residual_norm"] / out["rhs_norm"])), flush=True)
+comm.close_windows()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("flavour", [("put", "tree", False), ("get", "decentralized", False), ("put", "decentralized", True)])
+def test_free_running_onesided_mode_through_hip_ipc_windows(schwz, oracle, torch_cuda, tmp_path, flavour):
+    """The asynchronous iteration of the reference (exchange_boundary_onesided,
+    restricted_schwarz.cpp:715-852) with three rank PROCESSES sharing this GPU: every rank's receive and
+    send buffers are device windows the neighbours map through HIP IPC; a "put" is the pack kernel
+    storing straight into the neighbour's window, a "get" the unpack kernel loading from it; nobody
+    posts a receive and the loop contains no collective.  Termination by the tree / the decentralised
+    protocol on shared-memory windows.  Non-deterministic by construction: checked by properties --
+    all ranks converge, the assembled solution solves the system (against the oracle's synchronous run),
+    fp32 windows (use_mixed_precision) reach the accuracy fp32 halos allow."""
+    import json
+    import subprocess
+    import sys
+    import socket
+    put, proto, mixed = flavour
+    world = 3
+    sol = str(tmp_path / "sol.npy")
+    script = tmp_path / "rank.py"
+    script.write_text(_FREE_RUNNING_RANK % dict(
+        pkg=os.path.join(os.path.dirname(os.path.dirname(__file__)), "schwarz-lib_amd"), put=put == "put",
+        tree=proto == "tree", mixed=mixed, tol=1e-4 if mixed else 1e-7, sol=sol))
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, e = p.communicate()
+        assert p.returncode == 0, o + e[-3000:]
+        outs.append(json.loads([ln for ln in o.splitlines() if ln.startswith("{")][-1]))
+    assert all(o["conv"] for o in outs)
+    assert all(5 < o["iters"] < 3000 for o in outs)
+    rp, col, val = oracle.laplacian3d(24, 20, 30)
+    N = len(rp) - 1
+    ref = oracle.ras_run(rp, col, val, np.ones(N), world, oracle.first_rows_regular(N, world),
+                         oracle.make_settings(max_iters=3000, tol=1e-9, precond=1, local_tol=1e-10))
+    assert ref["converged"]
+    x = np.load(sol)
+    assert np.abs(x - ref["solution"]).max() <= (2e-3 if mixed else 1e-4) * np.abs(ref["solution"]).max()
+    assert outs[0]["rel"] < (1e-2 if mixed else 1e-4)
