@@ -260,6 +260,7 @@ struct schwz_csr {
          *d_ptbl_val = nullptr, *d_ptbl_meta = nullptr, *d_chunk_dual = nullptr;
     void *d_tile_dual = nullptr;
     std::vector<schwz_idx> h_tiles;  // host copy of the tile boundaries
+    int pair_deal_shift = 0;         // log2 of the run length (in tiles) of the XCD deal the pair kernels derive theirs from
     double dict_fraction = 0.0;  // share of the nonzeros that are dictionary coded
     double pattern_fraction = 0.0;  // share of the nonzeros in row-pattern coded tiles
     double pair_fraction = 0.0;     // share of the nonzeros in row-pair coded tiles

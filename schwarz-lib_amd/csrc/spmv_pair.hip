@@ -1597,7 +1597,7 @@ int build_spmv_pair(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, con
         A->pair_code_bytes = bytes;
     }
     // the XCD deal of the chunks: the tile deal's run length in rows, in chunks (a power of two)
-    int sh = A->v.xcd_shift;
+    int sh = A->pair_deal_shift;
     const int64_t rows_per_tile = std::max<int64_t>(1, nrows / std::max<int64_t>(1, (int64_t)tiles.size() - 1));
     for (int64_t f = kPairRows / std::max<int64_t>(1, rows_per_tile); f > 1 && sh > 0; f >>= 1) --sh;
     A->v.pair_shift = sh;
