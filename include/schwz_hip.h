@@ -85,6 +85,17 @@ int schwz_gather(int64_t n, const schwz_idx *d_idx, const double *d_from,
 int schwz_scatter(int64_t n, const schwz_idx *d_idx, const double *d_from,
                   double *d_into, int op, schwz_stream stream);
 
+/* The other instantiations of Gather / Scatter (source/gather_kernel.cu:112-146,
+ * source/scatter_kernel.cu:109-142: {float, double, int, long} values x {int, long} indices); the hot
+ * path itself only uses fp64 values with int32 indices (schwz_gather / schwz_scatter) and the fp32 wire
+ * format of the mixed-precision halo. */
+enum schwz_value_type { SCHWZ_VALUE_F32 = 0, SCHWZ_VALUE_F64 = 1, SCHWZ_VALUE_I32 = 2, SCHWZ_VALUE_I64 = 3 };
+enum schwz_index_type { SCHWZ_INDEX_I32 = 0, SCHWZ_INDEX_I64 = 1 };
+int schwz_gather_typed(int64_t n, const void *d_idx, int index_type, const void *d_from, void *d_into,
+                       int value_type, int op, schwz_stream stream);
+int schwz_scatter_typed(int64_t n, const void *d_idx, int index_type, const void *d_from, void *d_into,
+                        int value_type, int op, schwz_stream stream);
+
 /* CSR matrix resident in HBM, with the row-tile table the SpMV kernel needs.
  * Replaces gko::matrix::Csr<double,int> on the device executor. */
 typedef struct schwz_csr schwz_csr;

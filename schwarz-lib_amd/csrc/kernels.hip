@@ -52,6 +52,60 @@ __global__ void scatter_kernel(int64_t n, const schwz_idx *__restrict__ idx,
     }
 }
 
+// The reference instantiates its Gather / Scatter for {float, double, int, long} values and {int, long}
+// indices (source/gather_kernel.cu:112-146, scatter_kernel.cu:109-142): the same here, one grid-stride
+// kernel per (value, index, op) behind schwz_gather_typed / schwz_scatter_typed.  avg follows the CPU
+// definition (y + x) / 2 in the value type (integer division for the integer types).
+template <typename V, int OP>
+__device__ __forceinline__ V combine_t(V into, V from)
+{
+    if (OP == SCHWZ_OP_COPY) return from;
+    if (OP == SCHWZ_OP_ADD) return from + into;
+    if (OP == SCHWZ_OP_DIFF) return from - into;
+    return (from + into) / 2;
+}
+
+template <typename V, typename I, int OP>
+__global__ void gather_typed_kernel(int64_t n, const I *__restrict__ idx, const V *__restrict__ from, V *__restrict__ into)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        into[i] = combine_t<V, OP>(OP == SCHWZ_OP_COPY ? V(0) : into[i], from[idx[i]]);
+}
+
+template <typename V, typename I, int OP>
+__global__ void scatter_typed_kernel(int64_t n, const I *__restrict__ idx, const V *__restrict__ from, V *__restrict__ into)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const I k = idx[i];
+        into[k] = combine_t<V, OP>(OP == SCHWZ_OP_COPY ? V(0) : into[k], from[i]);
+    }
+}
+
+template <typename V, typename I>
+int launch_gs_typed(bool scatter, int64_t n, const void *idx, const void *from, void *into, int op, hipStream_t st)
+{
+    const int g = grid_for(n);
+#define SCHWZ_GS(OP_)                                                                                                   \
+    if (scatter)                                                                                                        \
+        hipLaunchKernelGGL((scatter_typed_kernel<V, I, OP_>), dim3(g), dim3(kBlock), 0, st, n, (const I *)idx,           \
+                           (const V *)from, (V *)into);                                                                 \
+    else                                                                                                                \
+        hipLaunchKernelGGL((gather_typed_kernel<V, I, OP_>), dim3(g), dim3(kBlock), 0, st, n, (const I *)idx,            \
+                           (const V *)from, (V *)into);
+    switch (op) {
+    case SCHWZ_OP_COPY: SCHWZ_GS(SCHWZ_OP_COPY) break;
+    case SCHWZ_OP_ADD: SCHWZ_GS(SCHWZ_OP_ADD) break;
+    case SCHWZ_OP_DIFF: SCHWZ_GS(SCHWZ_OP_DIFF) break;
+    case SCHWZ_OP_AVG: SCHWZ_GS(SCHWZ_OP_AVG) break;
+    default: set_error(scatter ? "Undefined scatter operation" : "Undefined gather operation"); return SCHWZ_ERR_INVALID;
+    }
+#undef SCHWZ_GS
+    SCHWZ_HIP_TRY(hipGetLastError());
+    return SCHWZ_OK;
+}
+
 // halo pack / unpack with the fp64 <-> fp32 conversion of the mixed-precision exchange
 __global__ void gather_f32_kernel(int64_t n, const schwz_idx *__restrict__ idx, const double *__restrict__ from,
                                   float *__restrict__ into)
@@ -190,6 +244,44 @@ int schwz_scatter(int64_t n, const schwz_idx *d_idx, const double *d_from, doubl
     return SCHWZ_OK;
 }
 #undef LAUNCH_GS
+
+static int gs_typed(bool scatter, int64_t n, const void *d_idx, int index_type, const void *d_from, void *d_into,
+                    int value_type, int op, schwz_stream stream)
+{
+    SCHWZ_REQUIRE(n >= 0, "schwz_gather_typed / schwz_scatter_typed: negative length");
+    SCHWZ_REQUIRE(index_type == SCHWZ_INDEX_I32 || index_type == SCHWZ_INDEX_I64, "unknown index type");
+    if (n == 0) return SCHWZ_OK;
+    SCHWZ_REQUIRE(d_idx && d_from && d_into, "schwz_gather_typed / schwz_scatter_typed: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const bool wide = index_type == SCHWZ_INDEX_I64;
+    switch (value_type) {
+    case SCHWZ_VALUE_F32:
+        return wide ? launch_gs_typed<float, int64_t>(scatter, n, d_idx, d_from, d_into, op, st)
+                    : launch_gs_typed<float, int32_t>(scatter, n, d_idx, d_from, d_into, op, st);
+    case SCHWZ_VALUE_F64:
+        return wide ? launch_gs_typed<double, int64_t>(scatter, n, d_idx, d_from, d_into, op, st)
+                    : launch_gs_typed<double, int32_t>(scatter, n, d_idx, d_from, d_into, op, st);
+    case SCHWZ_VALUE_I32:
+        return wide ? launch_gs_typed<int32_t, int64_t>(scatter, n, d_idx, d_from, d_into, op, st)
+                    : launch_gs_typed<int32_t, int32_t>(scatter, n, d_idx, d_from, d_into, op, st);
+    case SCHWZ_VALUE_I64:
+        return wide ? launch_gs_typed<int64_t, int64_t>(scatter, n, d_idx, d_from, d_into, op, st)
+                    : launch_gs_typed<int64_t, int32_t>(scatter, n, d_idx, d_from, d_into, op, st);
+    default: set_error("schwz_gather_typed / schwz_scatter_typed: unknown value type"); return SCHWZ_ERR_INVALID;
+    }
+}
+
+int schwz_gather_typed(int64_t n, const void *d_idx, int index_type, const void *d_from, void *d_into, int value_type,
+                       int op, schwz_stream stream)
+{
+    return gs_typed(false, n, d_idx, index_type, d_from, d_into, value_type, op, stream);
+}
+
+int schwz_scatter_typed(int64_t n, const void *d_idx, int index_type, const void *d_from, void *d_into, int value_type,
+                        int op, schwz_stream stream)
+{
+    return gs_typed(true, n, d_idx, index_type, d_from, d_into, value_type, op, stream);
+}
 
 // ---- CSR --------------------------------------------------------------------
 

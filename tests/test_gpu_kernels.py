@@ -866,3 +866,46 @@ def test_canonical_stencil_layout_variants(schwz, oracle, torch_cuda, monkeypatc
     assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
     ex_x, it_o, rn_o = oracle.pcg(rp, col, val, outs[0][2], None, 1, 0.0, 12)
     assert np.abs(outs[0][0] - ex_x).max() <= RTOL_CG * np.abs(ex_x).max()
+
+
+@pytest.mark.parametrize("vt", ["float32", "float64", "int32", "int64"])
+@pytest.mark.parametrize("it", ["int32", "int64"])
+def test_gather_scatter_every_reference_instantiation(schwz, torch_cuda, vt, it):
+    """Gather / Scatter for the eight (value, index) type pairs the reference instantiates
+    (gather_kernel.cu:112-146, scatter_kernel.cu:109-142) and its four ops, against numpy with the
+    same element type (bit exact: one operation per element, integer avg = integer division)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(7)
+    n, m = 5000, 7000
+    vcode = {"float32": 0, "float64": 1, "int32": 2, "int64": 3}[vt]
+    icode = {"int32": 0, "int64": 1}[it]
+    idx = rng.permutation(m)[:n].astype(it)          # distinct targets: the scatter has no collisions
+    src_g = (rng.standard_normal(m) * 100).astype(vt)
+    src_s = (rng.standard_normal(n) * 100).astype(vt)
+    d_idx = torch.from_numpy(idx).cuda()
+    for op in (schwz.capi.OP_COPY, schwz.capi.OP_ADD, schwz.capi.OP_DIFF, schwz.capi.OP_AVG):
+        def ref(into, frm):
+            if op == schwz.capi.OP_COPY:
+                return frm.copy()
+            if op == schwz.capi.OP_ADD:
+                return frm + into
+            if op == schwz.capi.OP_DIFF:
+                return frm - into
+            s = frm + into
+            if vt.startswith("float"):
+                return (s / np.array(2, dtype=vt)).astype(vt)
+            return (np.sign(s) * (np.abs(s) // 2)).astype(vt)  # C++ integer division truncates toward zero
+        into0 = (rng.standard_normal(n) * 10).astype(vt)
+        d_from, d_into = torch.from_numpy(src_g).cuda(), torch.from_numpy(into0.copy()).cuda()
+        schwz.capi.check(schwz.capi.lib.schwz_gather_typed(n, d_idx.data_ptr(), icode, d_from.data_ptr(),
+                                                           d_into.data_ptr(), vcode, op, None))
+        torch.cuda.synchronize()
+        assert np.array_equal(d_into.cpu().numpy(), ref(into0, src_g[idx]))
+        big0 = (rng.standard_normal(m) * 10).astype(vt)
+        d_from, d_big = torch.from_numpy(src_s).cuda(), torch.from_numpy(big0.copy()).cuda()
+        schwz.capi.check(schwz.capi.lib.schwz_scatter_typed(n, d_idx.data_ptr(), icode, d_from.data_ptr(),
+                                                            d_big.data_ptr(), vcode, op, None))
+        torch.cuda.synchronize()
+        exp = big0.copy()
+        exp[idx] = ref(big0[idx], src_s)
+        assert np.array_equal(d_big.cpu().numpy(), exp)
