@@ -150,6 +150,8 @@ def lib():
     L.schwz_or_pcg_ex.argtypes = [i64, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_double, C.c_int, vp]
     L.schwz_or_gmres.restype = C.c_int
     L.schwz_or_gmres.argtypes = [i64, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp]
+    L.schwz_or_jacobi_blocks.argtypes = [i64, vp, vp, C.c_int, vp]
+    L.schwz_or_jacobi_blocks.restype = i64
     L.schwz_or_ilu0.argtypes = [i64, vp, vp, vp] + [C.POINTER(vp)] * 6
     L.schwz_or_isai.argtypes = [i64, vp, vp, vp, C.c_int, C.POINTER(vp)]
     L.schwz_or_isai.restype = None
@@ -433,6 +435,15 @@ def scatter(idx, src, into, op=OP_COPY):
     idx = np.ascontiguousarray(idx, dtype=IDX)
     lib().schwz_or_scatter(len(idx), _p(idx), _p(src), _p(into), op)
     return into
+
+
+def jacobi_blocks(rp, col, max_block_size):
+    """Block boundaries of the block-Jacobi preconditioner (Ginkgo's supervariable agglomeration)."""
+    n = len(rp) - 1
+    ptr = np.zeros(n + 2, dtype=np.int64)
+    nb = lib().schwz_or_jacobi_blocks(n, _p(np.ascontiguousarray(rp, dtype=IDX)),
+                                      _p(np.ascontiguousarray(col, dtype=IDX)), int(max_block_size), _p(ptr))
+    return ptr[:nb + 1].copy()
 
 
 def precond_code(local_precond, block_size=1):

@@ -560,8 +560,9 @@ typedef struct {
     int kind;         /* OR_PRECOND_* */
     int64_t n;
     double *dinv;     /* Jacobi */
-    int bs;           /* block-Jacobi: consecutive blocks of bs rows (the last may be shorter) */
-    double *binv;     /* [nblocks][bs][bs], identity padded */
+    int bs;           /* block-Jacobi: max_block_size */
+    int64_t nblocks, *bptr, *row_blk; /* detected blocks: boundaries, block of each row */
+    double *binv;     /* [nblocks][bs][bs]: the k x k inverse of a block in the top left corner */
     or_idx *l_rp, *l_col, *u_rp, *u_col; /* ILU(0): L unit lower with the 1 stored LAST in each */
     double *l_val, *u_val;               /* row, U upper with its diagonal FIRST */
     double *wl_val, *wu_val; /* ISAI: approximate inverses of L and U on the patterns of L and U */
@@ -603,30 +604,81 @@ static void invert_block(int bs, double *a, double *inv)
     }
 }
 
-/* Block-Jacobi (gko::preconditioner::Jacobi with max_block_size bs, solve.cpp:490-505,
- * 575-589).  Ginkgo finds blocks by supervariable agglomeration; for matrices whose rows all
- * have distinct column patterns (every stencil) that is consecutive rows, which is what is
- * restated here for every matrix -- block detection "parity unpinned". */
+/* Block detection of gko::preconditioner::Jacobi when no block pointers are given (solve.cpp:490-505
+ * passes max_block_size only).  Ginkgo is absent from the reference tree; its published algorithm
+ * (ginkgo-project/ginkgo, reference/preconditioner/jacobi_kernels.cpp, find_blocks =
+ * find_natural_blocks + agglomerate_supervariables) is restated:
+ *   natural blocks: maximal runs of CONSECUTIVE rows with the same column pattern (supervariables),
+ *     cut at max_block_size rows;
+ *   agglomeration: neighbouring natural blocks are merged greedily, left to right, while the merged
+ *     block stays within max_block_size rows.
+ * A matrix whose consecutive rows all differ in pattern (every stencil) therefore gets consecutive
+ * blocks of exactly max_block_size rows (the last one shorter).  ptr receives nb + 1 block boundaries;
+ * returns nb.  "parity unpinned": no reference fixture holds block pointers. */
+static int64_t detect_jacobi_blocks(int64_t n, const or_idx *rp, const or_idx *col, int max_bs, int64_t *ptr)
+{
+    ptr[0] = 0;
+    if (n == 0) return 0;
+    int64_t nb = 1, cur = 1;
+    for (int64_t i = 0; i + 1 < n; ++i) {
+        const or_idx la = rp[i + 1] - rp[i], lb = rp[i + 2] - rp[i + 1];
+        int same = la == lb;
+        for (or_idx k = 0; same && k < la; ++k) same = col[rp[i] + k] == col[rp[i + 1] + k];
+        if (cur < max_bs && same) {
+            ++cur;
+        } else {
+            ptr[nb] = ptr[nb - 1] + cur;
+            ++nb;
+            cur = 1;
+        }
+    }
+    ptr[nb] = ptr[nb - 1] + cur;
+    /* agglomerate_supervariables */
+    const int64_t natural = nb;
+    nb = 1;
+    cur = ptr[1] - ptr[0];
+    for (int64_t i = 1; i < natural; ++i) {
+        const int64_t size = ptr[i + 1] - ptr[i];
+        if (cur + size <= max_bs) {
+            cur += size;
+        } else {
+            ptr[nb] = ptr[nb - 1] + cur;
+            ++nb;
+            cur = size;
+        }
+    }
+    ptr[nb] = ptr[nb - 1] + cur;
+    return nb;
+}
+
+/* Block-Jacobi (gko::preconditioner::Jacobi with max_block_size bs, solve.cpp:490-505, 575-589):
+ * the diagonal blocks found above, inverted (Gauss-Jordan with partial pivoting), applied as z = inv r. */
 static void build_block_jacobi(or_precond *M, const or_idx *rp, const or_idx *col, const double *val)
 {
     const int bs = M->bs;
-    const int64_t n = M->n, nb = (n + bs - 1) / bs;
-    M->binv = (double *)xcalloc((size_t)nb * bs * bs, sizeof(double));
+    const int64_t n = M->n;
+    M->bptr = (int64_t *)xmalloc(sizeof(int64_t) * (size_t)(n + 2));
+    const int64_t nb = detect_jacobi_blocks(n, rp, col, bs, M->bptr);
+    M->nblocks = nb;
+    M->row_blk = (int64_t *)xmalloc(sizeof(int64_t) * (size_t)(n ? n : 1));
+    M->binv = (double *)xcalloc((size_t)(nb ? nb : 1) * bs * bs, sizeof(double));
     double *blk = (double *)xmalloc(sizeof(double) * (size_t)bs * bs);
+    double *inv = (double *)xmalloc(sizeof(double) * (size_t)bs * bs);
     for (int64_t b = 0; b < nb; ++b) {
-        const int64_t r0 = b * bs;
-        for (int i = 0; i < bs * bs; ++i) blk[i] = 0.0;
-        for (int i = 0; i < bs; ++i) {
-            if (r0 + i >= n) {
-                blk[i * bs + i] = 1.0;
-                continue;
-            }
+        const int64_t r0 = M->bptr[b];
+        const int k = (int)(M->bptr[b + 1] - r0);
+        for (int i = 0; i < k * k; ++i) blk[i] = 0.0;
+        for (int i = 0; i < k; ++i) {
+            M->row_blk[r0 + i] = b;
             for (or_idx j = rp[r0 + i]; j < rp[r0 + i + 1]; ++j)
-                if (col[j] >= r0 && col[j] < r0 + bs) blk[i * bs + (col[j] - r0)] = val[j];
+                if (col[j] >= r0 && col[j] < r0 + k) blk[i * k + (col[j] - r0)] = val[j];
         }
-        invert_block(bs, blk, M->binv + (size_t)b * bs * bs);
+        invert_block(k, blk, inv);
+        for (int i = 0; i < k; ++i)
+            for (int j = 0; j < k; ++j) M->binv[((size_t)b * bs + (size_t)i) * bs + j] = inv[i * k + j];
     }
     free(blk);
+    free(inv);
 }
 
 /* ILU(0) on the pattern of A (columns sorted), IKJ order.  gko::factorization::ParIlu
@@ -767,6 +819,8 @@ static void precond_free(or_precond *M)
     if (!M) return;
     free(M->dinv);
     free(M->binv);
+    free(M->bptr);
+    free(M->row_blk);
     free(M->l_rp);
     free(M->l_col);
     free(M->l_val);
@@ -790,10 +844,11 @@ static void precond_apply(const or_precond *M, const double *r, double *z)
         const int bs = M->bs;
 #pragma omp parallel for schedule(static) if (n > OMP_MIN_N)
         for (int64_t i = 0; i < n; ++i) {
-            const int64_t b = i / bs, r0 = b * bs;
+            const int64_t b = M->row_blk[i], r0 = M->bptr[b];
+            const int k = (int)(M->bptr[b + 1] - r0);
             const double *row = M->binv + ((size_t)b * bs + (size_t)(i - r0)) * bs;
             double s = 0.0;
-            for (int j = 0; j < bs && r0 + j < n; ++j) s += row[j] * r[r0 + j];
+            for (int j = 0; j < k; ++j) s += row[j] * r[r0 + j];
             z[i] = s;
         }
     } else if (M->kind == OR_PRECOND_ILU) {
@@ -980,6 +1035,13 @@ void schwz_or_isai(int64_t n, const or_idx *rp, const or_idx *col, const double 
 }
 
 /* ILU(0) factors for inspection by the tests (malloc'd; free with schwz_or_free) */
+/* block boundaries of the block-Jacobi preconditioner (detect_jacobi_blocks); ptr holds n + 1 entries,
+ * returns the number of blocks */
+int64_t schwz_or_jacobi_blocks(int64_t n, const or_idx *rp, const or_idx *col, int max_block_size, int64_t *ptr)
+{
+    return detect_jacobi_blocks(n, rp, col, max_block_size < 1 ? 1 : max_block_size, ptr);
+}
+
 void schwz_or_ilu0(int64_t n, const or_idx *rp, const or_idx *col, const double *val, or_idx **l_rp,
                    or_idx **l_col, double **l_val, or_idx **u_rp, or_idx **u_col, double **u_val)
 {

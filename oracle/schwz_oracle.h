@@ -211,6 +211,10 @@ int schwz_or_gmres(int64_t n, const or_idx *rp, const or_idx *col, const double 
                    double *final_resnorm);
 /* ISAI of a triangular factor on its own pattern (LowerIsai / UpperIsai, solve.cpp:616-638) */
 void schwz_or_isai(int64_t n, const or_idx *rp, const or_idx *col, const double *val, int lower, double **w_val);
+/* Block boundaries gko::preconditioner::Jacobi detects for max_block_size (source/solve.cpp:490-505):
+ * Ginkgo's published find_natural_blocks + agglomerate_supervariables.  ptr: n + 1 entries. */
+int64_t schwz_or_jacobi_blocks(int64_t n, const or_idx *rp, const or_idx *col, int max_block_size, int64_t *ptr);
+
 void schwz_or_ilu0(int64_t n, const or_idx *rp, const or_idx *col, const double *val, or_idx **l_rp,
                    or_idx **l_col, double **l_val, or_idx **u_rp, or_idx **u_col, double **u_val);
 /* sparse LL^T of A(perm,perm); outputs malloc'd CSR L and U=L^T; perm is

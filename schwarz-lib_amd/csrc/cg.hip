@@ -310,6 +310,29 @@ __global__ __launch_bounds__(kBlock) void block_jacobi_apply_kernel(int64_t n, i
     }
 }
 
+// the same for detected blocks of different sizes (supervariable agglomeration): block of the row, its
+// first row and size from blk_ptr
+__global__ __launch_bounds__(kBlock) void block_jacobi_var_apply_kernel(int64_t n, int bs,
+                                                                        const schwz_idx *__restrict__ row_blk,
+                                                                        const schwz_idx *__restrict__ blk_ptr,
+                                                                        const schwz_idx *__restrict__ blk_id,
+                                                                        const double *__restrict__ blk_inv,
+                                                                        const double *__restrict__ r,
+                                                                        double *__restrict__ z)
+{
+#pragma clang fp contract(off)
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const int b = row_blk[i];
+        const int64_t r0 = blk_ptr[b];
+        const int k = blk_ptr[b + 1] - blk_ptr[b];
+        const double *row = blk_inv + ((int64_t)blk_id[b] * bs + (i - r0)) * bs;
+        double s = 0.0;
+        for (int j = 0; j < k; ++j) s += row[j] * r[r0 + j];
+        z[i] = s;
+    }
+}
+
 // partial sums of r.z and r.r (banks 0 and 1), optionally p := z
 __global__ __launch_bounds__(kBlock) void dot_rz_kernel(int64_t n, const double *__restrict__ r,
                                                         const double *__restrict__ z, double *__restrict__ p_out,
@@ -448,73 +471,112 @@ static int pcg_setup_general(schwz_pcg *s)
         schwz_free(u_val);
         return rc;
     }
-    // block-Jacobi: consecutive blocks of bs rows, inverted by Gauss-Jordan with partial
-    // pivoting; identical inverse blocks are stored once (a stencil matrix has a handful)
+    // block-Jacobi.  Blocks as gko::preconditioner::Jacobi finds them when only max_block_size is given
+    // (solve.cpp:490-505; Ginkgo's published find_blocks = find_natural_blocks + agglomerate_supervariables,
+    // restated in oracle/schwz_oracle.c::detect_jacobi_blocks): maximal runs of consecutive rows with the
+    // same column pattern, cut at bs rows, then merged left to right while a merged block stays within bs
+    // rows.  Stencil matrices get consecutive blocks of exactly bs rows.  Every block is inverted by
+    // Gauss-Jordan with partial pivoting; identical inverse blocks are stored once.
     const int bs = s->block_size;
-    const int64_t nb = (n + bs - 1) / bs;
-    std::vector<schwz_idx> id((size_t)nb);
-    std::vector<double> uniq, blk((size_t)bs * bs), inv((size_t)bs * bs);
+    std::vector<schwz_idx> bptr;
+    bptr.push_back(0);
+    if (n > 0) {
+        std::vector<schwz_idx> nat;
+        nat.push_back(0);
+        schwz_idx cur = 1;
+        for (int64_t i = 0; i + 1 < n; ++i) {
+            const schwz_idx la = rp[(size_t)i + 1] - rp[(size_t)i], lb = rp[(size_t)i + 2] - rp[(size_t)i + 1];
+            bool same = la == lb;
+            for (schwz_idx k = 0; same && k < la; ++k) same = col[(size_t)(rp[(size_t)i] + k)] == col[(size_t)(rp[(size_t)i + 1] + k)];
+            if (cur < bs && same) {
+                ++cur;
+            } else {
+                nat.push_back(nat.back() + cur);
+                cur = 1;
+            }
+        }
+        nat.push_back(nat.back() + cur);
+        cur = nat[1] - nat[0];
+        for (size_t i = 1; i + 1 < nat.size(); ++i) {
+            const schwz_idx size = nat[i + 1] - nat[i];
+            if (cur + size <= bs) {
+                cur += size;
+            } else {
+                bptr.push_back(bptr.back() + cur);
+                cur = size;
+            }
+        }
+        bptr.push_back(bptr.back() + cur);
+    }
+    const int64_t nb = (int64_t)bptr.size() - 1;
+    bool uniform = true;
+    for (int64_t b = 0; b < nb && uniform; ++b) uniform = bptr[(size_t)b] == b * bs;
+    std::vector<schwz_idx> id((size_t)nb), row_blk;
+    if (!uniform) row_blk.resize((size_t)n);
+    std::vector<double> uniq, blk((size_t)bs * bs), inv((size_t)bs * bs), padded((size_t)bs * bs);
     std::unordered_multimap<uint64_t, schwz_idx> seen;
     for (int64_t b = 0; b < nb; ++b) {
-        const int64_t r0 = b * bs;
+        const int64_t r0 = bptr[(size_t)b];
+        const int k = (int)(bptr[(size_t)b + 1] - r0);
         std::fill(blk.begin(), blk.end(), 0.0);
-        for (int i = 0; i < bs; ++i) {
-            if (r0 + i >= n) {
-                blk[(size_t)i * bs + i] = 1.0;
-                continue;
-            }
+        for (int i = 0; i < k; ++i) {
+            if (!uniform) row_blk[(size_t)(r0 + i)] = (schwz_idx)b;
             for (schwz_idx j = rp[(size_t)(r0 + i)]; j < rp[(size_t)(r0 + i) + 1]; ++j)
-                if (col[(size_t)j] >= r0 && col[(size_t)j] < r0 + bs)
-                    blk[(size_t)i * bs + (col[(size_t)j] - r0)] = val[(size_t)j];
+                if (col[(size_t)j] >= r0 && col[(size_t)j] < r0 + k)
+                    blk[(size_t)i * k + (col[(size_t)j] - r0)] = val[(size_t)j];
         }
-        uint64_t h = 1469598103934665603ull;
-        for (double v : blk) {
-            uint64_t bits;
-            std::memcpy(&bits, &v, 8);
-            h = (h ^ bits) * 1099511628211ull;
-        }
-        // invert (the copy in blk is destroyed)
-        std::vector<double> a = blk;
-        for (int i = 0; i < bs; ++i)
-            for (int j = 0; j < bs; ++j) inv[(size_t)i * bs + j] = i == j ? 1.0 : 0.0;
-        for (int c = 0; c < bs; ++c) {
+        // invert the k x k block (the copy in blk is destroyed)
+        std::vector<double> &a = blk;
+        for (int i = 0; i < k; ++i)
+            for (int j = 0; j < k; ++j) inv[(size_t)i * k + j] = i == j ? 1.0 : 0.0;
+        for (int c = 0; c < k; ++c) {
             int piv = c;
-            for (int r = c + 1; r < bs; ++r)
-                if (std::fabs(a[(size_t)r * bs + c]) > std::fabs(a[(size_t)piv * bs + c])) piv = r;
-            if (a[(size_t)piv * bs + c] == 0.0) {
+            for (int r = c + 1; r < k; ++r)
+                if (std::fabs(a[(size_t)r * k + c]) > std::fabs(a[(size_t)piv * k + c])) piv = r;
+            if (a[(size_t)piv * k + c] == 0.0) {
                 set_error("block-Jacobi: singular diagonal block");
                 return SCHWZ_ERR_NOT_SPD;
             }
             if (piv != c)
-                for (int j = 0; j < bs; ++j) {
-                    std::swap(a[(size_t)c * bs + j], a[(size_t)piv * bs + j]);
-                    std::swap(inv[(size_t)c * bs + j], inv[(size_t)piv * bs + j]);
+                for (int j = 0; j < k; ++j) {
+                    std::swap(a[(size_t)c * k + j], a[(size_t)piv * k + j]);
+                    std::swap(inv[(size_t)c * k + j], inv[(size_t)piv * k + j]);
                 }
-            const double d = a[(size_t)c * bs + c];
-            for (int j = 0; j < bs; ++j) {
-                a[(size_t)c * bs + j] /= d;
-                inv[(size_t)c * bs + j] /= d;
+            const double d = a[(size_t)c * k + c];
+            for (int j = 0; j < k; ++j) {
+                a[(size_t)c * k + j] /= d;
+                inv[(size_t)c * k + j] /= d;
             }
-            for (int r = 0; r < bs; ++r) {
+            for (int r = 0; r < k; ++r) {
                 if (r == c) continue;
-                const double f = a[(size_t)r * bs + c];
+                const double f = a[(size_t)r * k + c];
                 if (f == 0.0) continue;
-                for (int j = 0; j < bs; ++j) {
-                    a[(size_t)r * bs + j] -= f * a[(size_t)c * bs + j];
-                    inv[(size_t)r * bs + j] -= f * inv[(size_t)c * bs + j];
+                for (int j = 0; j < k; ++j) {
+                    a[(size_t)r * k + j] -= f * a[(size_t)c * k + j];
+                    inv[(size_t)r * k + j] -= f * inv[(size_t)c * k + j];
                 }
             }
+        }
+        // stored in the top left corner of a bs x bs slot
+        std::fill(padded.begin(), padded.end(), 0.0);
+        for (int i = 0; i < k; ++i)
+            for (int j = 0; j < k; ++j) padded[(size_t)i * bs + j] = inv[(size_t)i * k + j];
+        uint64_t h = 1469598103934665603ull ^ (uint64_t)k;
+        for (double v : padded) {
+            uint64_t bits;
+            std::memcpy(&bits, &v, 8);
+            h = (h ^ bits) * 1099511628211ull;
         }
         schwz_idx found = -1;
         auto range = seen.equal_range(h);
         for (auto it = range.first; it != range.second; ++it)
-            if (std::memcmp(&uniq[(size_t)it->second * bs * bs], inv.data(), sizeof(double) * bs * bs) == 0) {
+            if (std::memcmp(&uniq[(size_t)it->second * bs * bs], padded.data(), sizeof(double) * bs * bs) == 0) {
                 found = it->second;
                 break;
             }
         if (found < 0) {
             found = (schwz_idx)(uniq.size() / ((size_t)bs * bs));
-            uniq.insert(uniq.end(), inv.begin(), inv.end());
+            uniq.insert(uniq.end(), padded.begin(), padded.end());
             seen.emplace(h, found);
         }
         id[(size_t)b] = found;
@@ -525,6 +587,12 @@ static int pcg_setup_general(schwz_pcg *s)
     s->d_blk_id = (schwz_idx *)d;
     if ((rc = upload(uniq.data(), uniq.size(), &d))) return rc;
     s->d_blk_inv = (double *)d;
+    if (!uniform) {
+        if ((rc = upload(row_blk.data(), row_blk.size(), &d))) return rc;
+        s->d_row_blk = (schwz_idx *)d;
+        if ((rc = upload(bptr.data(), bptr.size(), &d))) return rc;
+        s->d_blk_ptr = (schwz_idx *)d;
+    }
     return SCHWZ_OK;
 }
 
@@ -633,6 +701,8 @@ void schwz_pcg_destroy(schwz_pcg *s)
     (void)hipFree(s->z);
     (void)hipFree(s->d_blk_id);
     (void)hipFree(s->d_blk_inv);
+    (void)hipFree(s->d_row_blk);
+    (void)hipFree(s->d_blk_ptr);
     for (auto &g : s->graphs) (void)hipGraphExecDestroy(g.exec);
     if (s->capture_stream) (void)hipStreamDestroy(s->capture_stream);
     schwz_trs_destroy(s->ilu);
@@ -677,7 +747,10 @@ int precond_apply(schwz_pcg *s, const double *in, double *out, hipStream_t st)
         a.y = out;
         return launch_spmv(s->isai_u->v, kSpmvPlain, a, 0, st);
     }
-    if (s->precond == SCHWZ_PRECOND_BLOCK_JACOBI) {
+    if (s->precond == SCHWZ_PRECOND_BLOCK_JACOBI && s->d_row_blk) {
+        hipLaunchKernelGGL(block_jacobi_var_apply_kernel, dim3(grid_for(s->n)), dim3(kBlock), 0, st, s->n, s->block_size,
+                           s->d_row_blk, s->d_blk_ptr, s->d_blk_id, s->d_blk_inv, in, out);
+    } else if (s->precond == SCHWZ_PRECOND_BLOCK_JACOBI) {
         hipLaunchKernelGGL(block_jacobi_apply_kernel, dim3(grid_for(s->n)), dim3(kBlock), 0, st, s->n, s->block_size,
                            s->d_blk_id, s->d_blk_inv, in, out);
     } else if (s->precond == SCHWZ_PRECOND_JACOBI) {

@@ -276,7 +276,8 @@ struct schwz_pcg {
     double *z = nullptr;
     int block_size = 1;
     schwz_idx *d_blk_id = nullptr;  // block-Jacobi: index of each block's inverse
-    double *d_blk_inv = nullptr;    // unique inverse blocks, [nunique][bs][bs]
+    double *d_blk_inv = nullptr;    // unique inverse blocks, [nunique][bs][bs] (a k x k inverse in the top left corner)
+    schwz_idx *d_row_blk = nullptr, *d_blk_ptr = nullptr;  // detected blocks of different sizes: block of a row, boundaries
     schwz_trs *ilu = nullptr;       // ILU(0): level-scheduled L and U sweeps
     schwz_csr *isai_l = nullptr, *isai_u = nullptr;  // ISAI: approximate inverses of L and U
     double *isai_tmp = nullptr;

@@ -189,13 +189,25 @@ def test_direct_solve_matches_oracle(schwz, oracle, torch_cuda, case, natural):
 
 
 @pytest.mark.parametrize("pc", [(2, 2), (2, 7), (2, 16), (2, 32), (3, 1), (4, 1)])
-@pytest.mark.parametrize("case", ["lap2d", "lap3d", "ani3"])
+@pytest.mark.parametrize("case", ["lap2d", "lap3d", "ani3", "nodes3"])
 def test_pcg_block_jacobi_and_ilu_match_oracle(schwz, oracle, torch_cuda, case, pc):
-    """Block-Jacobi with consecutive blocks (gko preconditioner::Jacobi, solve.cpp:488-504) and
-    ILU(0) (solve.cpp:506-532) in the device-resident PCG against the oracle's recurrence."""
+    """Block-Jacobi (gko preconditioner::Jacobi, solve.cpp:488-504: blocks found by supervariable
+    agglomeration -- consecutive blocks on the stencil matrices, whole 3-unknown nodes per block,
+    i.e. blocks of different sizes, on `nodes3`) and ILU(0) (solve.cpp:506-532) in the device-resident
+    PCG against the oracle's recurrence."""
     torch = torch_cuda
     precond, bs = pc
-    if case == "lap2d":
+    if case == "nodes3":
+        import scipy.sparse as sp
+        t = sp.diags([-1.0, 2.5, -1.0], [-1, 0, 1], shape=(900, 900), format="csr")
+        blk = np.array([[2.0, 0.3, 0.1], [0.3, 1.5, 0.2], [0.1, 0.2, 1.8]])   # SPD: rows of a node share their pattern
+        a = sp.kron(t, blk, format="csr")
+        a.sort_indices()
+        rp, col, val = a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data.copy()
+        if precond == 2 and bs in (7, 16, 32):
+            ptr = oracle.jacobi_blocks(rp, col, bs)
+            assert set(np.diff(ptr)) <= {3 * (bs // 3), len(rp) - 1 - ptr[-2]} and (np.diff(ptr) % 3 == 0).all()
+    elif case == "lap2d":
         rp, col, val = oracle.laplacian2d(50)
     elif case == "lap3d":
         rp, col, val = oracle.laplacian3d(21, 19, 23)   # n = 9177 > 8192: multi-launch trs plan

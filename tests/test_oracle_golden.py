@@ -294,3 +294,30 @@ def test_gmres_preconditioners_and_iteration_cap(oracle, convdiff):
     assert it14 == 7 and np.linalg.norm(b - A @ x14) < np.linalg.norm(b - A @ x7)
     x0, it0, rn0 = oracle.gmres(rp, col, val, np.zeros(n), None, 0, 1e-8, 50, 5)
     assert it0 == 0 and rn0 == 0.0 and not x0.any()
+
+
+def test_block_jacobi_block_detection_follows_ginkgo(oracle):
+    """gko::preconditioner::Jacobi with only max_block_size given (solve.cpp:490-505) finds its blocks by
+    supervariable agglomeration: runs of consecutive rows with identical column patterns, cut at
+    max_block_size, merged left to right while the merged block fits.  Hand-derived known answers:
+    a stencil (no two neighbouring rows share a pattern) gets consecutive blocks of exactly
+    max_block_size rows; a matrix with 3 unknowns per node (identical patterns inside a node) gets
+    whole nodes per block -- 2 nodes = 6 rows at max_block_size 8, 5 nodes = 15 rows at 16, one node
+    at 4 or 3, single rows... never a split node unless the node itself exceeds the cap."""
+    import scipy.sparse as sp
+    rp, col, val = oracle.laplacian2d(7)
+    n = 49
+    for bs in (1, 4, 16):
+        ptr = oracle.jacobi_blocks(rp, col, bs)
+        assert np.array_equal(ptr, np.append(np.arange(0, n, bs), n))
+    t = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(10, 10), format="csr")
+    a = sp.kron(t, np.ones((3, 3)), format="csr")   # 10 nodes x 3 unknowns, rows of a node share their pattern
+    a.sort_indices()
+    arp, acol = a.indptr.astype(np.int32), a.indices.astype(np.int32)
+    assert np.array_equal(oracle.jacobi_blocks(arp, acol, 8), [0, 6, 12, 18, 24, 30])
+    assert np.array_equal(oracle.jacobi_blocks(arp, acol, 16), [0, 15, 30])
+    assert np.array_equal(oracle.jacobi_blocks(arp, acol, 4), np.arange(0, 31, 3))
+    assert np.array_equal(oracle.jacobi_blocks(arp, acol, 3), np.arange(0, 31, 3))
+    # a node larger than the cap is cut at the cap: natural blocks 2 + 1, merged again only if they fit
+    assert np.array_equal(oracle.jacobi_blocks(arp, acol, 2),
+                          np.sort(np.concatenate([np.arange(0, 31, 3), np.arange(2, 30, 3)])))
