@@ -671,17 +671,21 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
         // has just consumed; the halo of plane z + 1 (L2 hits) first thing in step z.
         pvd2 own_a[NH], own_b[NH], hreg[NHL];
         Ahead r_a[NH], r_b[NH];
-        load_own(z0 - 1, own_a);
-        store_own(z0 - 1, own_a);
-        load_own(z0, own_a);
-        store_own(z0, own_a);
-        load_halo(z0, hreg);
-        load_own(z0 + 1, own_b);
-        load_own(z0 + 2, own_a);
+        {
+            // everything the first two planes need is requested before anything is waited for
+            pvd2 first[NH], second[NH];
+            load_own(z0 - 1, first);
+            load_own(z0, second);
+            load_halo(z0, hreg);
+            load_own(z0 + 1, own_b);
+            load_own(z0 + 2, own_a);
 #pragma unroll
-        for (int h = 0; h < NH; ++h) {
-            r_a[h] = fetch(z0, h);
-            r_b[h] = fetch(z0 + 1 < z1 ? z0 + 1 : z0, h);
+            for (int h = 0; h < NH; ++h) {
+                r_a[h] = fetch(z0, h);
+                r_b[h] = fetch(z0 + 1 < z1 ? z0 + 1 : z0, h);
+            }
+            store_own(z0 - 1, first);
+            store_own(z0, second);
         }
         // one plane: `own_next` holds own(z + 1) on entry and own(z + 3) on exit, `rr` r(z) / r(z + 2)
         auto step = [&](int z, pvd2 (&own_next)[NH], Ahead (&rr)[NH]) {
@@ -864,11 +868,14 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
         Own own_a, own_b;
         Halo hreg;
         Rle rle_a[NH], rle_b[NH];
-        load_own(z0, own_a);
-        store_own(z0, own_a, true);
-        load_halo(z0, hreg);
-        load_own(z0 + 1, own_b);
-        load_own(z0 + 2, own_a);
+        {
+            Own first;
+            load_own(z0, first);
+            load_halo(z0, hreg);
+            load_own(z0 + 1, own_b);
+            load_own(z0 + 2, own_a);
+            store_own(z0, first, true);
+        }
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             rle_a[h] = fetch_rle(z0, h);
@@ -1474,7 +1481,9 @@ int build_spmv_pair(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, con
                         prop.multiProcessorCount > 0)
                         cus = prop.multiProcessorCount;
                 }
-                int L = l_env ? std::atoi(l_env) : (int)std::max<int64_t>(8, (steps + 3 * cus - 1) / (3 * cus));
+                // (bands of 1024 rows keep twice the loads in flight per workgroup: two segments per CU there)
+                const int per_cu = T == 1024 ? 2 : 3;
+                int L = l_env ? std::atoi(l_env) : (int)std::max<int64_t>(8, (steps + per_cu * cus - 1) / (per_cu * cus));
                 if (L < 2) L = 16;
                 // the segments and the workgroups of the generic walk must fit the launch grid
                 auto count = [&](int len) {
@@ -1488,7 +1497,10 @@ int build_spmv_pair(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, con
                 std::vector<schwz_idx> gen;
                 for (int c = 0; c < nchunks; ++c)
                     if (!covered[(size_t)c]) gen.push_back(c);
-                const int gen_blocks = (int)std::min<size_t>(gen.size(), 256);
+                // the companion launch walks its chunks with one gather round trip after the other: as many
+                // workgroups as the partial-sum slots next to the segments allow (up to one per chunk)
+                const int seg_slots = (int)((count(L) + kXcds - 1) / kXcds * kXcds) + kXcds;
+                const int gen_blocks = (int)std::min<int64_t>((int64_t)gen.size(), std::max(256, std::min(1024, grid - seg_slots)));
                 while (count(L) + kXcds > grid - gen_blocks && L < (1 << 20)) L += 4;
                 // deal: XCD x takes the bands [x * bands / 8, (x + 1) * bands / 8) (a band's window shares its
                 // NX-row halos with the neighbouring bands: the same L2), segment by segment of the z range
