@@ -117,6 +117,10 @@ int schwz_csr_symmetric(const schwz_csr *A);
  * swept through consecutive planes, operands from an LDS ring of plane windows; csrc/spmv_pair.hip):
  * the number of workgroup slots of that walk.  0: chunk-by-chunk gathers. */
 int schwz_csr_sweep_slots(const schwz_csr *A);
+/* chunks of 512 rows that walk leaves to a companion launch of the chunk-by-chunk kernel (rows whose
+ * couplings do not fit the plane chains: 0 for a grid in natural order and for the slabs of its z-slab
+ * partition, whose appended overlap planes are chained to the interior) */
+int schwz_csr_sweep_left_out(const schwz_csr *A);
 /* bytes of MATRIX data one SpMV pass reads in the coding `variant` launches (0: the coding the upload
  * chose, schwz_csr_format; anything else: plain CSR = 12 nnz + 4 (rows + 1), the figure of SURVEY 8(d)).
  * bench.py prices its roofline fraction on these bytes (+ the vector bytes of the launch). */

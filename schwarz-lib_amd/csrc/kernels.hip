@@ -544,6 +544,9 @@ int schwz_csr_symmetric(const schwz_csr *A) { return A && A->v.pair_id && A->v.p
 // workgroup slots of the z-sweep walk the upload prepared (0: the matrix is walked chunk by chunk)
 int schwz_csr_sweep_slots(const schwz_csr *A) { return A ? A->v.sweep_nslots : 0; }
 
+// chunks of 512 rows the z-sweep walk leaves to its companion launch (0: it covers the whole matrix)
+int schwz_csr_sweep_left_out(const schwz_csr *A) { return A ? A->v.sweep_ngen : 0; }
+
 // Bytes of matrix data one pass of the default (variant 0) SpMV launch has to read in the coding the
 // upload chose: what "algorithmic bytes of the launched format" means in bench.py's roofline.
 int64_t schwz_csr_matrix_bytes(const schwz_csr *A, int variant)

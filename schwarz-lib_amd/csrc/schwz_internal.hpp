@@ -109,14 +109,19 @@ struct CsrView {
     int64_t sweep_pl = 0;
     const int4 *sweep_seg = nullptr;
     const schwz_idx *sweep_gen = nullptr;
-    // per pattern of table 0: its entries expanded to the 7 slots of pair_canon (8 PairVal, slot 7 unused)
-    // and the presence mask (bit k: row r has slot k, bit 8 + k: row r + 1), as stage_table derives them
+    // per pattern of table 0: its entries in the nine slots [far before 0, far before 1, -NX, -1, 0, +1, +NX,
+    // far after 0, far after 1] (9 PairVal) and the presence mask (bit k: row r has slot k, bit 16 + k: row r + 1)
     const double *canon_val = nullptr;
     const int *canon_mask = nullptr;
     int canon_npat = 0;
-    // the same for the upper-triangle twin of the table (symmetric matrices): slots {0, +1, +NX, +PL}, 4 PairVal
+    // the same for the upper-triangle twin of the table (symmetric matrices): slots [0, +1, +NX, far after 0,
+    // far after 1], 5 PairVal
     const double *canon_sym_val = nullptr;
     const int *canon_sym_mask = nullptr;
+    // chains of planes (see build_sweep): plane index per chain position (-1: none) and, per position, which
+    // window each far slot reads (2 bits per slot B0, B1, A0, A1: 0 none, 1 previous position, 2 next)
+    const int *chain_plane = nullptr;
+    const int *chain_far = nullptr;
 };
 
 // epilogues of the tiled SpMV kernel
@@ -255,7 +260,7 @@ struct schwz_csr {
          *d_tbl_delta = nullptr;
     void *d_pair_rle = nullptr;
     void *d_sweep_seg = nullptr, *d_sweep_gen = nullptr, *d_canon_val = nullptr, *d_canon_mask = nullptr,
-         *d_canon_sym_val = nullptr, *d_canon_sym_mask = nullptr;
+         *d_canon_sym_val = nullptr, *d_canon_sym_mask = nullptr, *d_chain_plane = nullptr, *d_chain_far = nullptr;
     void *d_pair_id = nullptr, *d_tile_ptable = nullptr, *d_ptbl_desc = nullptr, *d_ptbl_len = nullptr,
          *d_ptbl_val = nullptr, *d_ptbl_meta = nullptr, *d_chunk_dual = nullptr;
     void *d_tile_dual = nullptr;

@@ -588,22 +588,22 @@ template <int NHL, int NH, bool DIAGVEC>
 __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, SpmvArgs a)
 {
 #pragma clang fp contract(off)
-    // dynamic LDS: own parts of four planes [4][T], the +-NX halos of two planes [2][2 NX] (only the plane
-    // being computed needs its halo, which is why it is requested one plane ahead, not two: its lines are
-    // the own lines of the neighbouring bands, i.e. L2 hits), the canonical tables of the matrix
+    // dynamic LDS: own parts of four chain positions [4][T], the +-NX halos of two [2][2 NX] (only the plane
+    // being computed needs its halo, which is why it is requested one position ahead, not two: its lines are
+    // the own lines of the neighbouring bands, i.e. L2 hits), the slot tables of the matrix
     extern __shared__ __attribute__((aligned(16))) char sweep_lds[];
     constexpr int T = NH * kPairRows;
     const int NX = A.sweep_nx;
     double *const own_ring = reinterpret_cast<double *>(sweep_lds);
     double *const halo_ring = own_ring + 4 * T;
     PairVal *const cpv = reinterpret_cast<PairVal *>(halo_ring + 4 * NX);
-    int *const cmask = reinterpret_cast<int *>(cpv + A.canon_npat * 8);
+    int *const cmask = reinterpret_cast<int *>(cpv + A.canon_npat * 9);
     __shared__ double red[4];
     if (a.it >= a.cg_state->stop_iter) return;
     const double cg_alpha = a.cg_state->rho[a.it & 1] / fold_partials(a.pq_partials, a.pq_nparts, red);
     const int tid = threadIdx.x;
     if (blockIdx.x == 0 && tid == 0 && a.alpha_out) *a.alpha_out = cg_alpha;
-    for (int i = tid; i < A.canon_npat * 8; i += kBlock) cpv[i] = PairVal{A.canon_val[2 * i], A.canon_val[2 * i + 1]};
+    for (int i = tid; i < A.canon_npat * 9; i += kBlock) cpv[i] = PairVal{A.canon_val[2 * i], A.canon_val[2 * i + 1]};
     if (tid < A.canon_npat) cmask[tid] = A.canon_mask[tid];
     // partial-sum slots no workgroup of this launch or of its companion writes
     if (blockIdx.x == 0)
@@ -612,27 +612,35 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
     lds_barrier();
     const int4 sg = A.sweep_seg[blockIdx.x];
     const int64_t PL = A.sweep_pl;
-    const int band = sg.x, z0 = sg.y, z1 = sg.z;
+    const int band = sg.x, z0 = sg.y, z1 = sg.z;  // chain positions z0 <= z < z1
     const int64_t gmax = A.ncols - 2;
     double acc0 = 0.0, acc1 = 0.0;
     typedef const unsigned __attribute__((address_space(4))) *const_words;
+    typedef const int __attribute__((address_space(4))) *const_ints;
     if (z0 < z1) {
-        // Pieces beyond the vector's ends (first / last plane, first / last band) are clamped to a valid
-        // address: no row has an entry there, the masks drop what they deliver.
+        // first row of the band at a chain position (scalar loads: the position is workgroup-uniform); a
+        // position without a plane (the ends of a chain) reads plane 0 -- valid memory no mask lets through
+        const const_ints chain = (const_ints)(uintptr_t)A.chain_plane;
+        const const_ints chain_far = (const_ints)(uintptr_t)A.chain_far;
+        auto band_row = [&](int z) -> int64_t {
+            const int k = chain[z];
+            return (int64_t)(k < 0 ? 0 : k) * PL + (int64_t)band * T;
+        };
+        // Pieces beyond the vector's ends (first / last band of a plane) are clamped to a valid address: no
+        // row has an entry there, the masks drop what they deliver.
         auto clampg = [&](int64_t g) -> int64_t { return g < 0 ? 0 : (g > gmax ? gmax : g); };
-        auto load_own = [&](int z, pvd2 (&reg)[NH]) {
-            const int64_t base = (int64_t)z * PL + (int64_t)band * T;
+        auto load_own = [&](int64_t base, pvd2 (&reg)[NH]) {
 #pragma unroll
             for (int k = 0; k < NH; ++k) __builtin_memcpy(&reg[k], a.x + clampg(base + 2 * (tid + k * kBlock)), 16);
         };
         auto store_own = [&](int z, const pvd2 (&reg)[NH]) {
-            double *slot_p = own_ring + (size_t)((z + 4) & 3) * T;
+            double *slot_p = own_ring + (size_t)(z & 3) * T;
 #pragma unroll
             for (int k = 0; k < NH; ++k) *reinterpret_cast<pvd2 *>(slot_p + 2 * (tid + k * kBlock)) = reg[k];
         };
-        // halo of plane z: the NX rows below the band (pieces 0 .. NX/2) and the NX rows above it
-        auto load_halo = [&](int z, pvd2 (&reg)[NHL]) {
-            const int64_t lo = (int64_t)z * PL + (int64_t)band * T - NX, up = lo + NX + T;
+        // halo of a plane: the NX rows below the band (pieces 0 .. NX/2) and the NX rows above it
+        auto load_halo = [&](int64_t base, pvd2 (&reg)[NHL]) {
+            const int64_t lo = base - NX, up = base + T;
 #pragma unroll
             for (int k = 0; k < NHL; ++k) {
                 const int pc = min(tid + k * kBlock, NX - 1);  // NX pieces: NX/2 below, NX/2 above
@@ -652,9 +660,9 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
             pvd2 r, d;
             unsigned w0, w1, w2, w3;
         };
-        auto fetch = [&](int z, int h) -> Ahead {
+        auto fetch = [&](int64_t base, int h) -> Ahead {
             Ahead f;
-            const int64_t row0 = (int64_t)z * PL + (int64_t)band * T + h * kPairRows;
+            const int64_t row0 = base + h * kPairRows;
             const int ra = (int)row0 + 2 * tid;
             const const_words q = (const_words)(uintptr_t)(A.pair_rle + (row0 / kPairRows));
             f.w0 = q[0];
@@ -666,44 +674,55 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
             return f;
         };
         // Software pipeline, two steps deep, without register copies (the loop is unrolled by two and the
-        // register sets alternate): own(z + 3) is requested while plane z is computed, into the set whose
+        // register sets alternate): own(z + 3) is requested while position z is computed, into the set whose
         // content -- own(z + 1) -- has just gone to LDS; r(z + 2) at the end of step z, into the set step z
-        // has just consumed; the halo of plane z + 1 (L2 hits) first thing in step z.
+        // has just consumed; the halo of position z + 1 (L2 hits) first thing in step z.  The band's first
+        // rows at the positions z - 1 .. z + 3 travel in scalar registers (brow), one new one per step.
         pvd2 own_a[NH], own_b[NH], hreg[NHL];
         Ahead r_a[NH], r_b[NH];
+        int64_t brow[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) brow[k] = band_row(z0 - 1 + k);
         {
-            // everything the first two planes need is requested before anything is waited for
+            // everything the first two positions need is requested before anything is waited for
             pvd2 first[NH], second[NH];
-            load_own(z0 - 1, first);
-            load_own(z0, second);
-            load_halo(z0, hreg);
-            load_own(z0 + 1, own_b);
-            load_own(z0 + 2, own_a);
+            load_own(brow[0], first);
+            load_own(brow[1], second);
+            load_halo(brow[1], hreg);
+            load_own(brow[2], own_b);
+            load_own(brow[3], own_a);
 #pragma unroll
             for (int h = 0; h < NH; ++h) {
-                r_a[h] = fetch(z0, h);
-                r_b[h] = fetch(z0 + 1 < z1 ? z0 + 1 : z0, h);
+                r_a[h] = fetch(brow[1], h);
+                r_b[h] = fetch(z0 + 1 < z1 ? brow[2] : brow[1], h);
             }
             store_own(z0 - 1, first);
             store_own(z0, second);
         }
-        // one plane: `own_next` holds own(z + 1) on entry and own(z + 3) on exit, `rr` r(z) / r(z + 2)
+        // one position: `own_next` holds own(z + 1) on entry and own(z + 3) on exit, `rr` r(z) / r(z + 2)
         auto step = [&](int z, pvd2 (&own_next)[NH], Ahead (&rr)[NH]) {
+            // brow[] = first rows at z - 1, z, z + 1, z + 2, z + 3
             store_own(z + 1, own_next);
             store_halo(z, hreg);
             lds_barrier();
-            load_halo(z + 1, hreg);
-            load_own(z + 3, own_next);
-            const double *cur = own_ring + (size_t)((z + 4) & 3) * T;
+            load_halo(brow[2], hreg);
+            load_own(brow[4], own_next);
+            const int far = chain_far[z];
+            const double *cur = own_ring + (size_t)(z & 3) * T;
             const double *prv = own_ring + (size_t)((z + 3) & 3) * T;
-            const double *nxt = own_ring + (size_t)((z + 5) & 3) * T;
+            const double *nxt = own_ring + (size_t)((z + 1) & 3) * T;
             const double *hlo = halo_ring + (size_t)(z & 1) * 2 * NX, *hup = hlo + NX;
-            const int zn = z + 2 < z1 ? z + 2 : z1 - 1;  // past the segment: a valid plane, never used
+            // window each far slot reads (slots of a plane without that coupling read `cur`: masked anyway)
+            const double *fb0 = (far & 3) == 1 ? prv : ((far & 3) == 2 ? nxt : cur);
+            const double *fb1 = ((far >> 2) & 3) == 1 ? prv : (((far >> 2) & 3) == 2 ? nxt : cur);
+            const double *fa0 = ((far >> 4) & 3) == 1 ? prv : (((far >> 4) & 3) == 2 ? nxt : cur);
+            const double *fa1 = ((far >> 6) & 3) == 1 ? prv : (((far >> 6) & 3) == 2 ? nxt : cur);
+            const int64_t rbase = z + 2 < z1 ? brow[3] : brow[1];  // past the segment: a valid plane, never used
 #pragma unroll
             for (int h = 0; h < NH; ++h) {
                 const Ahead f = rr[h];
                 const int i0 = h * kPairRows + 2 * tid;  // position inside the band
-                const int ra = (int)((int64_t)z * PL + (int64_t)band * T) + i0;
+                const int ra = (int)brow[1] + i0;
                 // the id of the last run that starts at or before this lane's pair
                 const unsigned w[4] = {f.w0, f.w1, f.w2, f.w3};
                 int pid = (int)((w[0] >> 8) & 0xffu);
@@ -713,25 +732,27 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
                     if ((unsigned)tid >= (e & 0xffu)) pid = (int)(e >> 8);
                 }
                 const int mask = cmask[pid];
-                pvd2 t[7];
-                t[3] = *reinterpret_cast<const pvd2 *>(cur + i0);
-                t[2].x = i0 > 0 ? cur[i0 - 1] : hlo[NX - 1];
-                t[2].y = t[3].x;
-                t[4].x = t[3].y;
-                t[4].y = i0 + 2 < T ? cur[i0 + 2] : hup[0];
-                t[1] = *reinterpret_cast<const pvd2 *>(i0 >= NX ? cur + (i0 - NX) : hlo + i0);
-                t[5] = *reinterpret_cast<const pvd2 *>(i0 + NX < T ? cur + (i0 + NX) : hup + (i0 + NX - T));
-                t[0] = *reinterpret_cast<const pvd2 *>(prv + i0);
-                t[6] = *reinterpret_cast<const pvd2 *>(nxt + i0);
+                pvd2 t[9];
+                t[4] = *reinterpret_cast<const pvd2 *>(cur + i0);
+                t[3].x = i0 > 0 ? cur[i0 - 1] : hlo[NX - 1];
+                t[3].y = t[4].x;
+                t[5].x = t[4].y;
+                t[5].y = i0 + 2 < T ? cur[i0 + 2] : hup[0];
+                t[2] = *reinterpret_cast<const pvd2 *>(i0 >= NX ? cur + (i0 - NX) : hlo + i0);
+                t[6] = *reinterpret_cast<const pvd2 *>(i0 + NX < T ? cur + (i0 + NX) : hup + (i0 + NX - T));
+                t[0] = *reinterpret_cast<const pvd2 *>(fb0 + i0);
+                t[1] = *reinterpret_cast<const pvd2 *>(fb1 + i0);
+                t[7] = *reinterpret_cast<const pvd2 *>(fa0 + i0);
+                t[8] = *reinterpret_cast<const pvd2 *>(fa1 + i0);
                 // masked sums without branches: an absent entry adds +0.0, which leaves a sum that began
                 // at +0.0 unchanged bit for bit (such a sum is never -0.0)
                 double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-                for (int k = 0; k < 7; ++k) {
-                    const PairVal v = cpv[pid * 8 + k];
+                for (int k = 0; k < 9; ++k) {
+                    const PairVal v = cpv[pid * 9 + k];
                     const double p0 = v.a * t[k].x, p1 = v.b * t[k].y;
                     s0 += ((mask >> k) & 1) ? p0 : 0.0;
-                    s1 += ((mask >> (kPairChunk + k)) & 1) ? p1 : 0.0;
+                    s1 += ((mask >> (16 + k)) & 1) ? p1 : 0.0;
                 }
                 // r -= alpha q ; z = D^-1 r ; partial r.z and r.r  (kSpmvCgUpdate's epilogue, x deferred)
                 const double r0 = f.r.x - cg_alpha * s0;
@@ -744,8 +765,11 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
                 acc1 += r1 * r1;
                 const pvd2 rn = {r0, r1};
                 __builtin_nontemporal_store(rn, reinterpret_cast<pvd2 *>(a.cg_r + ra));
-                rr[h] = fetch(zn, h);
+                rr[h] = fetch(rbase, h);
             }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) brow[k] = brow[k + 1];
+            brow[4] = band_row(z + 4);
         };
         int z = z0;
         for (; z + 1 < z1; z += 2) {
@@ -766,12 +790,11 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
 // The same walk for the fused direction update + p.(A p) launch of symmetric matrices (kSpmvDirDotSym):
 // beta from the folded partials, p' = z + beta p (z = D^-1 r, uniform or no Jacobi scaling) computed ONCE
 // per element from coalesced loads of r and p -- into the LDS ring, and into the output buffer for the
-// planes of the segment -- and the upper-triangle sum p'.(A p') = sum_i p'_i (a_ii p'_i + 2 sum_{j>i}
-// a_ij p'_j) read from LDS: own and +1 from the band's plane, +NX from it or its upper halo, +PL from the
-// next plane.  The chunk-by-chunk form of this launch gathers r AND p at every entry; here every
-// element of r and p is loaded once (plus the NX-row halo, L2 hits).  Same expression for p' everywhere,
-// same products in the same order: the same bits per row.  Workgroup 0 advances CgState like
-// cg_direction_kernel.  NHL / NH as above.
+// positions of the segment -- and the upper-triangle sum p'.(A p') = sum_i p'_i (a_ii p'_i + 2 sum_{j>i}
+// a_ij p'_j) read from LDS: slots [0, +1, +NX, far after 0, far after 1].  The chunk-by-chunk form of this
+// launch gathers r AND p at every entry; here every element of r and p is loaded once (plus the NX-row
+// halo, L2 hits).  Same expression for p' everywhere, same products in the same order: the same bits per
+// row.  Workgroup 0 advances CgState like cg_direction_kernel.  NHL / NH as above.
 // ---------------------------------------------------------------------------------------------------
 template <int NHL, int NH>
 __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView A, SpmvArgs a)
@@ -780,17 +803,17 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
     extern __shared__ __attribute__((aligned(16))) char sweep_lds[];
     constexpr int T = NH * kPairRows;
     const int NX = A.sweep_nx;
-    double *const own_ring = reinterpret_cast<double *>(sweep_lds);  // p' of three planes [3][T]
-    double *const halo_ring = own_ring + 3 * T;                       // p' of the NX rows above the band [2][NX]
+    double *const own_ring = reinterpret_cast<double *>(sweep_lds);  // p' of four chain positions [4][T]
+    double *const halo_ring = own_ring + 4 * T;                       // p' of the NX rows above the band [2][NX]
     PairVal *const cpv = reinterpret_cast<PairVal *>(halo_ring + 2 * NX);
-    int *const cmask = reinterpret_cast<int *>(cpv + A.canon_npat * 4);
+    int *const cmask = reinterpret_cast<int *>(cpv + A.canon_npat * 5);
     __shared__ double red[4];
     if (a.it >= a.cg_state->stop_iter) return;
     const double cg_rho_new = fold_partials(a.pq_partials, a.pq_nparts, red);
     const double cg_rr = fold_partials(a.pq_partials + a.pq_nparts, a.pq_nparts, red);
     const double cg_beta = cg_rho_new / a.cg_state->rho[a.it & 1];
     const int tid = threadIdx.x;
-    for (int i = tid; i < A.canon_npat * 4; i += kBlock) cpv[i] = PairVal{A.canon_sym_val[2 * i], A.canon_sym_val[2 * i + 1]};
+    for (int i = tid; i < A.canon_npat * 5; i += kBlock) cpv[i] = PairVal{A.canon_sym_val[2 * i], A.canon_sym_val[2 * i + 1]};
     if (tid < A.canon_npat) cmask[tid] = A.canon_sym_mask[tid];
     if (blockIdx.x == 0)
         for (int i = (int)gridDim.x + a.part_offset + tid; i < a.part_stride; i += kBlock)
@@ -803,7 +826,14 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
     const pvd2 du = {a.diag_uniform, a.diag_uniform};
     double acc0 = 0.0;
     typedef const unsigned __attribute__((address_space(4))) *const_words;
+    typedef const int __attribute__((address_space(4))) *const_ints;
     if (z0 < z1) {
+        const const_ints chain = (const_ints)(uintptr_t)A.chain_plane;
+        const const_ints chain_far = (const_ints)(uintptr_t)A.chain_far;
+        auto band_row = [&](int z) -> int64_t {
+            const int k = chain[z];
+            return (int64_t)(k < 0 ? 0 : k) * PL + (int64_t)band * T;
+        };
         auto clampg = [&](int64_t g) -> int64_t { return g < 0 ? 0 : (g > gmax ? gmax : g); };
         // p' at one 16-byte piece: the expression of dir2 / cg_direction_kernel
         auto newp = [&](pvd2 rv, pvd2 pv) -> pvd2 {
@@ -819,8 +849,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
         struct Halo {
             pvd2 r[NHL], p[NHL];
         };
-        auto load_own = [&](int z, Own &o) {
-            const int64_t base = (int64_t)z * PL + (int64_t)band * T;
+        auto load_own = [&](int64_t base, Own &o) {
 #pragma unroll
             for (int k = 0; k < NH; ++k) {
                 const int64_t g = clampg(base + 2 * (tid + k * kBlock));
@@ -828,10 +857,10 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
                 __builtin_memcpy(&o.p[k], a.x + g, 16);
             }
         };
-        // p'(z) of the band: to the ring, and to the output vector where the plane belongs to the segment
-        auto store_own = [&](int z, const Own &o, bool out) {
-            double *slot_p = own_ring + (size_t)((z + 3) % 3) * T;
-            const int64_t base = (int64_t)z * PL + (int64_t)band * T;
+        // p' of the band at a position: to the ring, and to the output vector where the position belongs to
+        // the segment
+        auto store_own = [&](int z, int64_t base, const Own &o, bool out) {
+            double *slot_p = own_ring + (size_t)(z & 3) * T;
 #pragma unroll
             for (int k = 0; k < NH; ++k) {
                 const pvd2 v = newp(o.r[k], o.p[k]);
@@ -839,8 +868,8 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
                 if (out) __builtin_memcpy(a.y + base + 2 * (tid + k * kBlock), &v, 16);
             }
         };
-        auto load_halo = [&](int z, Halo &hh) {
-            const int64_t up = (int64_t)z * PL + (int64_t)band * T + T;
+        auto load_halo = [&](int64_t base, Halo &hh) {
+            const int64_t up = base + T;
 #pragma unroll
             for (int k = 0; k < NHL; ++k) {
                 const int pc = min(tid + k * kBlock, NX / 2 - 1);
@@ -860,38 +889,47 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
         struct Rle {
             unsigned w0, w1, w2, w3;
         };
-        auto fetch_rle = [&](int z, int h) -> Rle {
-            const int64_t row0 = (int64_t)z * PL + (int64_t)band * T + h * kPairRows;
-            const const_words q = (const_words)(uintptr_t)(A.pair_rle + (row0 / kPairRows));
+        auto fetch_rle = [&](int64_t base, int h) -> Rle {
+            const const_words q = (const_words)(uintptr_t)(A.pair_rle + ((base + h * kPairRows) / kPairRows));
             return Rle{q[0], q[1], q[2], q[3]};
         };
         Own own_a, own_b;
         Halo hreg;
         Rle rle_a[NH], rle_b[NH];
+        int64_t brow[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) brow[k] = band_row(z0 - 1 + k);
         {
-            Own first;
-            load_own(z0, first);
-            load_halo(z0, hreg);
-            load_own(z0 + 1, own_b);
-            load_own(z0 + 2, own_a);
-            store_own(z0, first, true);
+            // the previous position is read by rows whose far-after slot points backwards along the chain
+            Own before, first;
+            load_own(brow[0], before);
+            load_own(brow[1], first);
+            load_halo(brow[1], hreg);
+            load_own(brow[2], own_b);
+            load_own(brow[3], own_a);
+            store_own(z0 - 1, brow[0], before, false);
+            store_own(z0, brow[1], first, true);
         }
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
-            rle_a[h] = fetch_rle(z0, h);
-            rle_b[h] = fetch_rle(z0 + 1 < z1 ? z0 + 1 : z0, h);
+            rle_a[h] = fetch_rle(brow[1], h);
+            rle_b[h] = fetch_rle(z0 + 1 < z1 ? brow[2] : brow[1], h);
         }
-        // one plane: `own_next` holds r, p of plane z + 1 on entry and of plane z + 3 on exit
+        // one position: `own_next` holds r, p of position z + 1 on entry and of position z + 3 on exit
         auto step = [&](int z, Own &own_next, Rle (&rl)[NH]) {
-            store_own(z + 1, own_next, z + 1 < z1);
+            store_own(z + 1, brow[2], own_next, z + 1 < z1);
             store_halo(z, hreg);
             lds_barrier();
-            load_halo(z + 1, hreg);
-            load_own(z + 3, own_next);
-            const double *cur = own_ring + (size_t)((z + 3) % 3) * T;
-            const double *nxt = own_ring + (size_t)((z + 4) % 3) * T;
+            load_halo(brow[2], hreg);
+            load_own(brow[4], own_next);
+            const int far = chain_far[z];
+            const double *cur = own_ring + (size_t)(z & 3) * T;
+            const double *prv = own_ring + (size_t)((z + 3) & 3) * T;
+            const double *nxt = own_ring + (size_t)((z + 1) & 3) * T;
             const double *hup = halo_ring + (size_t)(z & 1) * NX;
-            const int zn = z + 2 < z1 ? z + 2 : z1 - 1;
+            const double *fa0 = ((far >> 4) & 3) == 1 ? prv : (((far >> 4) & 3) == 2 ? nxt : cur);
+            const double *fa1 = ((far >> 6) & 3) == 1 ? prv : (((far >> 6) & 3) == 2 ? nxt : cur);
+            const int64_t rbase = z + 2 < z1 ? brow[3] : brow[1];
 #pragma unroll
             for (int h = 0; h < NH; ++h) {
                 const Rle f = rl[h];
@@ -904,24 +942,28 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
                     if ((unsigned)tid >= (e & 0xffu)) pid = (int)(e >> 8);
                 }
                 const int mask = cmask[pid];
-                pvd2 t[4];
+                pvd2 t[5];
                 t[0] = *reinterpret_cast<const pvd2 *>(cur + i0);
                 t[1].x = t[0].y;
                 t[1].y = i0 + 2 < T ? cur[i0 + 2] : hup[0];
                 t[2] = *reinterpret_cast<const pvd2 *>(i0 + NX < T ? cur + (i0 + NX) : hup + (i0 + NX - T));
-                t[3] = *reinterpret_cast<const pvd2 *>(nxt + i0);
+                t[3] = *reinterpret_cast<const pvd2 *>(fa0 + i0);
+                t[4] = *reinterpret_cast<const pvd2 *>(fa1 + i0);
                 double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const PairVal v = cpv[pid * 4 + k];
+                for (int k = 0; k < 5; ++k) {
+                    const PairVal v = cpv[pid * 5 + k];
                     const double p0 = v.a * t[k].x, p1 = v.b * t[k].y;
                     s0 += ((mask >> k) & 1) ? p0 : 0.0;
-                    s1 += ((mask >> (kPairChunk + k)) & 1) ? p1 : 0.0;
+                    s1 += ((mask >> (16 + k)) & 1) ? p1 : 0.0;
                 }
                 acc0 += t[0].x * s0;
                 acc0 += t[0].y * s1;
-                rl[h] = fetch_rle(zn, h);
+                rl[h] = fetch_rle(rbase, h);
             }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) brow[k] = brow[k + 1];
+            brow[4] = band_row(z + 4);
         };
         int z = z0;
         for (; z + 1 < z1; z += 2) {
@@ -955,7 +997,7 @@ int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hi
             // z-sweep walk + (where boundary planes or overlap rows exist) the listed walk of the chunks it
             // leaves out; the consumer folds `grid` partial sums per bank, as after a chunk-by-chunk launch
             const int nhl = (A.sweep_nx + kBlock - 1) / kBlock, nh = A.sweep_T / kPairRows;  // halo / own pieces per lane
-            const size_t lds = (size_t)(4 * A.sweep_T + 4 * A.sweep_nx) * sizeof(double) + (size_t)A.canon_npat * (8 * 16 + 4);
+            const size_t lds = (size_t)(4 * A.sweep_T + 4 * A.sweep_nx) * sizeof(double) + (size_t)A.canon_npat * (9 * 16 + 4);
             SpmvArgs b = a;
             b.part_stride = grid;
             b.part_offset = A.sweep_gen_blocks;  // slots of the companion launch follow this one's
@@ -1002,7 +1044,7 @@ int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hi
         const char *sweep_env = std::getenv("SCHWZ_CG_SWEEP");
         if (!(sweep_env && sweep_env[0] == '0')) {
             const int nhl = (A.sweep_nx / 2 + kBlock - 1) / kBlock, nh = A.sweep_T / kPairRows;
-            const size_t lds = (size_t)(3 * A.sweep_T + 2 * A.sweep_nx) * sizeof(double) + (size_t)A.canon_npat * (4 * 16 + 4);
+            const size_t lds = (size_t)(4 * A.sweep_T + 2 * A.sweep_nx) * sizeof(double) + (size_t)A.canon_npat * (5 * 16 + 4);
             if (nhl <= 2) {
                 // the companion first: the z-sweep kernel's workgroup 0 advances CgState for both
                 if (A.sweep_gen_blocks > 0) {
@@ -1085,6 +1127,326 @@ int upv(const std::vector<T> &h, void **d)
 }
 
 }  // namespace
+
+// The z-sweep walk (spmv_pair_sweep_kernel, spmv_pair_dirdot_sweep_kernel): host side.
+//
+// Geometry.  The matrix is cut into PLANES of PL consecutive rows (PL = the dominant far offset of the
+// canonical layout, NX its in-plane line offset).  A row of plane k may couple to {-NX, -1, 0, +1, +NX}
+// inside its plane and to the row at the SAME in-plane position of at most two other planes: for the
+// interior of a grid in natural order those are k - 1 and k + 1; for a subdomain whose overlap planes are
+// appended behind its interior the first interior plane couples to the plane PL rows on and
+// to the lower overlap plane far behind it, and so on.  Planes linked like that form CHAINS; a workgroup
+// sweeps a band of rows along a chain and keeps the windows of three consecutive chain positions in LDS,
+// so every far operand of a row is in the window before or after its own -- wherever the numbering put
+// that plane.  Slots of a row pair, in the order the entries are summed (= ascending column, the CSR
+// order): [far before 0, far before 1, -NX, -1, 0, +1, +NX, far after 0, far after 1]; which window
+// (previous / next chain position) a far slot reads is a property of the plane (sweep_far).
+// A plane takes part when all its chunks are full, run-length coded, and every pattern in them fits those
+// slots; the rest of the matrix is left to the companion launch (sweep_gen).
+static int build_sweep(schwz_csr *A, int64_t nrows, const PairTable &tb, const PairTable *ts,
+                       const std::vector<uint8_t> &pair_id, const std::vector<uint16_t> &rle, int64_t ntiles)
+{
+    const char *sw_env = std::getenv("SCHWZ_SPMV_SWEEP");
+    const int sw_mode = sw_env ? std::atoi(sw_env) : 1;
+    const int *cn = A->v.pair_canon;
+    const int64_t NX = cn[5], PL = cn[6];
+    const bool shape_ok = cn[7] && cn[0] == -PL && cn[1] == -NX && NX >= 2 && PL > NX && NX % 2 == 0 && PL % kPairRows == 0 &&
+                          NX <= 1024;
+    if (sw_mode == 0 || !shape_ok || !(nrows >= (int64_t(1) << 20) || sw_mode == 2) || nrows < 3 * PL || nrows % 2 ||
+        A->v.ncols != nrows || rle.empty())
+        return SCHWZ_OK;
+    const int nchunks = (int)((nrows + kPairRows - 1) / kPairRows);
+    const int nplanes = (int)(nrows / PL), cpp = (int)(PL / kPairRows);
+    // ---- per plane: the far offsets its rows use -------------------------------------------------
+    auto in_plane = [&](schwz_idx off) { return off == 0 || off == 1 || off == -1 || off == NX || off == -NX; };
+    std::vector<std::vector<schwz_idx>> pat_far((size_t)tb.npat);
+    std::vector<uint8_t> pat_bad((size_t)tb.npat, 0);
+    for (int q = 0; q < tb.npat; ++q) {
+        if ((int)tb.len[(size_t)q] > 9) pat_bad[(size_t)q] = 1;
+        for (int k = 0; k < (int)tb.len[(size_t)q]; ++k) {
+            const schwz_idx off = tb.ent[(size_t)q * tb.lmax + k].off;
+            if (in_plane(off)) continue;
+            if (off % PL != 0) pat_bad[(size_t)q] = 1;  // a far entry must keep the in-plane position
+            pat_far[(size_t)q].push_back(off);
+        }
+    }
+    std::vector<uint8_t> plane_ok((size_t)nplanes, 1);
+    std::vector<std::vector<schwz_idx>> plane_far((size_t)nplanes);  // sorted ascending
+    std::vector<std::vector<int>> plane_pats((size_t)nplanes);
+    for (int k = 0; k < nplanes; ++k) {
+        std::vector<uint8_t> used((size_t)tb.npat, 0);
+        for (int c = k * cpp; c < (k + 1) * cpp && plane_ok[(size_t)k]; ++c) {
+            if (rle[(size_t)c * 8] == 0xffffu) {  // ids must run-length code (scalar loads only)
+                plane_ok[(size_t)k] = 0;
+                break;
+            }
+            // the patterns of a chunk are the ids of its runs
+            for (int r = 0; r < 8; ++r) used[(size_t)(rle[(size_t)c * 8 + r] >> 8)] = 1;
+        }
+        if (!plane_ok[(size_t)k]) continue;
+        std::vector<schwz_idx> far;
+        for (int q = 0; q < tb.npat; ++q) {
+            if (!used[(size_t)q]) continue;
+            plane_pats[(size_t)k].push_back(q);
+            if (pat_bad[(size_t)q]) plane_ok[(size_t)k] = 0;
+            for (schwz_idx f : pat_far[(size_t)q]) far.push_back(f);
+        }
+        std::sort(far.begin(), far.end());
+        far.erase(std::unique(far.begin(), far.end()), far.end());
+        int nb = 0, na = 0;
+        for (schwz_idx f : far) {
+            const int64_t j = k + f / PL;
+            if (j < 0 || j >= nplanes) plane_ok[(size_t)k] = 0;
+            (f < 0 ? nb : na)++;
+        }
+        if (far.size() > 2 || nb > 2 || na > 2) plane_ok[(size_t)k] = 0;
+        if (plane_ok[(size_t)k]) plane_far[(size_t)k] = far;
+    }
+    // ---- chains: planes linked by their far couplings (degree <= 2: paths) ------------------------
+    std::vector<std::vector<int>> adj((size_t)nplanes);
+    auto link = [&](int x, int y) {
+        if (std::find(adj[(size_t)x].begin(), adj[(size_t)x].end(), y) == adj[(size_t)x].end()) adj[(size_t)x].push_back(y);
+    };
+    for (int k = 0; k < nplanes; ++k)
+        for (schwz_idx f : plane_far[(size_t)k]) {
+            link(k, (int)(k + f / PL));
+            link((int)(k + f / PL), k);
+        }
+    for (int k = 0; k < nplanes; ++k)
+        if (adj[(size_t)k].size() > 2) {  // a plane somebody else points at as a third neighbour: not a path
+            plane_ok[(size_t)k] = 0;
+            for (int j : adj[(size_t)k]) plane_ok[(size_t)j] = 0;
+        }
+    std::vector<int> chain_plane;   // concatenated chains, -1 between them and at both ends
+    std::vector<int> pos_of((size_t)nplanes, -1);
+    chain_plane.push_back(-1);
+    std::vector<uint8_t> seen((size_t)nplanes, 0);
+    for (int pass = 0; pass < 2; ++pass)   // paths from their ends first, then whatever is left (rings: cut anywhere)
+        for (int k0 = 0; k0 < nplanes; ++k0) {
+            if (seen[(size_t)k0] || adj[(size_t)k0].size() > 2) continue;
+            if (pass == 0 && adj[(size_t)k0].size() != 1 && !adj[(size_t)k0].empty()) continue;
+            int prev = -1, k = k0;
+            while (k >= 0 && !seen[(size_t)k] && adj[(size_t)k].size() <= 2) {
+                seen[(size_t)k] = 1;
+                pos_of[(size_t)k] = (int)chain_plane.size();
+                chain_plane.push_back(k);
+                int next = -1;
+                for (int j : adj[(size_t)k])
+                    if (j != prev && !seen[(size_t)j]) next = j;
+                prev = k;
+                k = next;
+            }
+            chain_plane.push_back(-1);
+        }
+    const int npos = (int)chain_plane.size();
+    for (int k = 0; k < 4; ++k) chain_plane.push_back(-1);  // the kernels look up to four positions ahead
+    // ---- per chain position: which window each far slot reads; per pattern: its nine slots --------
+    // far code: 2 bits per far slot (B0, B1, A0, A1): 0 none, 1 previous chain position, 2 next
+    std::vector<int> chain_far((size_t)npos + 4, 0);
+    std::vector<double> cval((size_t)tb.npat * 18, 0.0), sval((size_t)tb.npat * 10, 0.0);
+    std::vector<int> cmsk((size_t)tb.npat, 0), smsk((size_t)tb.npat, 0);
+    std::vector<int8_t> pat_slot_set((size_t)tb.npat, 0);
+    std::vector<std::vector<int8_t>> pat_slots((size_t)tb.npat);
+    bool sym_ok = ts != nullptr && ts->npat == tb.npat;
+    for (int p = 0; p < npos; ++p) {
+        const int k = chain_plane[(size_t)p];
+        if (k < 0 || !plane_ok[(size_t)k]) continue;
+        const std::vector<schwz_idx> &far = plane_far[(size_t)k];
+        std::vector<schwz_idx> fb, fa;
+        for (schwz_idx f : far) (f < 0 ? fb : fa).push_back(f);
+        int code = 0;
+        bool ok = true;
+        auto src_of = [&](schwz_idx f) -> int {
+            const int j = (int)(k + f / PL);
+            if (pos_of[(size_t)j] == p - 1) return 1;
+            if (pos_of[(size_t)j] == p + 1) return 2;
+            ok = false;
+            return 0;
+        };
+        for (size_t i = 0; i < fb.size(); ++i) code |= src_of(fb[i]) << (2 * (int)i);
+        for (size_t i = 0; i < fa.size(); ++i) code |= src_of(fa[i]) << (4 + 2 * (int)i);
+        // slots of every pattern of the plane; a pattern shared with another plane must get the same ones
+        for (int q : plane_pats[(size_t)k]) {
+            std::vector<int8_t> slots;
+            for (int e = 0; e < (int)tb.len[(size_t)q] && ok; ++e) {
+                const schwz_idx off = tb.ent[(size_t)q * tb.lmax + e].off;
+                int slot = -1;
+                if (off == -NX) slot = 2;
+                else if (off == -1) slot = 3;
+                else if (off == 0) slot = 4;
+                else if (off == 1) slot = 5;
+                else if (off == NX) slot = 6;
+                else {
+                    for (size_t i = 0; i < fb.size(); ++i)
+                        if (fb[i] == off) slot = (int)i;
+                    for (size_t i = 0; i < fa.size(); ++i)
+                        if (fa[i] == off) slot = 7 + (int)i;
+                }
+                if (slot < 0) ok = false;
+                slots.push_back((int8_t)slot);
+            }
+            if (!ok) break;
+            if (pat_slot_set[(size_t)q] && pat_slots[(size_t)q] != slots) ok = false;
+            if (!ok) break;
+            pat_slot_set[(size_t)q] = 1;
+            pat_slots[(size_t)q] = slots;
+        }
+        if (!ok) {
+            plane_ok[(size_t)k] = 0;
+            continue;
+        }
+        chain_far[(size_t)p] = code;
+    }
+    for (int q = 0; q < tb.npat; ++q) {
+        if (!pat_slot_set[(size_t)q]) continue;
+        for (int e = 0; e < (int)tb.len[(size_t)q]; ++e) {
+            const PairEntryH &en = tb.ent[(size_t)q * tb.lmax + e];
+            const int slot = pat_slots[(size_t)q][(size_t)e];
+            std::memcpy(&cval[((size_t)q * 9 + slot) * 2], &en.va, 8);
+            std::memcpy(&cval[((size_t)q * 9 + slot) * 2 + 1], &en.vb, 8);
+            cmsk[(size_t)q] |= (en.flags & 1) << slot;
+            cmsk[(size_t)q] |= ((en.flags >> 1) & 1) << (16 + slot);
+        }
+        if (sym_ok) {
+            // upper-triangle twin: slots [0, +1, +NX, far after 0, far after 1] = slots 4 .. 8 of the full form
+            for (int e = 0; e < (int)ts->len[(size_t)q]; ++e) {
+                const PairEntryH &en = ts->ent[(size_t)q * ts->lmax + e];
+                int slot = -1;
+                for (int f = 0; f < (int)tb.len[(size_t)q]; ++f)
+                    if (tb.ent[(size_t)q * tb.lmax + f].off == en.off) slot = pat_slots[(size_t)q][(size_t)f] - 4;
+                if (slot < 0 || slot > 4) {
+                    sym_ok = false;
+                    break;
+                }
+                std::memcpy(&sval[((size_t)q * 5 + slot) * 2], &en.va, 8);
+                std::memcpy(&sval[((size_t)q * 5 + slot) * 2 + 1], &en.vb, 8);
+                smsk[(size_t)q] |= (en.flags & 1) << slot;
+                smsk[(size_t)q] |= ((en.flags >> 1) & 1) << (16 + slot);
+            }
+        }
+    }
+    // ---- segments -----------------------------------------------------------------------------------
+    const char *t_env = std::getenv("SCHWZ_SWEEP_T"), *l_env = std::getenv("SCHWZ_SWEEP_L");
+    int T = t_env ? std::atoi(t_env) : (NX >= 512 ? 1024 : 512);
+    if (T != 512 && T != 1024) T = 512;
+    if (PL % T) T = 512;
+    const int bands = (int)(PL / T), cpb = T / kPairRows;
+    const int grid = (int)((std::min<int64_t>(ntiles, kMaxGrid) + kXcds - 1) / kXcds) * kXcds;
+    struct Run { int p0, p1; };
+    std::vector<Run> runs;
+    int64_t steps = 0;
+    for (int p = 0; p < npos;) {
+        const int k = chain_plane[(size_t)p];
+        if (k < 0 || !plane_ok[(size_t)k]) {
+            ++p;
+            continue;
+        }
+        int e = p;
+        while (e < npos && chain_plane[(size_t)e] >= 0 && plane_ok[(size_t)chain_plane[(size_t)e]]) ++e;
+        if (e - p >= 2) {
+            runs.push_back({p, e});
+            steps += (int64_t)(e - p) * bands;
+        }
+        p = e;
+    }
+    if (runs.empty()) return SCHWZ_OK;
+    std::vector<uint8_t> covered((size_t)nchunks, 0);
+    for (const Run &r : runs)
+        for (int p = r.p0; p < r.p1; ++p)
+            for (int c = 0; c < cpp; ++c) covered[(size_t)chain_plane[(size_t)p] * cpp + c] = 1;
+    std::vector<schwz_idx> gen;
+    for (int c = 0; c < nchunks; ++c)
+        if (!covered[(size_t)c]) gen.push_back(c);
+    // segment length: about three segments per CU (two for bands of 1024 rows, which keep twice the loads
+    // in flight) in ONE round of workgroups (measured on MI355X, 256^3 and 512 x 512 x 64; tools/sweep_ab.sh)
+    int cus = 256;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+    }
+    const int per_cu = T == 1024 ? 2 : 3;
+    int L = l_env ? std::atoi(l_env) : (int)std::max<int64_t>(8, (steps + per_cu * cus - 1) / (per_cu * cus));
+    if (L < 2) L = 16;
+    auto count = [&](int len) {
+        int64_t n = 0;
+        for (const Run &r : runs) n += (int64_t)((r.p1 - r.p0 + len - 1) / len) * bands;
+        return n;
+    };
+    // the companion launch walks its chunks with one gather round trip after the other: as many workgroups
+    // as the partial-sum slots next to the segments allow (up to one per chunk)
+    const int seg_slots = (int)((count(L) + kXcds - 1) / kXcds * kXcds) + kXcds;
+    const int gen_blocks = (int)std::min<int64_t>((int64_t)gen.size(), std::max(256, std::min(1024, grid - seg_slots)));
+    while (count(L) + kXcds > grid - gen_blocks && L < (1 << 20)) L += 4;
+    struct Seg { int band, p0, p1; };
+    std::vector<Seg> segs;
+    for (const Run &r : runs) {
+        const int nseg = (r.p1 - r.p0 + L - 1) / L, len = (r.p1 - r.p0 + nseg - 1) / nseg;
+        for (int b = 0; b < bands; ++b)
+            for (int p = r.p0; p < r.p1; p += len) segs.push_back({b, p, std::min(p + len, r.p1)});
+    }
+    // deal: XCD x takes the bands [x * bands / 8, (x + 1) * bands / 8) (a band's window shares its NX-row
+    // halos with the neighbouring bands: the same L2), segment by segment along the chain
+    std::stable_sort(segs.begin(), segs.end(), [](const Seg &x, const Seg &y) { return x.p0 != y.p0 ? x.p0 < y.p0 : x.band < y.band; });
+    std::vector<std::vector<int4>> per_xcd(kXcds);
+    for (const Seg &sgm : segs) {
+        int4 v;
+        v.x = sgm.band;
+        v.y = sgm.p0;
+        v.z = sgm.p1;
+        v.w = 0;
+        size_t x;
+        if (bands >= 2 * kXcds) {
+            x = (size_t)((int64_t)sgm.band * kXcds / bands);
+        } else {  // few bands: round robin
+            x = 0;
+            for (size_t k = 1; k < (size_t)kXcds; ++k)
+                if (per_xcd[k].size() < per_xcd[x].size()) x = k;
+        }
+        per_xcd[x].push_back(v);
+    }
+    size_t depth = 0;
+    for (const auto &l : per_xcd) depth = std::max(depth, l.size());
+    std::vector<int4> slots_v(depth * kXcds);
+    for (size_t q = 0; q < depth; ++q)
+        for (int x = 0; x < kXcds; ++x) {
+            int4 v;
+            v.x = v.y = v.z = v.w = 0;
+            if (q < per_xcd[(size_t)x].size()) v = per_xcd[(size_t)x][q];
+            slots_v[q * kXcds + x] = v;
+        }
+    // Rows the walk leaves out cost a companion launch per CG launch: measured with 256 x 256 planes, 8 / 4 / 1
+    // slabs on one GPU when the boundary planes of a slab were still left out (tools/sweep_sizes.sh, bench.py
+    // --ttr-subdomains): +13 % time at 2.2 M rows, +2 % at 4.3 M, -18 % at 16.8 M; without left-out rows the
+    // walk wins from 1 M rows on.
+    const bool worth = gen.empty() || nrows >= 6000000 || sw_mode == 2;
+    if (!worth || (int64_t)slots_v.size() + gen_blocks > grid || steps * T * 2 < nrows) return SCHWZ_OK;
+    int rc;
+    if ((rc = upv(slots_v, &A->d_sweep_seg)) || (rc = upv(gen, &A->d_sweep_gen)) || (rc = upv(cval, &A->d_canon_val)) ||
+        (rc = upv(cmsk, &A->d_canon_mask)) || (rc = upv(chain_plane, &A->d_chain_plane)) ||
+        (rc = upv(chain_far, &A->d_chain_far)))
+        return rc;
+    A->v.canon_val = (const double *)A->d_canon_val;
+    A->v.canon_mask = (const int *)A->d_canon_mask;
+    A->v.canon_npat = tb.npat;
+    A->v.chain_plane = (const int *)A->d_chain_plane;
+    A->v.chain_far = (const int *)A->d_chain_far;
+    if (sym_ok) {
+        if ((rc = upv(sval, &A->d_canon_sym_val)) || (rc = upv(smsk, &A->d_canon_sym_mask))) return rc;
+        A->v.canon_sym_val = (const double *)A->d_canon_sym_val;
+        A->v.canon_sym_mask = (const int *)A->d_canon_sym_mask;
+    }
+    A->v.sweep_T = T;
+    A->v.sweep_nx = (int)NX;
+    A->v.sweep_pl = PL;
+    A->v.sweep_nslots = (int)slots_v.size();
+    A->v.sweep_ngen = (int)gen.size();
+    A->v.sweep_gen_blocks = gen_blocks;
+    A->v.sweep_seg = (const int4 *)A->d_sweep_seg;
+    A->v.sweep_gen = (const schwz_idx *)A->d_sweep_gen;
+    return SCHWZ_OK;
+}
 
 // Leaves A->v.pair_id null when fewer than 90 % of the nonzeros sit in pair-coded chunks
 // (SCHWZ_SPMV_PAIR=0 disables, =2 forces whatever the coverage).
@@ -1392,206 +1754,11 @@ int build_spmv_pair(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, con
         }
     }
     A->v.pair_sym_base = sym_base;
-    // z-sweep segments (CsrView::sweep_*) for a canonical layout {-PL, -NX, -1, 0, +1, +NX, +PL} with
-    // PL a multiple of the band length: SCHWZ_SPMV_SWEEP=0 off, =2 also below a million rows (tests);
+    // z-sweep segments (CsrView::sweep_*): SCHWZ_SPMV_SWEEP=0 off, =2 also below a million rows (tests);
     // SCHWZ_SWEEP_T (512 / 1024 rows per band), SCHWZ_SWEEP_L (planes per segment) override the defaults.
-    {
-        const char *sw_env = std::getenv("SCHWZ_SPMV_SWEEP");
-        const int sw_mode = sw_env ? std::atoi(sw_env) : 1;
-        const int *cn = A->v.pair_canon;
-        const int64_t NX = cn[5], PL = cn[6];
-        const bool shape_ok = single && cn[7] && cn[0] == -PL && cn[1] == -NX && NX >= 2 && PL > NX && NX % 2 == 0 &&
-                              PL % kPairRows == 0;
-        if (sw_mode != 0 && shape_ok && (nrows >= (int64_t(1) << 20) || sw_mode == 2) && nrows >= 3 * PL && nrows % 2 == 0 &&
-            A->v.ncols == nrows) {
-            const PairTable &tb = tables[0];
-            // a pattern fits the layout when each of its entries has one of the seven offsets (the device
-            // stages cmask the same way, stage_table)
-            std::vector<uint8_t> pat_ok((size_t)tb.npat, 1);
-            std::vector<double> cval((size_t)tb.npat * 16, 0.0);
-            std::vector<int> cmsk((size_t)tb.npat, 0);
-            for (int q = 0; q < tb.npat; ++q) {
-                if ((int)tb.len[(size_t)q] > kPairChunk) pat_ok[(size_t)q] = 0;
-                for (int k = 0; k < (int)tb.len[(size_t)q]; ++k) {
-                    const PairEntryH &e = tb.ent[(size_t)q * tb.lmax + k];
-                    int slot = -1;  // the first layout slot with the entry's offset
-                    for (int t = 6; t >= 0; --t)
-                        if (cn[t] == e.off) slot = t;
-                    if (slot < 0) {
-                        pat_ok[(size_t)q] = 0;
-                        continue;
-                    }
-                    std::memcpy(&cval[((size_t)q * 8 + slot) * 2], &e.va, 8);
-                    std::memcpy(&cval[((size_t)q * 8 + slot) * 2 + 1], &e.vb, 8);
-                    cmsk[(size_t)q] |= (e.flags & 1) << slot;
-                    cmsk[(size_t)q] |= ((e.flags >> 1) & 1) << (kPairChunk + slot);
-                }
-                if (!pat_ok[(size_t)q]) cmsk[(size_t)q] = -1;
-            }
-            std::vector<uint8_t> chunk_ok((size_t)nchunks, 0);
-            for (int c = 0; c < nchunks; ++c) {
-                const int64_t p0 = (int64_t)c * (kPairRows / 2), p1 = p0 + kPairRows / 2;
-                if (p1 * 2 > nrows) continue;  // a partial chunk stays generic
-                if (rle.empty() || rle[(size_t)c * 8] == 0xffffu) continue;  // ids must run-length code (scalar loads only)
-                bool ok = true;
-                for (int64_t q = p0; q < p1 && ok; ++q) ok = pat_ok[(size_t)pair_id[(size_t)q]] != 0;
-                chunk_ok[(size_t)c] = ok ? 1 : 0;
-            }
-            const char *t_env = std::getenv("SCHWZ_SWEEP_T"), *l_env = std::getenv("SCHWZ_SWEEP_L");
-            int T = t_env ? std::atoi(t_env) : (NX >= 512 ? 1024 : 512);
-            if (T != 512 && T != 1024) T = 512;
-            if (PL % T) T = 512;
-            const int64_t W = T + 2 * NX;
-            const int nplanes = (int)(nrows / PL), bands = (int)(PL / T), cpb = T / kPairRows, cpp = (int)(PL / kPairRows);
-            const int grid = ((std::min<int64_t>((int64_t)tiles.size() - 1, kMaxGrid) + kXcds - 1) / kXcds) * kXcds;
-            if (NX <= 1024 && W > 0 && bands >= 1 && nplanes >= 3) {
-                // maximal runs of planes in which every chunk of the band is canonical
-                struct Run { int band, z0, z1; };
-                std::vector<Run> runs;
-                int64_t steps = 0;
-                for (int b = 0; b < bands; ++b) {
-                    int z = 0;
-                    while (z < nplanes) {
-                        auto okz = [&](int zz) {
-                            for (int h = 0; h < cpb; ++h)
-                                if (!chunk_ok[(size_t)((int64_t)zz * cpp + (int64_t)b * cpb + h)]) return false;
-                            return true;
-                        };
-                        if (!okz(z)) {
-                            ++z;
-                            continue;
-                        }
-                        int e = z;
-                        while (e < nplanes && okz(e)) ++e;
-                        if (e - z >= 2) {
-                            runs.push_back({b, z, e});
-                            steps += e - z;
-                        }
-                        z = e;
-                    }
-                }
-                std::vector<uint8_t> covered((size_t)nchunks, 0);
-                // segment length: about three segments per CU in ONE round of workgroups (measured on MI355X,
-                // 256^3 and 512 x 512 x 64: 2 and 5 per CU are both slower; tools/sweep_ab.sh)
-                int cus = 256;
-                {
-                    int dev = 0;
-                    hipDeviceProp_t prop;
-                    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-                        prop.multiProcessorCount > 0)
-                        cus = prop.multiProcessorCount;
-                }
-                // (bands of 1024 rows keep twice the loads in flight per workgroup: two segments per CU there)
-                const int per_cu = T == 1024 ? 2 : 3;
-                int L = l_env ? std::atoi(l_env) : (int)std::max<int64_t>(8, (steps + per_cu * cus - 1) / (per_cu * cus));
-                if (L < 2) L = 16;
-                // the segments and the workgroups of the generic walk must fit the launch grid
-                auto count = [&](int len) {
-                    int64_t n = 0;
-                    for (const Run &r : runs) n += (r.z1 - r.z0 + len - 1) / len;
-                    return n;
-                };
-                for (const Run &r : runs)
-                    for (int z = r.z0; z < r.z1; ++z)
-                        for (int h = 0; h < cpb; ++h) covered[(size_t)((int64_t)z * cpp + (int64_t)r.band * cpb + h)] = 1;
-                std::vector<schwz_idx> gen;
-                for (int c = 0; c < nchunks; ++c)
-                    if (!covered[(size_t)c]) gen.push_back(c);
-                // the companion launch walks its chunks with one gather round trip after the other: as many
-                // workgroups as the partial-sum slots next to the segments allow (up to one per chunk)
-                const int seg_slots = (int)((count(L) + kXcds - 1) / kXcds * kXcds) + kXcds;
-                const int gen_blocks = (int)std::min<int64_t>((int64_t)gen.size(), std::max(256, std::min(1024, grid - seg_slots)));
-                while (count(L) + kXcds > grid - gen_blocks && L < (1 << 20)) L += 4;
-                // deal: XCD x takes the bands [x * bands / 8, (x + 1) * bands / 8) (a band's window shares its
-                // NX-row halos with the neighbouring bands: the same L2), segment by segment of the z range
-                std::vector<std::vector<int4>> per_xcd(kXcds);
-                struct Seg { int band, z0, z1; };
-                std::vector<Seg> segs;
-                for (const Run &r : runs) {
-                    const int nseg = (r.z1 - r.z0 + L - 1) / L, len = (r.z1 - r.z0 + nseg - 1) / nseg;
-                    for (int z = r.z0; z < r.z1; z += len) segs.push_back({r.band, z, std::min(z + len, r.z1)});
-                }
-                std::stable_sort(segs.begin(), segs.end(), [](const Seg &x, const Seg &y) {
-                    return x.z0 != y.z0 ? x.z0 < y.z0 : x.band < y.band;
-                });
-                for (const Seg &sgm : segs) {
-                    const int x = bands >= 2 * kXcds ? (int)((int64_t)sgm.band * kXcds / bands) : -1;
-                    int4 v;
-                    v.x = sgm.band;
-                    v.y = sgm.z0;
-                    v.z = sgm.z1;
-                    v.w = 0;
-                    if (x >= 0) {
-                        per_xcd[(size_t)x].push_back(v);
-                    } else {  // few bands: round robin
-                        size_t best = 0;
-                        for (size_t k = 1; k < (size_t)kXcds; ++k)
-                            if (per_xcd[k].size() < per_xcd[best].size()) best = k;
-                        per_xcd[best].push_back(v);
-                    }
-                }
-                size_t depth = 0;
-                for (const auto &l : per_xcd) depth = std::max(depth, l.size());
-                std::vector<int4> slots_v(depth * kXcds);
-                for (size_t q = 0; q < depth; ++q)
-                    for (int x = 0; x < kXcds; ++x) {
-                        int4 v;
-                        v.x = v.y = v.z = v.w = 0;
-                        if (q < per_xcd[(size_t)x].size()) v = per_xcd[(size_t)x][q];
-                        slots_v[q * kXcds + x] = v;
-                    }
-                // Rows the walk leaves out (a subdomain's boundary planes and appended overlap planes) cost a
-                // companion launch per CG launch: measured with 256 x 256 planes, 8 / 4 / 1 slabs on one GPU
-                // (tools/sweep_sizes.sh, bench.py --ttr-subdomains): +13 % time at 2.2 M rows, +2 % at 4.3 M,
-                // -18 % at 16.8 M; without left-out rows the walk wins from 1 M rows on.
-                const bool worth = gen.empty() || nrows >= 6000000 || sw_mode == 2;
-                if (worth && !segs.empty() && (int64_t)slots_v.size() + gen_blocks <= grid && steps * T * 2 >= nrows) {
-                    if ((rc = upv(slots_v, &A->d_sweep_seg)) || (rc = upv(gen, &A->d_sweep_gen)) ||
-                        (rc = upv(cval, &A->d_canon_val)) || (rc = upv(cmsk, &A->d_canon_mask)))
-                        return rc;
-                    A->v.canon_val = (const double *)A->d_canon_val;
-                    A->v.canon_mask = (const int *)A->d_canon_mask;
-                    A->v.canon_npat = tb.npat;
-                    if (sym_base > 0) {
-                        // the upper-triangle twin of the table in the slots {0, +1, +NX, +PL}
-                        const PairTable &ts = tables[(size_t)sym_base];
-                        const schwz_idx lay[4] = {0, 1, (schwz_idx)NX, (schwz_idx)PL};
-                        std::vector<double> sval((size_t)ts.npat * 8, 0.0);
-                        std::vector<int> smsk((size_t)ts.npat, 0);
-                        bool sym_ok = ts.npat == tb.npat;
-                        for (int q = 0; q < ts.npat && sym_ok; ++q)
-                            for (int k = 0; k < (int)ts.len[(size_t)q]; ++k) {
-                                const PairEntryH &e = ts.ent[(size_t)q * ts.lmax + k];
-                                int slot = -1;
-                                for (int t = 3; t >= 0; --t)
-                                    if (lay[t] == e.off) slot = t;
-                                if (slot < 0) {
-                                    if (pat_ok[(size_t)q]) sym_ok = false;  // cannot happen for a pattern inside the layout
-                                    continue;
-                                }
-                                std::memcpy(&sval[((size_t)q * 4 + slot) * 2], &e.va, 8);
-                                std::memcpy(&sval[((size_t)q * 4 + slot) * 2 + 1], &e.vb, 8);
-                                smsk[(size_t)q] |= (e.flags & 1) << slot;
-                                smsk[(size_t)q] |= ((e.flags >> 1) & 1) << (kPairChunk + slot);
-                            }
-                        if (sym_ok) {
-                            if ((rc = upv(sval, &A->d_canon_sym_val)) || (rc = upv(smsk, &A->d_canon_sym_mask))) return rc;
-                            A->v.canon_sym_val = (const double *)A->d_canon_sym_val;
-                            A->v.canon_sym_mask = (const int *)A->d_canon_sym_mask;
-                        }
-                    }
-                    A->v.sweep_T = T;
-                    A->v.sweep_nx = (int)NX;
-                    A->v.sweep_pl = PL;
-                    A->v.sweep_nslots = (int)slots_v.size();
-                    A->v.sweep_ngen = (int)gen.size();
-                    A->v.sweep_gen_blocks = gen_blocks;
-                    A->v.sweep_seg = (const int4 *)A->d_sweep_seg;
-                    A->v.sweep_gen = (const schwz_idx *)A->d_sweep_gen;
-                }
-            }
-        }
-    }
+    if (single && (rc = build_sweep(A, nrows, tables[0], sym_base > 0 ? &tables[(size_t)sym_base] : nullptr, pair_id, rle,
+                                    (int64_t)tiles.size() - 1)))
+        return rc;
     {
         // what a pass over the coded matrix reads: per chunk its 16-byte run-length record, or one byte per
         // pair where the ids do not run-length code; the chunk's table id unless one table serves the whole
@@ -1645,6 +1812,9 @@ void free_spmv_pair(schwz_csr *A)
     (void)hipFree(A->d_canon_mask);
     (void)hipFree(A->d_canon_sym_val);
     (void)hipFree(A->d_canon_sym_mask);
+    (void)hipFree(A->d_chain_plane);
+    (void)hipFree(A->d_chain_far);
+    A->d_chain_plane = A->d_chain_far = nullptr;
     A->d_sweep_seg = A->d_sweep_gen = A->d_canon_val = A->d_canon_mask = A->d_canon_sym_val = A->d_canon_sym_mask = nullptr;
     A->v.canon_sym_val = nullptr;
     A->v.sweep_nslots = 0;

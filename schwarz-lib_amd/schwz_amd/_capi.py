@@ -28,7 +28,7 @@ PRECOND_NONE, PRECOND_JACOBI, PRECOND_BLOCK_JACOBI, PRECOND_ILU, PRECOND_ISAI = 
 SYMBOLS = [
     "schwz_last_error", "schwz_version", "schwz_device_count", "schwz_set_device",
     "schwz_gather", "schwz_scatter", "schwz_gather_typed", "schwz_scatter_typed",
-    "schwz_csr_create", "schwz_csr_destroy", "schwz_csr_nnz", "schwz_csr_format", "schwz_csr_symmetric", "schwz_csr_matrix_bytes", "schwz_csr_sweep_slots", "schwz_csr_spmv",
+    "schwz_csr_create", "schwz_csr_destroy", "schwz_csr_nnz", "schwz_csr_format", "schwz_csr_symmetric", "schwz_csr_matrix_bytes", "schwz_csr_sweep_slots", "schwz_csr_sweep_left_out", "schwz_csr_spmv",
     "schwz_pcg_create", "schwz_pcg_create_ex", "schwz_pcg_destroy", "schwz_pcg_flavour", "schwz_pcg_solve",
     "schwz_gmres_create", "schwz_gmres_destroy", "schwz_gmres_solve", "schwz_gmres_last_stats",
     "schwz_profile_begin", "schwz_profile_end", "schwz_profile_kind", "schwz_stream_probe",
@@ -115,6 +115,7 @@ _sig("schwz_csr_format", i32, [vp])
 _sig("schwz_csr_symmetric", i32, [vp])
 _sig("schwz_csr_matrix_bytes", i64, [vp, i32])
 _sig("schwz_csr_sweep_slots", i32, [vp])
+_sig("schwz_csr_sweep_left_out", i32, [vp])
 _sig("schwz_csr_spmv", i32, [vp, dbl, vp, dbl, vp, i32, vp])
 _sig("schwz_pcg_create", i32, [vp, i32, pvp])
 _sig("schwz_pcg_create_ex", i32, [vp, i32, i32, pvp])

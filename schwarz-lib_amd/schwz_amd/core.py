@@ -61,6 +61,10 @@ class Csr:
         """Workgroup slots of the z-sweep walk of the CG update launch (0: not a canonical 3-D stencil)."""
         return int(lib.schwz_csr_sweep_slots(self.h))
 
+    def sweep_left_out(self):
+        """Chunks of 512 rows the z-sweep walk leaves to its companion launch."""
+        return int(lib.schwz_csr_sweep_left_out(self.h))
+
     def algorithmic_bytes(self):
         # SURVEY 8(d): 12 nnz + 4 (rows+1) + 16 rows
         return 12 * self.nnz + 4 * (self.nrows + 1) + 16 * self.nrows

@@ -710,6 +710,8 @@ def test_z_sweep_update_launch_matches_the_gather_walk(schwz, oracle, torch_cuda
     x0 = 0.1 * rng.standard_normal(n)
     A = schwz.Csr(rp, col, val)
     assert A.format() == 3 and A.symmetric() and A.sweep_slots() > 0
+    # the appended overlap planes of a slab are chained to its interior: nothing is left to a companion launch
+    assert A.sweep_left_out() == 0
     cg = schwz.Pcg(A, 1)
 
     def solve(sweep, defer, iters, rtol=0.0):
