@@ -622,14 +622,14 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
         // position without a plane (the ends of a chain) reads plane 0 -- valid memory no mask lets through
         const const_ints chain = (const_ints)(uintptr_t)A.chain_plane;
         const const_ints chain_far = (const_ints)(uintptr_t)A.chain_far;
-        auto band_row = [&](int z) -> int64_t {
+        auto band_row = [&](int z) -> int {  // rows fit 32 bits (the launch is for ncols < 2^28)
             const int k = chain[z];
-            return (int64_t)(k < 0 ? 0 : k) * PL + (int64_t)band * T;
+            return (k < 0 ? 0 : k) * (int)PL + band * T;
         };
         // Pieces beyond the vector's ends (first / last band of a plane) are clamped to a valid address: no
         // row has an entry there, the masks drop what they deliver.
-        auto clampg = [&](int64_t g) -> int64_t { return g < 0 ? 0 : (g > gmax ? gmax : g); };
-        auto load_own = [&](int64_t base, pvd2 (&reg)[NH]) {
+        auto clampg = [&](int g) -> int { return g < 0 ? 0 : (g > (int)gmax ? (int)gmax : g); };
+        auto load_own = [&](int base, pvd2 (&reg)[NH]) {
 #pragma unroll
             for (int k = 0; k < NH; ++k) __builtin_memcpy(&reg[k], a.x + clampg(base + 2 * (tid + k * kBlock)), 16);
         };
@@ -639,12 +639,12 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
             for (int k = 0; k < NH; ++k) *reinterpret_cast<pvd2 *>(slot_p + 2 * (tid + k * kBlock)) = reg[k];
         };
         // halo of a plane: the NX rows below the band (pieces 0 .. NX/2) and the NX rows above it
-        auto load_halo = [&](int64_t base, pvd2 (&reg)[NHL]) {
-            const int64_t lo = base - NX, up = base + T;
+        auto load_halo = [&](int base, pvd2 (&reg)[NHL]) {
+            const int lo = base - NX, up = base + T;
 #pragma unroll
             for (int k = 0; k < NHL; ++k) {
                 const int pc = min(tid + k * kBlock, NX - 1);  // NX pieces: NX/2 below, NX/2 above
-                const int64_t g = pc < NX / 2 ? lo + 2 * pc : up + 2 * (pc - NX / 2);
+                const int g = pc < NX / 2 ? lo + 2 * pc : up + 2 * (pc - NX / 2);
                 __builtin_memcpy(&reg[k], a.x + clampg(g), 16);
             }
         };
@@ -660,10 +660,10 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
             pvd2 r, d;
             unsigned w0, w1, w2, w3;
         };
-        auto fetch = [&](int64_t base, int h) -> Ahead {
+        auto fetch = [&](int base, int h) -> Ahead {
             Ahead f;
-            const int64_t row0 = base + h * kPairRows;
-            const int ra = (int)row0 + 2 * tid;
+            const int row0 = base + h * kPairRows;
+            const int ra = row0 + 2 * tid;
             const const_words q = (const_words)(uintptr_t)(A.pair_rle + (row0 / kPairRows));
             f.w0 = q[0];
             f.w1 = q[1];
@@ -680,7 +680,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
         // rows at the positions z - 1 .. z + 3 travel in scalar registers (brow), one new one per step.
         pvd2 own_a[NH], own_b[NH], hreg[NHL];
         Ahead r_a[NH], r_b[NH];
-        int64_t brow[5];
+        int brow[5];
 #pragma unroll
         for (int k = 0; k < 5; ++k) brow[k] = band_row(z0 - 1 + k);
         {
@@ -717,12 +717,12 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
             const double *fb1 = ((far >> 2) & 3) == 1 ? prv : (((far >> 2) & 3) == 2 ? nxt : cur);
             const double *fa0 = ((far >> 4) & 3) == 1 ? prv : (((far >> 4) & 3) == 2 ? nxt : cur);
             const double *fa1 = ((far >> 6) & 3) == 1 ? prv : (((far >> 6) & 3) == 2 ? nxt : cur);
-            const int64_t rbase = z + 2 < z1 ? brow[3] : brow[1];  // past the segment: a valid plane, never used
+            const int rbase = z + 2 < z1 ? brow[3] : brow[1];  // past the segment: a valid plane, never used
 #pragma unroll
             for (int h = 0; h < NH; ++h) {
                 const Ahead f = rr[h];
                 const int i0 = h * kPairRows + 2 * tid;  // position inside the band
-                const int ra = (int)brow[1] + i0;
+                const int ra = brow[1] + i0;
                 // the id of the last run that starts at or before this lane's pair
                 const unsigned w[4] = {f.w0, f.w1, f.w2, f.w3};
                 int pid = (int)((w[0] >> 8) & 0xffu);
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
                     if ((unsigned)tid >= (e & 0xffu)) pid = (int)(e >> 8);
                 }
                 const int mask = cmask[pid];
-                pvd2 t[9];
+                pvd2 t[8];
                 t[4] = *reinterpret_cast<const pvd2 *>(cur + i0);
                 t[3].x = i0 > 0 ? cur[i0 - 1] : hlo[NX - 1];
                 t[3].y = t[4].x;
@@ -741,19 +741,22 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
                 t[2] = *reinterpret_cast<const pvd2 *>(i0 >= NX ? cur + (i0 - NX) : hlo + i0);
                 t[6] = *reinterpret_cast<const pvd2 *>(i0 + NX < T ? cur + (i0 + NX) : hup + (i0 + NX - T));
                 t[0] = *reinterpret_cast<const pvd2 *>(fb0 + i0);
-                t[1] = *reinterpret_cast<const pvd2 *>(fb1 + i0);
                 t[7] = *reinterpret_cast<const pvd2 *>(fa0 + i0);
-                t[8] = *reinterpret_cast<const pvd2 *>(fa1 + i0);
                 // masked sums without branches: an absent entry adds +0.0, which leaves a sum that began
-                // at +0.0 unchanged bit for bit (such a sum is never -0.0)
+                // at +0.0 unchanged bit for bit (such a sum is never -0.0).  The second far slots exist on a
+                // subdomain's boundary planes only: a plane without them skips both (workgroup-uniform).
                 double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-                for (int k = 0; k < 9; ++k) {
+                auto add = [&](int k, pvd2 tv) {
                     const PairVal v = cpv[pid * 9 + k];
-                    const double p0 = v.a * t[k].x, p1 = v.b * t[k].y;
+                    const double p0 = v.a * tv.x, p1 = v.b * tv.y;
                     s0 += ((mask >> k) & 1) ? p0 : 0.0;
                     s1 += ((mask >> (16 + k)) & 1) ? p1 : 0.0;
-                }
+                };
+                add(0, t[0]);
+                if (far & 0x0c) add(1, *reinterpret_cast<const pvd2 *>(fb1 + i0));
+#pragma unroll
+                for (int k = 2; k < 8; ++k) add(k, t[k]);
+                if (far & 0xc0) add(8, *reinterpret_cast<const pvd2 *>(fa1 + i0));
                 // r -= alpha q ; z = D^-1 r ; partial r.z and r.r  (kSpmvCgUpdate's epilogue, x deferred)
                 const double r0 = f.r.x - cg_alpha * s0;
                 const double zz0 = a.diag_mode ? (DIAGVEC ? f.d.x : a.diag_uniform) * r0 : r0;
@@ -830,11 +833,11 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
     if (z0 < z1) {
         const const_ints chain = (const_ints)(uintptr_t)A.chain_plane;
         const const_ints chain_far = (const_ints)(uintptr_t)A.chain_far;
-        auto band_row = [&](int z) -> int64_t {
+        auto band_row = [&](int z) -> int {  // rows fit 32 bits (the launch is for ncols < 2^28)
             const int k = chain[z];
-            return (int64_t)(k < 0 ? 0 : k) * PL + (int64_t)band * T;
+            return (k < 0 ? 0 : k) * (int)PL + band * T;
         };
-        auto clampg = [&](int64_t g) -> int64_t { return g < 0 ? 0 : (g > gmax ? gmax : g); };
+        auto clampg = [&](int g) -> int { return g < 0 ? 0 : (g > (int)gmax ? (int)gmax : g); };
         // p' at one 16-byte piece: the expression of dir2 / cg_direction_kernel
         auto newp = [&](pvd2 rv, pvd2 pv) -> pvd2 {
             const pvd2 zv = a.diag_mode ? du * rv : rv;
@@ -849,17 +852,17 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
         struct Halo {
             pvd2 r[NHL], p[NHL];
         };
-        auto load_own = [&](int64_t base, Own &o) {
+        auto load_own = [&](int base, Own &o) {
 #pragma unroll
             for (int k = 0; k < NH; ++k) {
-                const int64_t g = clampg(base + 2 * (tid + k * kBlock));
+                const int g = clampg(base + 2 * (tid + k * kBlock));
                 o.r[k] = __builtin_nontemporal_load(reinterpret_cast<const pvd2 *>(a.cg_r + g));
                 __builtin_memcpy(&o.p[k], a.x + g, 16);
             }
         };
         // p' of the band at a position: to the ring, and to the output vector where the position belongs to
         // the segment
-        auto store_own = [&](int z, int64_t base, const Own &o, bool out) {
+        auto store_own = [&](int z, int base, const Own &o, bool out) {
             double *slot_p = own_ring + (size_t)(z & 3) * T;
 #pragma unroll
             for (int k = 0; k < NH; ++k) {
@@ -868,12 +871,12 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
                 if (out) __builtin_memcpy(a.y + base + 2 * (tid + k * kBlock), &v, 16);
             }
         };
-        auto load_halo = [&](int64_t base, Halo &hh) {
-            const int64_t up = base + T;
+        auto load_halo = [&](int base, Halo &hh) {
+            const int up = base + T;
 #pragma unroll
             for (int k = 0; k < NHL; ++k) {
                 const int pc = min(tid + k * kBlock, NX / 2 - 1);
-                const int64_t g = clampg(up + 2 * pc);
+                const int g = clampg(up + 2 * pc);
                 __builtin_memcpy(&hh.r[k], a.cg_r + g, 16);
                 __builtin_memcpy(&hh.p[k], a.x + g, 16);
             }
@@ -889,14 +892,14 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
         struct Rle {
             unsigned w0, w1, w2, w3;
         };
-        auto fetch_rle = [&](int64_t base, int h) -> Rle {
+        auto fetch_rle = [&](int base, int h) -> Rle {
             const const_words q = (const_words)(uintptr_t)(A.pair_rle + ((base + h * kPairRows) / kPairRows));
             return Rle{q[0], q[1], q[2], q[3]};
         };
         Own own_a, own_b;
         Halo hreg;
         Rle rle_a[NH], rle_b[NH];
-        int64_t brow[5];
+        int brow[5];
 #pragma unroll
         for (int k = 0; k < 5; ++k) brow[k] = band_row(z0 - 1 + k);
         {
@@ -929,7 +932,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
             const double *hup = halo_ring + (size_t)(z & 1) * NX;
             const double *fa0 = ((far >> 4) & 3) == 1 ? prv : (((far >> 4) & 3) == 2 ? nxt : cur);
             const double *fa1 = ((far >> 6) & 3) == 1 ? prv : (((far >> 6) & 3) == 2 ? nxt : cur);
-            const int64_t rbase = z + 2 < z1 ? brow[3] : brow[1];
+            const int rbase = z + 2 < z1 ? brow[3] : brow[1];
 #pragma unroll
             for (int h = 0; h < NH; ++h) {
                 const Rle f = rl[h];
@@ -942,21 +945,22 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
                     if ((unsigned)tid >= (e & 0xffu)) pid = (int)(e >> 8);
                 }
                 const int mask = cmask[pid];
-                pvd2 t[5];
+                pvd2 t[4];
                 t[0] = *reinterpret_cast<const pvd2 *>(cur + i0);
                 t[1].x = t[0].y;
                 t[1].y = i0 + 2 < T ? cur[i0 + 2] : hup[0];
                 t[2] = *reinterpret_cast<const pvd2 *>(i0 + NX < T ? cur + (i0 + NX) : hup + (i0 + NX - T));
                 t[3] = *reinterpret_cast<const pvd2 *>(fa0 + i0);
-                t[4] = *reinterpret_cast<const pvd2 *>(fa1 + i0);
                 double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-                for (int k = 0; k < 5; ++k) {
+                auto add = [&](int k, pvd2 tv) {
                     const PairVal v = cpv[pid * 5 + k];
-                    const double p0 = v.a * t[k].x, p1 = v.b * t[k].y;
+                    const double p0 = v.a * tv.x, p1 = v.b * tv.y;
                     s0 += ((mask >> k) & 1) ? p0 : 0.0;
                     s1 += ((mask >> (16 + k)) & 1) ? p1 : 0.0;
-                }
+                };
+#pragma unroll
+                for (int k = 0; k < 4; ++k) add(k, t[k]);
+                if (far & 0xc0) add(4, *reinterpret_cast<const pvd2 *>(fa1 + i0));
                 acc0 += t[0].x * s0;
                 acc0 += t[0].y * s1;
                 rl[h] = fetch_rle(rbase, h);
