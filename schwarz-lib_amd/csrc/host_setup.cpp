@@ -13,6 +13,8 @@
 #include <fstream>
 #include <numeric>
 #include <queue>
+#include <set>
+#include <unordered_map>
 #include <sstream>
 
 #include "schwz_internal.hpp"
@@ -436,6 +438,91 @@ static void bisect(const schwz_problem *p, std::vector<int64_t> &nodes, int part
     bfs(far, order);
     far = order.back();
     bfs(far, order);
+    // Refinement of the level-structure cut (what METIS does after its initial bisection): passes of
+    // Fiduccia-Mattheyses moves, taken in PAIRS (best node of the left side, then best node of the right
+    // side) so that the sizes never change; the pass keeps the best prefix of its move sequence and the
+    // passes stop when one brings nothing.  Unit edge weights.  SCHWZ_PART_REFINE=0 disables it; skipped
+    // above 4 M nodes per bisection (the regular partitions are the ones used at that size).
+    static const bool refine_on = [] {
+        const char *e = std::getenv("SCHWZ_PART_REFINE");
+        return !(e && e[0] == '0');
+    }();
+    if (refine_on && nodes.size() >= 4 && nodes.size() <= (size_t)4000000 && target > 0 &&
+        target < (int64_t)nodes.size()) {
+        // side 0 / 1 of the members, kept in `mark` as member + 1 / member + 2 (both != any other stamp in use)
+        stamp += 2;
+        const int32_t s0 = stamp - 1, s1 = stamp;
+        const size_t nodes_count = nodes.size();
+        for (int64_t i = 0; i < (int64_t)order.size(); ++i) mark[order[(size_t)i]] = i < target ? s0 : s1;
+        std::unordered_map<int64_t, int> gain;
+        gain.reserve(nodes.size() * 2);
+        auto compute_gain = [&](int64_t u) {
+            const int len = p->row(u, c.data(), v.data());
+            int g = 0;
+            for (int k = 0; k < len; ++k) {
+                const int64_t w = c[k];
+                if (w == u || (mark[w] != s0 && mark[w] != s1)) continue;
+                g += mark[w] != mark[u] ? 1 : -1;
+            }
+            return g;
+        };
+        for (int pass = 0; pass < 8; ++pass) {
+            std::set<std::pair<int, int64_t>> q[2];  // (-gain, node): begin() = best move
+            for (int64_t u : order) {
+                const int g = compute_gain(u);
+                gain[u] = g;
+                q[mark[u] == s1].insert({-g, u});
+            }
+            std::vector<int64_t> moved;
+            std::unordered_map<int64_t, char> locked;
+            int64_t delta = 0, best = 0;
+            size_t best_len = 0;
+            int stale = 0;
+            auto move = [&](int from) -> bool {
+                if (q[from].empty()) return false;
+                const auto it = q[from].begin();
+                const int64_t u = it->second;
+                const int g = -it->first;
+                q[from].erase(it);
+                locked[u] = 1;
+                delta -= g;
+                mark[u] = from == 0 ? s1 : s0;
+                moved.push_back(u);
+                const int len = p->row(u, c.data(), v.data());
+                for (int k = 0; k < len; ++k) {
+                    const int64_t w = c[k];
+                    if (w == u || (mark[w] != s0 && mark[w] != s1) || locked.count(w)) continue;
+                    const int side_w = mark[w] == s1;
+                    int &gw = gain[w];
+                    q[side_w].erase({-gw, w});
+                    gw += (side_w == from) ? 2 : -2;  // u left w's side: the edge is cut now; or joined it: no longer cut
+                    q[side_w].insert({-gw, w});
+                }
+                return true;
+            };
+            const int patience = (int)std::min<size_t>(4000, std::max<size_t>(64, nodes_count / 50));
+            while (stale < patience) {
+                if (!move(0) || !move(1)) break;
+                if (delta < best) {
+                    best = delta;
+                    best_len = moved.size();
+                    stale = 0;
+                } else {
+                    ++stale;
+                }
+            }
+            for (size_t i = moved.size(); i > best_len; --i) {  // undo what came after the best prefix
+                const int64_t u = moved[i - 1];
+                mark[u] = mark[u] == s0 ? s1 : s0;
+            }
+            if (best == 0) break;
+        }
+        size_t wl = 0, wr = (size_t)target;
+        std::vector<int64_t> resorted(order.size());
+        for (int64_t u : order) resorted[mark[u] == s0 ? wl++ : wr++] = u;
+        order.swap(resorted);
+        for (int64_t u : order) mark[u] = member;
+    }
     std::vector<int64_t> left(order.begin(), order.begin() + target);
     std::vector<int64_t> right(order.begin() + target, order.end());
     std::sort(left.begin(), left.end());
