@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <iostream>
+#include <limits>
 #include <numeric>
 #include <sstream>
 #include <type_traits>
@@ -110,9 +111,25 @@ struct SchwarzBase<ValueType, IndexType, MixedValueType>::Impl {
     ncclComm_t nccl = nullptr;  // halo exchange over RCCL; nullptr: staged through host over MPI
     hipStream_t side = nullptr;  // overlapped mode: the halo transfers run here, beside the local solve
     hipEvent_t ev_packed = nullptr, ev_arrived = nullptr;
+    // free-running one-sided mode (exchange_boundary_onesided, restricted_schwarz.cpp:715-852): d_recv and
+    // d_send are windows the neighbours map through HIP IPC; the termination / residual windows are one
+    // MPI shared-memory window of the node
+    bool free_running = false;
+    std::vector<void *> peer_recv, peer_send;          // per out- / in-neighbour: its mapped recv / send window
+    std::vector<long long> peer_recv_off, peer_send_off;  // where that window expects / keeps this rank's values
+    MPI_Win host_win = MPI_WIN_NULL;
+    MPI_Comm node_comm = MPI_COMM_NULL;
+    std::vector<int32_t *> win_int;   // per rank: tree[4], flags[P], count
+    std::vector<double *> win_res;    // per rank: resid[P]
+    std::vector<int32_t> flags_sent;
+    bool counted = false;
 
     ~Impl()
     {
+        for (void *w : peer_recv) (void)schwz_window_close(w);
+        for (void *w : peer_send) (void)schwz_window_close(w);
+        if (host_win != MPI_WIN_NULL) MPI_Win_free(&host_win);
+        if (node_comm != MPI_COMM_NULL) MPI_Comm_free(&node_comm);
         if (nccl) (void)ncclCommDestroy(nccl);
         if (side) (void)hipStreamDestroy(side);
         if (ev_packed) (void)hipEventDestroy(ev_packed);
@@ -411,6 +428,68 @@ void SchwarzBase<V, I, M>::initialize()
                       << std::endl;
     }
 
+    // ---- Communicate::setup_windows (communicate.hpp:67-224) for the free-running one-sided mode ------
+    // --enable_onesided without --enable_comm_overlap, every rank on this node: the halo buffers become
+    // windows the neighbours map (HIP IPC), the convergence / residual windows one MPI shared-memory
+    // window.  SCHWZ_ONESIDED=lockstep keeps the deterministic stand-in (local tests, all-gathered flags).
+    {
+        const char *osm = std::getenv("SCHWZ_ONESIDED");
+        const bool lockstep = osm && std::string(osm) == "lockstep";
+        im.free_running = s.comm_settings.enable_onesided && !s.comm_settings.enable_overlap && !lockstep && P > 1 &&
+                          m.local_num_procs == m.comm_size;
+        if (im.free_running) {
+            unsigned char mine[128];
+            SCHWZ_CALL(schwz_window_export(im.d_recv, mine));
+            SCHWZ_CALL(schwz_window_export(im.d_send, mine + 64));
+            std::vector<unsigned char> handles((size_t)P * 128);
+            MPI_Allgather(mine, 128, MPI_BYTE, handles.data(), 128, MPI_BYTE, MPI_COMM_WORLD);
+            std::vector<long long> my_ro((size_t)P, -1), my_so((size_t)P, -1), ro((size_t)P), so((size_t)P);
+            for (int k = 0; k < n_in; ++k) my_ro[(size_t)im.nbr_in[(size_t)k]] = im.recv_off[(size_t)k];
+            for (int k = 0; k < n_out; ++k) my_so[(size_t)im.nbr_out[(size_t)k]] = im.send_off[(size_t)k];
+            MPI_Alltoall(my_ro.data(), 1, MPI_LONG_LONG, ro.data(), 1, MPI_LONG_LONG, MPI_COMM_WORLD);
+            MPI_Alltoall(my_so.data(), 1, MPI_LONG_LONG, so.data(), 1, MPI_LONG_LONG, MPI_COMM_WORLD);
+            for (int k = 0; k < n_out; ++k) {  // put: my values go into q's receive window where q expects me
+                const int q = im.nbr_out[(size_t)k];
+                void *w = nullptr;
+                SCHWZ_CALL(schwz_window_open(&handles[(size_t)q * 128], &w));
+                im.peer_recv.push_back(w);
+                im.peer_recv_off.push_back(ro[(size_t)q]);
+            }
+            for (int k = 0; k < n_in; ++k) {  // get: p's values for me sit in p's send window
+                const int pr = im.nbr_in[(size_t)k];
+                void *w = nullptr;
+                SCHWZ_CALL(schwz_window_open(&handles[(size_t)pr * 128 + 64], &w));
+                im.peer_send.push_back(w);
+                im.peer_send_off.push_back(so[(size_t)pr]);
+            }
+            MPI_Comm_split_type(MPI_COMM_WORLD, MPI_COMM_TYPE_SHARED, 0, MPI_INFO_NULL, &im.node_comm);
+            const MPI_Aint ints = (MPI_Aint)(((size_t)P + 5 + 1) / 2 * 2);  // tree[4], flags[P], count; even
+            const MPI_Aint bytes = ints * 4 + (MPI_Aint)P * 8;
+            void *base = nullptr;
+            MPI_Win_allocate_shared(bytes, 1, MPI_INFO_NULL, im.node_comm, &base, &im.host_win);
+            im.win_int.resize((size_t)P);
+            im.win_res.resize((size_t)P);
+            for (int r = 0; r < P; ++r) {
+                MPI_Aint sz = 0;
+                int du = 0;
+                void *ptr = nullptr;
+                MPI_Win_shared_query(im.host_win, r, &sz, &du, &ptr);
+                im.win_int[(size_t)r] = (int32_t *)ptr;
+                im.win_res[(size_t)r] = (double *)((char *)ptr + ints * 4);
+            }
+            im.flags_sent.assign((size_t)P, 0);
+            if (me == 0)
+                std::cout << " One-sided exchange: free running, halo "
+                          << (s.comm_settings.enable_put ? "put into" : "get from")
+                          << " the neighbours' device windows (HIP IPC); termination: "
+                          << (s.convergence_settings.enable_global_simple_tree
+                                  ? "centralised tree"
+                                  : (s.convergence_settings.enable_accumulate ? "decentralised, accumulated counters"
+                                                                              : "decentralised flag propagation"))
+                          << std::endl;
+        }
+    }
+
     // gather_comm_data (schwarz_base.cpp:275-319): one entry per subdomain, only mine is filled
     m.comm_data_struct.assign((size_t)P, {});
     {
@@ -642,7 +721,135 @@ void SchwarzBase<V, I, M>::run(std::shared_ptr<gko::matrix::Dense<V>> &solution)
             MPI_Waitall(nreq_flag, freqs.data(), MPI_STATUSES_IGNORE);
         }
     }
-    for (; !overlapped && m.iter_count < m.max_iters; ++m.iter_count) {
+    if (im.free_running) {
+        // The reference's asynchronous iteration: every rank at its own pace, no collective and no matched
+        // receive in the loop (same protocols as schwz_amd/solver.py::_step_free_running).
+        const int ints = (int)(((size_t)P + 5 + 1) / 2 * 2);
+        int32_t *tree = im.win_int[(size_t)me], *flags = tree + 4, *count = tree + 4 + P;
+        double *resid = im.win_res[(size_t)me];
+        for (int k = 0; k < ints; ++k) tree[k] = 0;
+        for (int j = 0; j < P; ++j) resid[j] = std::numeric_limits<double>::max();
+        std::fill(im.flags_sent.begin(), im.flags_sent.end(), 0);
+        im.counted = false;
+        MPI_Barrier(MPI_COMM_WORLD);
+        const int single = im.f32_wire ? 1 : 0;
+        for (; m.iter_count < m.max_iters; ++m.iter_count) {
+            const auto it = m.iter_count;
+            const double t0 = now();
+            if (s.reset_local_crit_iter != -1 && it > s.reset_local_crit_iter && !two_stage_on) {
+                SCHWZ_CALL(schwz_ras_set_local_max_iters(im.sd, (int)m.updated_max_iters));
+                two_stage_on = true;
+            }
+            if (it > 0) {  // restricted_schwarz.cpp:725
+                if (cs.enable_put) {
+                    for (int k = 0; k < n_out; ++k)
+                        SCHWZ_CALL(schwz_ras_pack_neighbor(im.sd, k, im.wire((double *)im.peer_recv[(size_t)k], im.peer_recv_off[(size_t)k]),
+                                                           single, im.stream));
+                    for (int k = 0; k < n_in; ++k)
+                        SCHWZ_CALL(schwz_ras_unpack_neighbor(im.sd, k, im.wire(im.d_recv, im.recv_off[(size_t)k]), single, im.stream));
+                } else {
+                    for (int k = 0; k < n_out; ++k)
+                        SCHWZ_CALL(schwz_ras_pack_neighbor(im.sd, k, im.wire(im.d_send, im.send_off[(size_t)k]), single, im.stream));
+                    for (int k = 0; k < n_in; ++k)
+                        SCHWZ_CALL(schwz_ras_unpack_neighbor(im.sd, k, im.wire((double *)im.peer_send[(size_t)k], im.peer_send_off[(size_t)k]),
+                                                             single, im.stream));
+                }
+            }
+            const double t1 = now();
+            SCHWZ_CALL(schwz_ras_update_boundary(im.sd, im.stream));
+            const double t2 = now();
+            local_res = -1.0;
+            if (tol >= 0.0) {
+                SCHWZ_CALL(schwz_ras_check_and_solve_launch(im.sd, im.stream));
+                double r = 0.0;
+                SCHWZ_CALL(schwz_ras_local_residual_wait(im.sd, &r));
+                local_res = (V)r;
+                if (local_res0 < 0.0) local_res0 = local_res;
+            } else {
+                SCHWZ_CALL(schwz_ras_local_solve(im.sd, nullptr, im.stream));
+            }
+            if (std::isnan(local_res)) std::exit(-1);  // solve.cpp:982-984
+            ppd.local_residual_vector_out.push_back(local_res);
+            ppd.local_converged_resnorm.push_back(local_res / local_res0);
+            ppd.local_timestamp.push_back((V)(MPI_Wtime() - m.init_mpi_wtime));
+            m.current_residual_norm = local_res;
+            m.min_residual_norm = it == 0 ? local_res : std::min(local_res, m.min_residual_norm);
+            const bool iter_cond = cv.enable_global_check_iter_offset ? ((it > m.max_iters * 0.05) || m.max_iters < 1000) : true;
+            if (tol > 0.0 && iter_cond) {
+                const bool conv_local = local_res / local_res0 <= tol;
+                // window_residual_vector (conv_tools.hpp:56-142)
+                resid[me] = std::min(resid[me], (double)local_res);
+                const auto &hist_me = ppd.global_residual_vector_out[(size_t)me];
+                if (cv.put_all_local_residual_norms) {
+                    if (it > 0 && !hist_me.empty() && resid[me] != (double)hist_me.back())
+                        for (int j = 0; j < P; ++j)
+                            if (j != me) im.win_res[(size_t)j][me] = resid[me];
+                } else {
+                    for (int k = 0; k < n_out; ++k) {
+                        const int q = im.nbr_out[(size_t)k];
+                        for (int j = 0; j < P; ++j)
+                            if (j != q && resid[j] != std::numeric_limits<double>::max())
+                                (void)schwz_host_atomic_min_f64(&im.win_res[(size_t)q][j], resid[j]);
+                    }
+                }
+                for (int j = 0; j < P; ++j) ppd.global_residual_vector_out[(size_t)j].push_back((V)resid[j]);
+                if (cv.enable_global_simple_tree) {  // conv_tools.hpp:147-209
+                    if (((tree[0] == 1 && tree[1] == 1) || (tree[0] == 1 && me == P / 2 - 1) || (me >= P / 2 && tree[0] != 2)) &&
+                        conv_local) {
+                        if (me == 0) tree[2] = 1;
+                        else schwz_host_atomic_store_i32(&im.win_int[(size_t)((me - 1) / 2)][me % 2 == 0 ? 1 : 0], 1);
+                        tree[0] = 2;
+                    }
+                    if (schwz_host_atomic_load_i32(&tree[2]) == 1) {
+                        for (int child = 2 * me + 1; child <= 2 * me + 2; ++child)
+                            if (child < P) schwz_host_atomic_store_i32(&im.win_int[(size_t)child][2], 1);
+                        tree[1]++;
+                        num_converged = P;
+                    } else {
+                        num_converged = 0;
+                    }
+                } else if (cv.enable_accumulate) {  // conv_tools.hpp:229-246, one add per rank
+                    if (conv_local && !im.counted) {
+                        for (int j = 0; j < P; ++j) (void)schwz_host_atomic_add_i32(&im.win_int[(size_t)j][4 + P], 1);
+                        im.counted = true;
+                    }
+                    num_converged = schwz_host_atomic_load_i32(count);
+                } else {  // conv_tools.hpp:247-273
+                    if (conv_local) flags[me] = 1;
+                    std::vector<int32_t> local((size_t)P);
+                    int sum = 0;
+                    for (int j = 0; j < P; ++j) sum += (local[(size_t)j] = schwz_host_atomic_load_i32(&flags[j]));
+                    for (int k = 0; k < n_out; ++k) {
+                        const int q = im.nbr_out[(size_t)k];
+                        for (int j = 0; j < P; ++j)
+                            if (im.flags_sent[(size_t)j] == 0 && local[(size_t)j] == 1)
+                                schwz_host_atomic_store_i32(&im.win_int[(size_t)q][4 + j], 1);
+                    }
+                    im.flags_sent = local;
+                    num_converged = sum;
+                }
+            }
+            const double t3 = now();
+            timings[0].push_back((V)(t1 - t0));
+            timings[1].push_back((V)(t2 - t1));
+            timings[2].push_back((V)(t3 - t2));
+            if (num_converged == P) break;
+            const double t4 = now();
+            if (s.enable_logging) {
+                int inner = 0;
+                double inner_res = 0.0;
+                SCHWZ_CALL(schwz_ras_last_inner_stats(im.sd, &inner, &inner_res));
+                ppd.local_converged_iter_count.push_back((V)inner);
+            } else {
+                ppd.local_converged_iter_count.push_back(0);
+            }
+            SCHWZ_CALL(schwz_ras_restrict(im.sd, im.stream));
+            const double t5 = now();
+            timings[3].push_back((V)(t4 - t3));
+            timings[4].push_back((V)(t5 - t4));
+        }
+    }
+    for (; !overlapped && !im.free_running && m.iter_count < m.max_iters; ++m.iter_count) {
         const auto it = m.iter_count;
         const double t0 = now();
         if (s.reset_local_crit_iter != -1 && it > s.reset_local_crit_iter && !two_stage_on) {

@@ -186,7 +186,8 @@ def test_bench_ras_authors_iterative_study_settings(oracle):
     n, P = 48, 4
     out = _run(P, "--explicit_laplacian", "--set_1d_laplacian_size=%d" % n, "--num_iters=100", "--set_tol=1e-8",
                "--local_tol=0.1", "--local_max_iters=70", "--restart_iter=40", "--overlap=8",
-               "--local_precond=block-jacobi", "--enable_onesided", "--global_convergence_type=decentralized")
+               "--local_precond=block-jacobi", "--enable_onesided", "--global_convergence_type=decentralized",
+               env={"SCHWZ_ONESIDED": "lockstep"})
     rp, col, val = oracle.laplacian2d(n)
     N = n * n
     ref = oracle.ras_run(rp, col, val, np.ones(N), P, oracle.first_rows_regular(N, P),
@@ -259,8 +260,10 @@ def test_mirror_int64_index_instantiations(oracle, types):
 
 def test_bench_ras_onesided_rma_flavour_flags(oracle):
     """The reference's MPI RMA flavours (put instead of get, one message per value, local flush,
-    local lock: bench_ras.cpp:73-97) and its default convergence type (centralized-tree) select
-    calls, not values: the one-sided iteration is the same one."""
+    local lock: bench_ras.cpp:73-97) and its default convergence type (centralized-tree) through the
+    deterministic stand-in of the one-sided mode (SCHWZ_ONESIDED=lockstep: local tests, all-gathered
+    flags), which the oracle can reproduce: the flags select calls, not values.  The free-running
+    mode the same flags select by default is the next test."""
     n, P = 32, 3
     rp, col, val = oracle.laplacian2d(n)
     N = n * n
@@ -271,11 +274,38 @@ def test_bench_ras_onesided_rma_flavour_flags(oracle):
             "--enable_onesided"]
     for extra in ([], ["--remote_comm_type=put", "--enable_one_by_one", "--flush_type=flush-local",
                        "--lock_type=lock-local"]):
-        out = _run(P, *(base + extra))
+        out = _run(P, *(base + extra), env={"SCHWZ_ONESIDED": "lockstep"})
         iters = sorted(set(int(x) for x in re.findall(r"converged in (\d+) iterations", out)))
         assert iters == [ref["iter_count"]], out
         rel = float(re.search(r"relative residual norm of solution ([0-9.eE+-]+)", out).group(1))
         assert abs(rel - ref["residual_norm"] / ref["rhs_norm"]) <= 1e-6 * rel + 1e-12
+
+
+@pytest.mark.parametrize("flavour", [("put", "centralized-tree", []), ("get", "decentralized", []),
+                                     ("put", "decentralized", ["--enable_decentralized_accumulate"]),
+                                     ("get", "centralized-tree", ["--enable_put_all_local_residual_norms=false"])])
+def test_bench_ras_free_running_onesided(oracle, flavour):
+    """--enable_onesided through the UNCHANGED reference driver, free running: three ranks on this GPU,
+    halo values put into / got from the neighbours' device windows (HIP IPC), termination by the tree,
+    the decentralised flags or the accumulated counters on an MPI shared-memory window.  Not
+    deterministic: every rank converges (possibly at different iteration counts), and the residual
+    of the assembled solution is what the tolerance implies."""
+    n, P = 32, 3
+    comm_type, conv_type, extra = flavour
+    out = _run(P, "--explicit_laplacian", "--set_1d_laplacian_size=%d" % n, "--num_iters=3000", "--set_tol=1e-7",
+               "--enable_onesided", "--remote_comm_type=%s" % comm_type, "--global_convergence_type=%s" % conv_type, *extra)
+    assert "One-sided exchange: free running" in out, out
+    iters = [int(x) for x in re.findall(r"converged in (\d+) iterations", out)]
+    assert len(iters) == P and all(5 < i < 3000 for i in iters), out
+    assert "did not converge" not in out
+    rel = float(re.search(r"relative residual norm of solution ([0-9.eE+-]+)", out).group(1))
+    assert rel < 1e-4
+    rp, col, val = oracle.laplacian2d(n)
+    N = n * n
+    ref = oracle.ras_run(rp, col, val, np.ones(N), P, oracle.first_rows_regular(N, P),
+                         oracle.make_settings(max_iters=3000, tol=1e-7))
+    # asynchronous iterations need at least about as many sweeps as the synchronous loop
+    assert ref["converged"] and max(iters) >= ref["iter_count"] - 2
 
 
 @pytest.mark.parametrize("types", ["d32d", "d64d"])
