@@ -23,6 +23,8 @@ setup = time.perf_counter() - t0
 b = torch.ones(prob.N, dtype=torch.float64, device="cuda")
 x = torch.zeros(prob.N, dtype=torch.float64, device="cuda")
 cg.solve(b.data_ptr(), x.data_ptr(), 0.0, 3)
+x.zero_()
+cg.solve(b.data_ptr(), x.data_ptr(), 0.0, 20)   # same length as the timed solve: records its hipGraph, if any
 torch.cuda.synchronize()
 x.zero_()
 t0 = time.perf_counter()
