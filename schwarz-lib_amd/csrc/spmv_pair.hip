@@ -1334,7 +1334,7 @@ static int build_sweep(schwz_csr *A, int64_t nrows, const PairTable &tb, const P
     int T = t_env ? std::atoi(t_env) : (NX >= 512 ? 1024 : 512);
     if (T != 512 && T != 1024) T = 512;
     if (PL % T) T = 512;
-    const int bands = (int)(PL / T), cpb = T / kPairRows;
+    const int bands = (int)(PL / T);
     const int grid = (int)((std::min<int64_t>(ntiles, kMaxGrid) + kXcds - 1) / kXcds) * kXcds;
     struct Run { int p0, p1; };
     std::vector<Run> runs;

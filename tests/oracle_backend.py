@@ -215,6 +215,11 @@ class OracleBackend:
         return OracleProblem(*O.laplacian3d(nx, ny, nz))
 
     @staticmethod
+    def problem_from_csr(rp, col, val):
+        return OracleProblem(np.ascontiguousarray(rp, dtype=np.int32), np.ascontiguousarray(col, dtype=np.int32),
+                             np.ascontiguousarray(val, dtype=np.float64))
+
+    @staticmethod
     def problem_from_matrix_market(path):
         return OracleProblem(*O.read_matrix_market(path))
 

@@ -671,17 +671,19 @@ def test_deferred_x_update_is_bit_identical(schwz, oracle, torch_cuda, monkeypat
         assert np.array_equal(x_plain, x_def), rtol
 
 
-def _slab_local_matrix(schwz, shape, P, me):
+def _slab_local_matrix(schwz, shape, P, me, overlap=2):
     """local_matrix of subdomain `me` of a z-slab partition: interior planes in natural order, the
-    overlap planes appended at the end (rows next to them carry one far-away column)."""
+    overlap planes appended at the end (rows next to them carry one far-away column); overlap = 4:
+    three planes per side, appended layer by layer (lower 1, upper 1, lower 2, upper 2, ...)."""
     prob = schwz.Problem.laplacian(3, *shape)
-    sd = schwz.Subdomain(prob, P, me, 2, schwz.partition_regular(prob.N, P))
+    sd = schwz.Subdomain(prob, P, me, overlap, schwz.partition_regular(prob.N, P))
     return sd.local_matrix()
 
 
 @pytest.mark.parametrize("case", [("cube", (256, 4, 12), "512"), ("cube", (256, 4, 10), "1024"), ("cube", (512, 4, 8), "512"),
                                   ("cube", (512, 4, 8), "1024"), ("cube", (256, 8, 7), "512"), ("slab", (256, 4, 30), "512"),
-                                  ("slab", (256, 4, 30), "1024"), ("end", (256, 4, 24), "512")])
+                                  ("slab", (256, 4, 30), "1024"), ("end", (256, 4, 24), "512"),
+                                  ("slab4", (256, 4, 36), "512"), ("first", (256, 4, 24), "1024")])
 def test_z_sweep_update_launch_matches_the_gather_walk(schwz, oracle, torch_cuda, monkeypatch, case):
     """The z-sweep walk of the q-free update launch (a band of rows swept through consecutive planes,
     every operand of the canonical stencil layout read from an LDS ring of plane windows) against the
@@ -702,8 +704,10 @@ def test_z_sweep_update_launch_matches_the_gather_walk(schwz, oracle, torch_cuda
     monkeypatch.setenv("SCHWZ_SWEEP_L", "4")
     if kind == "cube":
         rp, col, val = oracle.laplacian3d(*shape)
+    elif kind == "slab4":
+        rp, col, val = _slab_local_matrix(schwz, shape, 3, 1, overlap=4)
     else:
-        rp, col, val = _slab_local_matrix(schwz, shape, 3, 1 if kind == "slab" else 2)
+        rp, col, val = _slab_local_matrix(schwz, shape, 3, {"slab": 1, "end": 2, "first": 0}[kind])
     n = len(rp) - 1
     rng = np.random.default_rng(11)
     b = rng.standard_normal(n)

@@ -1,0 +1,67 @@
+"""Edge cases of the host layer the advisor listed after round 1: a zero right-hand side must
+not raise (the reference gets NaN from 0/0 and keeps iterating), the overlapped mode refuses more than 62
+subdomains like the C++ mirror, a custom partition needs a valid partition vector.  CPU only: the
+per-subdomain arithmetic is the test-only oracle backend."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+
+def _solver(schwz, P, settings=None, **md):
+    from oracle_backend import OracleBackend
+    s = settings or schwz.Settings()
+    m = schwz.Metadata(num_subdomains=P, **md)
+    return schwz.SolverRAS(s, m, comm=schwz.InProcessComm(P), backend=OracleBackend(), quiet=True), m
+
+
+def test_zero_right_hand_side_iterates_without_raising(schwz, oracle):
+    solver, m = _solver(schwz, 2, oned_laplacian_size=8, tolerance=1e-6, max_iters=5)
+    solver.initialize(matrix=oracle.laplacian2d(8), rhs=np.zeros(64))
+    out = solver.run()
+    # 0 / 0 = NaN never passes "<= tol": all iterations are done, like the reference and the mirror
+    assert out["iter_count"] == 5 and not out["converged"]
+    assert np.all(out["solution"] == 0.0)
+
+
+def test_ratio_follows_ieee_division():
+    from schwz_amd.solver import _ratio
+    assert np.isnan(_ratio(0.0, 0.0)) and _ratio(1.0, 0.0) == float("inf") and _ratio(1.0, 4.0) == 0.25
+    assert np.isnan(_ratio(float("nan"), 0.0))
+
+
+def test_overlapped_mode_refuses_more_than_62_subdomains(schwz):
+    s = schwz.Settings()
+    s.comm_settings.enable_onesided = True
+    s.comm_settings.enable_overlap = True
+    s.convergence_settings.enable_decentralized_leader_election = True
+    solver, m = _solver(schwz, 63, settings=s, oned_laplacian_size=16, tolerance=1e-6, max_iters=3)
+    solver.initialize()
+    with pytest.raises(schwz.NotImplementedSchwz):
+        solver.run()
+
+
+def test_custom_partition_needs_a_valid_vector(schwz):
+    for vec in (None, np.zeros(5, dtype=np.uint32), np.full(64, 7, dtype=np.uint32)):
+        s = schwz.Settings(partition=schwz.PARTITION_CUSTOM, partition_vector=vec)
+        solver, m = _solver(schwz, 2, settings=s, oned_laplacian_size=8)
+        with pytest.raises(schwz.SchwzError):
+            solver.initialize()
+
+
+def test_onesided_run_says_which_protocol_runs(schwz, capsys):
+    from oracle_backend import OracleBackend
+    s = schwz.Settings()
+    s.comm_settings.enable_onesided = True
+    s.comm_settings.enable_put = True
+    s.convergence_settings.enable_global_simple_tree = True
+    m = schwz.Metadata(num_subdomains=2, oned_laplacian_size=8, tolerance=1e-6, max_iters=50)
+    solver = schwz.SolverRAS(s, m, comm=schwz.InProcessComm(2), backend=OracleBackend(), quiet=False)
+    solver.initialize()
+    solver.run()
+    out = capsys.readouterr().out
+    assert "RMA flavour flags" in out and "without node windows" in out
