@@ -169,3 +169,45 @@ def test_config4_per_gpu_size_overlapped_properties(schwz, oracle, torch_cuda):
     assert out2["converged"] and r["converged"]
     assert out2["iter_count"] == r["iter_count"] == 3
     assert solver._stop[0] == solver._stop[1] == 3
+
+
+@pytest.mark.parametrize("case", ["cube_256", "middle_slab_512x512x64"])
+def test_z_sweep_walk_at_bench_size_is_bit_identical_per_row(schwz, torch_cuda, monkeypatch, case):
+    """The z-sweep walk of the CG launches at the sizes the bench runs: the 256^3 matrix of configs[1]
+    and the local matrix of a MIDDLE slab of the 512 x 512 x 64N grids (two appended overlap planes,
+    chained to the interior: nothing left to a companion launch).  One CG iteration -- every row's
+    q_i = (A p)_i, the r update and x += alpha p -- gives the same bits with the walk and with the
+    chunk-by-chunk gather launches; ten iterations agree to the order in which partial sums are
+    folded."""
+    torch = torch_cuda
+    if case == "cube_256":
+        prob = schwz.Problem.laplacian(3, 256, 256, 256)
+        sd = schwz.Subdomain(prob, 1, 0, 2, schwz.partition_regular(prob.N, 1))
+    else:
+        prob = schwz.Problem.laplacian(3, 512, 512, 192)
+        sd = schwz.Subdomain(prob, 3, 1, 2, schwz.partition_regular(prob.N, 3))
+    rp, col, val = sd.local_matrix()
+    n = len(rp) - 1
+    A = schwz.Csr(rp, col, val)
+    del rp, col, val
+    assert A.format() == 3 and A.sweep_slots() > 0 and A.sweep_left_out() == 0
+    cg = schwz.Pcg(A, 1)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    b = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+    x0 = 0.1 * torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+
+    def solve(sweep, iters):
+        monkeypatch.setenv("SCHWZ_CG_SWEEP", sweep)
+        x = x0.clone()
+        it, rn = cg.solve(b.data_ptr(), x.data_ptr(), 0.0, iters)
+        return rn, x
+
+    rn0, x_ref = solve("0", 1)
+    assert cg.flavour() & 24 == 0
+    rn1, x_sw = solve("1", 1)
+    assert cg.flavour() & 24 == 24
+    assert torch.equal(x_ref, x_sw) and abs(rn0 - rn1) <= 1e-13 * rn0
+    rn0, x_ref = solve("0", 10)
+    rn1, x_sw = solve("1", 10)
+    assert float((x_ref - x_sw).abs().max()) <= 1e-12 * float(x_ref.abs().max())
+    assert abs(rn0 - rn1) <= 1e-10 * rn0
