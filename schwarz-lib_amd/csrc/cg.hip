@@ -221,6 +221,24 @@ __global__ __launch_bounds__(kBlock) void cg_direction_kernel(int64_t n, double 
     }
 }
 
+// What workgroup 0 of cg_direction_kernel does, alone: the LAST iteration of a solve needs the state
+// (rho, ||r||^2, the iteration count the deferred x update goes by) but no new search direction --
+// 24 n bytes and 0.067 ms at 256^3 that nobody reads.
+__global__ __launch_bounds__(kBlock) void cg_state_advance_kernel(const double *partials_in, int nparts, CgState *st,
+                                                                   int it, double rtol)
+{
+    __shared__ double red[4];
+    if (it >= st->stop_iter) return;
+    const double rho_new = fold_partials(partials_in, nparts, red);
+    const double rr = fold_partials(partials_in + nparts, nparts, red);
+    if (threadIdx.x == 0) {
+        st->rho[(it + 1) & 1] = rho_new;
+        st->rr = rr;
+        st->iters = st->iters + 1;
+        if (sqrt(rr) <= rtol * st->r0) st->stop_iter = 0;
+    }
+}
+
 // Measured on MI355X (256^3): U = 2/4 and non-temporal stores change the PCG iteration time by
 // < 1 % (0.403 / 0.406 / 0.417 ms for U = 1 / 2 / 4): these kernels sit at the mixed
 // read+write HBM ceiling (~5.0-5.5 TB/s), so the plain shape is used.
@@ -779,6 +797,90 @@ static bool pcg_is_general(const schwz_pcg *s)
            s->precond == SCHWZ_PRECOND_ISAI;
 }
 
+// How a solve on this system iterates (decided once per solve, the same way in pcg_begin and pcg_iterate).
+struct CgPlan {
+    bool qfree = false;         // row-pair coded matrix: q = A p is recomputed, never stored
+    int dot_mode = kSpmvDot;    // launch that yields p.(A p)
+    bool sweep_on = false;      // z-sweep walk of the update launch
+    bool sweep_dirdot = false;  // ... and of the fused direction + p.(A p) launch
+    bool fusedir = false;       // two launches per iteration
+    bool deferx = false;        // x += sum alpha_k p_k applied once per kDeferDepth iterations
+    bool sweep_start = false;   // the solve can start in the walk too (INIT / FIRST forms, spmv_pair.hip)
+    int flavour = 0;
+};
+
+static CgPlan pcg_plan(schwz_pcg *s)
+{
+    CgPlan pl;
+    const CsrView &A = s->A->v;
+    const int64_t n = s->n;
+    const int gs = spmv_grid(A, s->variant);
+    const bool general = pcg_is_general(s);
+    // SCHWZ_CG_QFREE=0 keeps the stored-q iteration for row-pair coded matrices too (A/B runs)
+    static const bool qfree_on = [] {
+        const char *e = std::getenv("SCHWZ_CG_QFREE");
+        return !(e && e[0] == '0');
+    }();
+    pl.qfree = qfree_on && !general && A.pair_id && s->variant == 0 && s->diag.mode != 2;
+    // p.(A p) from the upper triangle when the upload found the matrix symmetric (SCHWZ_CG_SYM=0: full rows)
+    static const bool sym_on = [] {
+        const char *e = std::getenv("SCHWZ_CG_SYM");
+        return !(e && e[0] == '0');
+    }();
+    pl.dot_mode = !pl.qfree ? kSpmvDot : (sym_on && A.pair_sym_base > 0 ? kSpmvDotSym : kSpmvDotOnly);
+    // Two launches per iteration: the direction update and the NEXT iteration's p.(A p) share one
+    // launch (kSpmvDirDotSym), p alternating between two buffers (a launch that recomputes its
+    // neighbours' new p must not overwrite the old one): s->p and the otherwise unused s->q, or the
+    // slots of the deferred-x ring.  The first p.(A p) of a solve is launched on its own.
+    // On launch-bound systems (up to kGraphRows rows) this is -11 to -13 % per outer iteration.  On
+    // large ones the fused launch costs what the two it replaces cost -- 0.102 vs 0.067 + 0.045 ms on the
+    // 256^3 cube (+1 % on the bench line), 0.111 vs 0.067 + 0.043 ms on the 512 x 512 x 64 slab of the
+    // multi-GPU runs (-1 %) -- so they keep three launches.  SCHWZ_CG_FUSEDIR=0: never, =2: every size
+    // (it combines with the deferred x update).
+    static const int fusedir_mode = [] {
+        const char *e = std::getenv("SCHWZ_CG_FUSEDIR");
+        return e ? std::atoi(e) : 1;
+    }();
+    const char *dx_env = std::getenv("SCHWZ_CG_DEFERX");  // read per solve: tests switch it
+    const int dx_mode = dx_env ? std::atoi(dx_env) : 1;
+    // ... unless the matrix takes the z-sweep walk (spmv_pair.hip): there the fused launch loads every
+    // element of r and p once instead of gathering both at every entry, and replaces 32 n bytes of the
+    // two launches by 24 n (SCHWZ_CG_SWEEP=0: chunk-by-chunk launches only).
+    const char *sweep_env = std::getenv("SCHWZ_CG_SWEEP");
+    pl.sweep_on = !(sweep_env && sweep_env[0] == '0') && A.sweep_nslots > 0 && s->variant == 0 &&
+                  A.ncols < (int64_t(1) << 28) && A.sweep_nslots + A.sweep_gen_blocks <= gs;
+    pl.sweep_dirdot = pl.sweep_on && A.canon_sym_val && (s->diag.mode == 0 || s->diag.mode == 3);
+    pl.fusedir = pl.dot_mode == kSpmvDotSym &&
+                 (fusedir_mode == 2 || (fusedir_mode == 1 && (n <= kGraphRows || pl.sweep_dirdot)));
+    pl.flavour = !pl.qfree ? 0 : (pl.fusedir ? 2 : 1);
+    // Large systems: x is not touched inside the iteration.  The search directions of up to
+    // kDeferDepth iterations stay in a ring (slots 0 and 1 are s->p and the otherwise unused s->q),
+    // the update launch stores alpha_k instead of updating x, and one launch per kDeferDepth
+    // iterations (and one at the end) applies x += sum_k alpha_k p_k in iteration order -- the same
+    // bits, (depth + 2) / depth vectors of traffic per iteration instead of 2.
+    // SCHWZ_CG_DEFERX=0: never, =2: every size (tests).
+    pl.deferx = pl.qfree && !s->ring_failed && (dx_mode == 2 || (dx_mode == 1 && n > kGraphRows));
+    if (pl.deferx && !s->p_ring) {
+        const size_t nb = (size_t)((n + 1) & ~int64_t(1)) * sizeof(double);
+        if (hipMalloc((void **)&s->p_ring, nb * (kDeferDepth - 2)) != hipSuccess ||
+            hipMalloc((void **)&s->alpha_hist, kDeferDepth * sizeof(double)) != hipSuccess) {
+            (void)hipGetLastError();  // not enough memory for the ring: the plain iteration
+            (void)hipFree(s->p_ring);
+            s->p_ring = nullptr;
+            s->ring_failed = true;
+            pl.deferx = false;
+        }
+    }
+    // A solve whose iterations all run in the walk starts in it as well: the start launch takes the walk
+    // (32 n -> 24 n bytes: p is not stored) and the first p.(A p) comes from the FIRST form of the fused
+    // direction launch, which builds p = D^-1 r from the r it reads anyway (SCHWZ_CG_SWEEPSTART=0: the
+    // chunk-by-chunk start launch + kSpmvDotSym).
+    const char *start_env = std::getenv("SCHWZ_CG_SWEEPSTART");
+    pl.sweep_start = !(start_env && start_env[0] == '0') && pl.deferx && pl.sweep_dirdot && pl.fusedir &&
+                     pair_sweep_start_ok(A, gs);
+    return pl;
+}
+
 // First half of a solve: r = b - A x, p = M^-1 r, rho, ||r||^2 -> CgState.  With
 // `fused` the same pass over the matrix also yields ||b - A x2||^2 over the rows
 // below row_limit in s->d_norm_sq[0] (x2 == nullptr: x2 is x).
@@ -804,6 +906,15 @@ int pcg_begin(schwz_pcg *s, const double *d_b, double *d_x, double rtol, bool fu
         a.dinv = nullptr;
         a.diag_mode = 3;
         a.diag_uniform = s->diag.uniform;
+    }
+    // the start launch in the z-sweep walk where the whole solve runs in it (not with the second product of
+    // the fused check residual, which the walk does not have)
+    s->p_pending = false;
+    const bool walk_start = !(fused && !same) && !pcg_is_general(s) && (a.diag_mode == 3 || !a.dinv);
+    if (walk_start && pcg_plan(s).sweep_start) {
+        a.sweep_init = 1;
+        a.p = nullptr;
+        s->p_pending = true;
     }
     int rc = launch_spmv(A, (fused && !same) ? kSpmvResidDual : kSpmvResidInit, a, s->variant, st);
     if (rc) return rc;
@@ -841,63 +952,12 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
     double *part_vec = s->partials + 3 * kMaxGrid;  // [2][gv]
     const bool poll = rtol > 0.0;
     const bool general = pcg_is_general(s);
-    // SCHWZ_CG_QFREE=0 keeps the stored-q iteration for row-pair coded matrices too (A/B runs)
-    static const bool qfree_on = [] {
-        const char *e = std::getenv("SCHWZ_CG_QFREE");
-        return !(e && e[0] == '0');
-    }();
-    const bool qfree = qfree_on && !general && A.pair_id && s->variant == 0 && s->diag.mode != 2;
-    // p.(A p) from the upper triangle when the upload found the matrix symmetric (SCHWZ_CG_SYM=0: full rows)
-    static const bool sym_on = [] {
-        const char *e = std::getenv("SCHWZ_CG_SYM");
-        return !(e && e[0] == '0');
-    }();
-    const int dot_mode = !qfree ? kSpmvDot : (sym_on && A.pair_sym_base > 0 ? kSpmvDotSym : kSpmvDotOnly);
-    // Two launches per iteration: the direction update and the NEXT iteration's p.(A p) share one
-    // launch (kSpmvDirDotSym), p alternating between two buffers (a launch that recomputes its
-    // neighbours' new p must not overwrite the old one): s->p and the otherwise unused s->q, or the
-    // slots of the deferred-x ring.  The first p.(A p) of a solve is launched on its own below.
-    // On launch-bound systems (up to kGraphRows rows) this is -11 to -13 % per outer iteration.  On
-    // large ones the fused launch costs what the two it replaces cost -- 0.102 vs 0.067 + 0.045 ms on the
-    // 256^3 cube (+1 % on the bench line), 0.111 vs 0.067 + 0.043 ms on the 512 x 512 x 64 slab of the
-    // multi-GPU runs (-1 %) -- so they keep three launches.  SCHWZ_CG_FUSEDIR=0: never, =2: every size
-    // (it combines with the deferred x update).
-    static const int fusedir_mode = [] {
-        const char *e = std::getenv("SCHWZ_CG_FUSEDIR");
-        return e ? std::atoi(e) : 1;
-    }();
-    const char *dx_env = std::getenv("SCHWZ_CG_DEFERX");  // read per solve: tests switch it
-    const int dx_mode = dx_env ? std::atoi(dx_env) : 1;
-    // ... unless the matrix takes the z-sweep walk (spmv_pair.hip): there the fused launch loads every
-    // element of r and p once instead of gathering both at every entry, and replaces 32 n bytes of the
-    // two launches by 24 n (SCHWZ_CG_SWEEP=0: chunk-by-chunk launches only).
-    const char *sweep_env = std::getenv("SCHWZ_CG_SWEEP");
-    const bool sweep_on = !(sweep_env && sweep_env[0] == '0') && A.sweep_nslots > 0 && s->variant == 0 &&
-                          A.ncols < (int64_t(1) << 28) && A.sweep_nslots + A.sweep_gen_blocks <= gs;
-    const bool sweep_dirdot = sweep_on && A.canon_sym_val && (s->diag.mode == 0 || s->diag.mode == 3);
-    const bool fusedir = dot_mode == kSpmvDotSym &&
-                         (fusedir_mode == 2 || (fusedir_mode == 1 && (n <= kGraphRows || sweep_dirdot)));
-    const int flavour = !qfree ? 0 : (fusedir ? 2 : 1);
-    // Large systems: x is not touched inside the iteration.  The search directions of up to
-    // kDeferDepth iterations stay in a ring (slots 0 and 1 are s->p and the otherwise unused s->q),
-    // the update launch stores alpha_k instead of updating x, and one launch per kDeferDepth
-    // iterations (and one at the end) applies x += sum_k alpha_k p_k in iteration order -- the same
-    // bits, (depth + 2) / depth vectors of traffic per iteration instead of 2.
-    // SCHWZ_CG_DEFERX=0: never, =2: every size (tests).
-    bool deferx = qfree && !s->ring_failed && (dx_mode == 2 || (dx_mode == 1 && n > kGraphRows));
-    if (deferx && !s->p_ring) {
-        const size_t nb = (size_t)((n + 1) & ~int64_t(1)) * sizeof(double);
-        if (hipMalloc((void **)&s->p_ring, nb * (kDeferDepth - 2)) != hipSuccess ||
-            hipMalloc((void **)&s->alpha_hist, kDeferDepth * sizeof(double)) != hipSuccess) {
-            (void)hipGetLastError();  // not enough memory for the ring: the plain iteration
-            (void)hipFree(s->p_ring);
-            s->p_ring = nullptr;
-            s->ring_failed = true;
-            deferx = false;
-        }
-    }
+    const CgPlan plan = pcg_plan(s);
+    const bool qfree = plan.qfree, sweep_on = plan.sweep_on, sweep_dirdot = plan.sweep_dirdot, fusedir = plan.fusedir;
+    const bool deferx = plan.deferx;
+    const int dot_mode = plan.dot_mode, flavour = plan.flavour;
     s->last_flavour = flavour | (deferx ? 4 : 0) | (sweep_on && deferx && s->diag.mode != 2 ? 8 : 0) |
-                      (sweep_dirdot && fusedir ? 16 : 0);
+                      (sweep_dirdot && fusedir ? 16 : 0) | (s->p_pending ? 32 : 0);
     PRing ring;
     const int64_t n_pad = (n + 1) & ~int64_t(1);
     for (int k = 0; k < kDeferDepth; ++k)
@@ -908,6 +968,9 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
                            count, pending);
     };
     double *const pbuf[2] = {s->p, fusedir ? s->q : s->p};
+    // SCHWZ_CG_LASTDIR=1: the last iteration of a solve updates the search direction like every other one
+    const char *ld_env = std::getenv("SCHWZ_CG_LASTDIR");
+    const bool last_state_only = !(ld_env && ld_env[0] == '1');
     // one CG iteration on stream `q`; `it` only enters through its parity (rho slot) and through
     // "it >= stop_iter", and stop_iter is 0 once the tolerance test has fired: a recorded sequence
     // of an even number of iterations can therefore be replayed as a hipGraph
@@ -985,8 +1048,11 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
                 // the ring is full: apply its kDeferDepth increments before slot (it + 1) % depth,
                 // the oldest direction, is overwritten
                 if ((it + 1) % kDeferDepth == 0) flush_x(it + 1 - kDeferDepth, kDeferDepth, it, q);
-                hipLaunchKernelGGL((cg_direction_kernel<1, false>), dim3(gv), dim3(kBlock), 0, q, n, slot(it), s->r,
-                                   s->diag, part_vec, gs, s->state, it, rtol, slot(it + 1));
+                if (instrument && it == max_iters - 1 && last_state_only)  // nobody reads the direction after the last iteration
+                    hipLaunchKernelGGL(cg_state_advance_kernel, dim3(1), dim3(kBlock), 0, q, part_vec, gs, s->state, it, rtol);
+                else
+                    hipLaunchKernelGGL((cg_direction_kernel<1, false>), dim3(gv), dim3(kBlock), 0, q, n, slot(it), s->r,
+                                       s->diag, part_vec, gs, s->state, it, rtol, slot(it + 1));
             } else {
                 hipLaunchKernelGGL((cg_direction_kernel<1, false>), dim3(gv), dim3(kBlock), 0, q, n, pbuf[it & 1], s->r,
                                    s->diag, part_vec, gs, s->state, it, rtol);
@@ -1043,16 +1109,33 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
             (void)hipGetLastError();
         }
     }
+    if (s->p_pending && !(fusedir && plan.sweep_start)) {
+        set_error("pcg_iterate: the start launch left p to a first-direction launch this solve does not run");
+        return SCHWZ_ERR_INVALID;
+    }
     if (fusedir && max_iters > 0) {
         // p0.(A p0): every later p.(A p) comes out of the fused direction launch
         SpmvArgs a;
-        a.x = s->p;
         a.partials = part_spmv;
-        a.stop_iter = &s->state->stop_iter;
         a.it = 0;
-        int rc = launch_spmv(A, kSpmvDotSym, a, s->variant, st);
+        int rc;
+        if (s->p_pending) {
+            // z-sweep start: p0 = D^-1 r0 is built here, from the r the launch reads anyway
+            a.y = slot(0);
+            a.cg_r = s->r;
+            a.cg_state = s->state;
+            a.diag_mode = s->diag.mode;
+            a.diag_uniform = s->diag.uniform;
+            a.sweep_first = 1;
+            rc = launch_spmv(A, kSpmvDirDotSym, a, s->variant, st);
+        } else {
+            a.x = s->p;
+            a.stop_iter = &s->state->stop_iter;
+            rc = launch_spmv(A, kSpmvDotSym, a, s->variant, st);
+        }
         if (rc) return rc;
     }
+    s->p_pending = false;
     int chunk = 16;
     int it = 0, pending = -1, bank = 0;
     bool stopped = false;

@@ -176,6 +176,10 @@ struct SpmvArgs {
     // CsrView::sweep_gen only; partial sums at [part_offset + blockIdx.x] of banks part_stride apart
     int sweep = 0;
     int part_offset = 0, part_stride = 0;
+    // kSpmvResidInit in the z-sweep walk (r stored, p left to the first direction launch), and that first
+    // direction launch (kSpmvDirDotSym: p' = D^-1 r, CgState untouched); pcg_begin / pcg_iterate set them
+    // where pair_sweep_start_ok holds
+    int sweep_init = 0, sweep_first = 0;
 };
 
 // launch grid of the streaming vector kernels: one lane per element up to kMaxGrid workgroups
@@ -199,6 +203,7 @@ int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipS
 int launch_spmv_dict(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s);
 int launch_spmv_pattern(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s);
 int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s);
+bool pair_sweep_start_ok(const CsrView &A, int grid);
 
 // Jacobi scaling as the CG vector kernels see it.  The full 1/diag vector costs 8 B per row and
 // per kernel; matrices with few distinct diagonal values (every stencil) get a 1-byte code per
@@ -308,8 +313,11 @@ struct schwz_pcg {
     double *p_ring = nullptr;      // kDeferDepth - 2 vectors; slots 0 and 1 of the ring are p and q
     double *alpha_hist = nullptr;  // kDeferDepth
     bool ring_failed = false;
+    // the start launch of the running solve left p to the first fused direction launch (z-sweep start)
+    bool p_pending = false;
     // how the last solve iterated: bits 0-1: 0 stored q, 1 q-free (three launches), 2 q-free with the fused
-    // direction + p.(A p) launch; 4: deferred x update; 8: z-sweep walk of the update launch; 16: of the fused launch
+    // direction + p.(A p) launch; 4: deferred x update; 8: z-sweep walk of the update launch; 16: of the fused launch;
+    // 32: of the start launch and the first direction as well
     int last_flavour = 0;
 };
 

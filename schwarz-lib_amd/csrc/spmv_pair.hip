@@ -583,8 +583,11 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
 // Products, order and presence masks are those of accumulate_canon: the same bits per row.
 // NL: 16-byte pieces of a window per lane; NH: chunks of 512 rows per band; DIAGVEC: Jacobi diagonal
 // as a full vector.  x is not touched (deferred x update only).
+// INIT: the same walk as the CG start launch (kSpmvResidInit without its p store): the ring holds the
+// windows of the start vector y, r = b - A y is stored to a.y, partial r.z and r.r -- p = D^-1 r is left
+// to the first fused direction launch (spmv_pair_dirdot_sweep_kernel<.., FIRST>), which reads r anyway.
 // ---------------------------------------------------------------------------------------------------
-template <int NHL, int NH, bool DIAGVEC>
+template <int NHL, int NH, bool DIAGVEC, bool INIT = false>
 __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, SpmvArgs a)
 {
 #pragma clang fp contract(off)
@@ -599,10 +602,18 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
     PairVal *const cpv = reinterpret_cast<PairVal *>(halo_ring + 4 * NX);
     int *const cmask = reinterpret_cast<int *>(cpv + A.canon_npat * 9);
     __shared__ double red[4];
-    if (a.it >= a.cg_state->stop_iter) return;
-    const double cg_alpha = a.cg_state->rho[a.it & 1] / fold_partials(a.pq_partials, a.pq_nparts, red);
+    double cg_alpha = 1.0;
     const int tid = threadIdx.x;
-    if (blockIdx.x == 0 && tid == 0 && a.alpha_out) *a.alpha_out = cg_alpha;
+    if (!INIT) {
+        if (a.it >= a.cg_state->stop_iter) return;
+        cg_alpha = a.cg_state->rho[a.it & 1] / fold_partials(a.pq_partials, a.pq_nparts, red);
+        if (blockIdx.x == 0 && tid == 0 && a.alpha_out) *a.alpha_out = cg_alpha;
+    }
+    // INIT reads the right-hand side where the update launch reads r (the caller's b need only be 8-byte
+    // aligned) and stores r to a.y
+    typedef double pvd2u __attribute__((ext_vector_type(2), aligned(8)));
+    const double *const r_in = INIT ? a.b : a.cg_r;
+    double *const r_out = INIT ? a.y : a.cg_r;
     for (int i = tid; i < A.canon_npat * 9; i += kBlock) cpv[i] = PairVal{A.canon_val[2 * i], A.canon_val[2 * i + 1]};
     if (tid < A.canon_npat) cmask[tid] = A.canon_mask[tid];
     // partial-sum slots no workgroup of this launch or of its companion writes
@@ -669,7 +680,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
             f.w1 = q[1];
             f.w2 = q[2];
             f.w3 = q[3];
-            f.r = __builtin_nontemporal_load(reinterpret_cast<const pvd2 *>(a.cg_r + ra));
+            f.r = __builtin_nontemporal_load(reinterpret_cast<const pvd2u *>(r_in + ra));
             if (DIAGVEC) f.d = __builtin_nontemporal_load(reinterpret_cast<const pvd2 *>(a.dinv + ra));
             return f;
         };
@@ -758,16 +769,16 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
                 for (int k = 2; k < 8; ++k) add(k, t[k]);
                 if (far & 0xc0) add(8, *reinterpret_cast<const pvd2 *>(fa1 + i0));
                 // r -= alpha q ; z = D^-1 r ; partial r.z and r.r  (kSpmvCgUpdate's epilogue, x deferred)
-                const double r0 = f.r.x - cg_alpha * s0;
+                const double r0 = INIT ? f.r.x - s0 : f.r.x - cg_alpha * s0;
                 const double zz0 = a.diag_mode ? (DIAGVEC ? f.d.x : a.diag_uniform) * r0 : r0;
                 acc0 += r0 * zz0;
                 acc1 += r0 * r0;
-                const double r1 = f.r.y - cg_alpha * s1;
+                const double r1 = INIT ? f.r.y - s1 : f.r.y - cg_alpha * s1;
                 const double zz1 = a.diag_mode ? (DIAGVEC ? f.d.y : a.diag_uniform) * r1 : r1;
                 acc0 += r1 * zz1;
                 acc1 += r1 * r1;
                 const pvd2 rn = {r0, r1};
-                __builtin_nontemporal_store(rn, reinterpret_cast<pvd2 *>(a.cg_r + ra));
+                __builtin_nontemporal_store(rn, reinterpret_cast<pvd2 *>(r_out + ra));
                 rr[h] = fetch(rbase, h);
             }
 #pragma unroll
@@ -798,8 +809,10 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
 // launch gathers r AND p at every entry; here every element of r and p is loaded once (plus the NX-row
 // halo, L2 hits).  Same expression for p' everywhere, same products in the same order: the same bits per
 // row.  Workgroup 0 advances CgState like cg_direction_kernel.  NHL / NH as above.
+// FIRST: the first direction of a solve whose start launch was the INIT walk above: p' = z (nothing is
+// read from p, beta does not exist yet), the partial sums of p'.(A p'), CgState untouched.
 // ---------------------------------------------------------------------------------------------------
-template <int NHL, int NH>
+template <int NHL, int NH, bool FIRST = false>
 __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView A, SpmvArgs a)
 {
 #pragma clang fp contract(off)
@@ -812,9 +825,12 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
     int *const cmask = reinterpret_cast<int *>(cpv + A.canon_npat * 5);
     __shared__ double red[4];
     if (a.it >= a.cg_state->stop_iter) return;
-    const double cg_rho_new = fold_partials(a.pq_partials, a.pq_nparts, red);
-    const double cg_rr = fold_partials(a.pq_partials + a.pq_nparts, a.pq_nparts, red);
-    const double cg_beta = cg_rho_new / a.cg_state->rho[a.it & 1];
+    double cg_rho_new = 0.0, cg_rr = 0.0, cg_beta = 0.0;
+    if (!FIRST) {
+        cg_rho_new = fold_partials(a.pq_partials, a.pq_nparts, red);
+        cg_rr = fold_partials(a.pq_partials + a.pq_nparts, a.pq_nparts, red);
+        cg_beta = cg_rho_new / a.cg_state->rho[a.it & 1];
+    }
     const int tid = threadIdx.x;
     for (int i = tid; i < A.canon_npat * 5; i += kBlock) cpv[i] = PairVal{A.canon_sym_val[2 * i], A.canon_sym_val[2 * i + 1]};
     if (tid < A.canon_npat) cmask[tid] = A.canon_sym_mask[tid];
@@ -841,6 +857,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
         // p' at one 16-byte piece: the expression of dir2 / cg_direction_kernel
         auto newp = [&](pvd2 rv, pvd2 pv) -> pvd2 {
             const pvd2 zv = a.diag_mode ? du * rv : rv;
+            if (FIRST) return zv;
             pvd2 o;
             o.x = __builtin_fma(cg_beta, pv.x, zv.x);
             o.y = __builtin_fma(cg_beta, pv.y, zv.y);
@@ -857,7 +874,10 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
             for (int k = 0; k < NH; ++k) {
                 const int g = clampg(base + 2 * (tid + k * kBlock));
                 o.r[k] = __builtin_nontemporal_load(reinterpret_cast<const pvd2 *>(a.cg_r + g));
-                __builtin_memcpy(&o.p[k], a.x + g, 16);
+                if (FIRST)
+                    o.p[k] = o.r[k];
+                else
+                    __builtin_memcpy(&o.p[k], a.x + g, 16);
             }
         };
         // p' of the band at a position: to the ring, and to the output vector where the position belongs to
@@ -878,7 +898,10 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
                 const int pc = min(tid + k * kBlock, NX / 2 - 1);
                 const int g = clampg(up + 2 * pc);
                 __builtin_memcpy(&hh.r[k], a.cg_r + g, 16);
-                __builtin_memcpy(&hh.p[k], a.x + g, 16);
+                if (FIRST)
+                    hh.p[k] = hh.r[k];
+                else
+                    __builtin_memcpy(&hh.p[k], a.x + g, 16);
             }
         };
         auto store_halo = [&](int z, const Halo &hh) {
@@ -981,7 +1004,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
         a.partials[blockIdx.x] = s0;
         a.partials[a.part_stride + blockIdx.x] = 0.0;
     }
-    if (blockIdx.x == 0 && tid == 0) {
+    if (!FIRST && blockIdx.x == 0 && tid == 0) {
         // what cg_direction_kernel's workgroup 0 does (see the chunk-by-chunk kernel's epilogue)
         CgState *st = const_cast<CgState *>(a.cg_state);
         st->rho[(a.it + 1) & 1] = cg_rho_new;
@@ -991,9 +1014,77 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
     }
 }
 
+// whether a solve on this matrix can START in the z-sweep walk: the INIT form of the update walk and the
+// FIRST form of the fused direction walk exist for the shapes below, and only where the walk covers
+// every row (no companion launch: cubes and z-slab subdomains)
+bool pair_sweep_start_ok(const CsrView &A, int grid)
+{
+    if (!(A.pair_single && A.sweep_nslots > 0 && A.canon_sym_val && A.sweep_gen_blocks == 0 && A.sweep_nslots <= grid &&
+          A.ncols < (int64_t(1) << 28)))
+        return false;
+    const int nh = A.sweep_T / kPairRows;
+    const int nhl_upd = (A.sweep_nx + kBlock - 1) / kBlock, nhl_dir = (A.sweep_nx / 2 + kBlock - 1) / kBlock;
+    return (nh == 1 || nh == 2) && nhl_upd <= 4 && nhl_dir <= 2;
+}
+
 int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s)
 {
     const bool wide = A.ncols >= (int64_t(1) << 28);  // byte offsets of x beyond 32 bits
+    if (mode == kSpmvResidInit && a.sweep_init) {
+        // CG start in the z-sweep walk (pcg_begin asks for it only where pair_sweep_start_ok holds and the
+        // Jacobi diagonal is a scalar or absent): r = b - A x to a.y, partial r.z and r.r; p is not written
+        if (!pair_sweep_start_ok(A, grid) || a.diag_mode == 1 || a.diag_mode == 2 || a.dinv) {
+            set_error("launch_spmv_pair: the z-sweep start launch does not apply to this matrix");
+            return SCHWZ_ERR_INVALID;
+        }
+        const int nhl = (A.sweep_nx + kBlock - 1) / kBlock, nh = A.sweep_T / kPairRows;
+        const size_t lds = (size_t)(4 * A.sweep_T + 4 * A.sweep_nx) * sizeof(double) + (size_t)A.canon_npat * (9 * 16 + 4);
+        SpmvArgs b = a;
+        b.part_stride = grid;
+        b.part_offset = 0;
+#define SCHWZ_SWEEP_INIT(L_, H_)                                                                                          \
+    {                                                                                                                    \
+        static const hipError_t e0 = hipFuncSetAttribute((const void *)spmv_pair_sweep_kernel<L_, H_, false, true>,      \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);          \
+        (void)e0;                                                                                                        \
+        hipLaunchKernelGGL((spmv_pair_sweep_kernel<L_, H_, false, true>), dim3(A.sweep_nslots), dim3(kBlock), lds, s, A, b); \
+    }
+        if (nh == 1 && nhl == 1) SCHWZ_SWEEP_INIT(1, 1)
+        else if (nh == 1 && nhl == 2) SCHWZ_SWEEP_INIT(2, 1)
+        else if (nh == 2 && nhl == 1) SCHWZ_SWEEP_INIT(1, 2)
+        else if (nh == 2 && nhl == 2) SCHWZ_SWEEP_INIT(2, 2)
+        else if (nh == 1) SCHWZ_SWEEP_INIT(4, 1)
+        else SCHWZ_SWEEP_INIT(4, 2)
+#undef SCHWZ_SWEEP_INIT
+        SCHWZ_HIP_TRY(hipGetLastError());
+        return SCHWZ_OK;
+    }
+    if (mode == kSpmvDirDotSym && a.sweep_first) {
+        // first direction of such a solve: p' = D^-1 r and the partial sums of p'.(A p'), CgState untouched
+        if (!pair_sweep_start_ok(A, grid) || a.diag_mode == 1 || a.diag_mode == 2) {
+            set_error("launch_spmv_pair: the z-sweep first-direction launch does not apply to this matrix");
+            return SCHWZ_ERR_INVALID;
+        }
+        const int nhl = (A.sweep_nx / 2 + kBlock - 1) / kBlock, nh = A.sweep_T / kPairRows;
+        const size_t lds = (size_t)(4 * A.sweep_T + 2 * A.sweep_nx) * sizeof(double) + (size_t)A.canon_npat * (5 * 16 + 4);
+        SpmvArgs b = a;
+        b.part_stride = grid;
+        b.part_offset = 0;
+#define SCHWZ_DIRDOT_FIRST(L_, H_)                                                                                        \
+    {                                                                                                                    \
+        static const hipError_t e0 = hipFuncSetAttribute((const void *)spmv_pair_dirdot_sweep_kernel<L_, H_, true>,      \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);          \
+        (void)e0;                                                                                                        \
+        hipLaunchKernelGGL((spmv_pair_dirdot_sweep_kernel<L_, H_, true>), dim3(A.sweep_nslots), dim3(kBlock), lds, s, A, b); \
+    }
+        if (nh == 1 && nhl == 1) SCHWZ_DIRDOT_FIRST(1, 1)
+        else if (nh == 1) SCHWZ_DIRDOT_FIRST(2, 1)
+        else if (nhl == 1) SCHWZ_DIRDOT_FIRST(1, 2)
+        else SCHWZ_DIRDOT_FIRST(2, 2)
+#undef SCHWZ_DIRDOT_FIRST
+        SCHWZ_HIP_TRY(hipGetLastError());
+        return SCHWZ_OK;
+    }
     if (mode == kSpmvCgUpdate && !wide && A.pair_single && A.sweep_nslots > 0 && !a.cg_x && a.diag_mode != 2 &&
         A.sweep_nslots + A.sweep_gen_blocks <= grid) {
         const char *sweep_env = std::getenv("SCHWZ_CG_SWEEP");  // read per launch: tests switch it

@@ -718,12 +718,31 @@ def test_z_sweep_update_launch_matches_the_gather_walk(schwz, oracle, torch_cuda
     assert A.sweep_left_out() == 0
     cg = schwz.Pcg(A, 1)
 
-    def solve(sweep, defer, iters, rtol=0.0):
+    def solve(sweep, defer, iters, rtol=0.0, start="0"):
         monkeypatch.setenv("SCHWZ_CG_SWEEP", sweep)
         monkeypatch.setenv("SCHWZ_CG_DEFERX", defer)
+        monkeypatch.setenv("SCHWZ_CG_SWEEPSTART", start)
         d_b, d_x = _dev(torch, b), _dev(torch, x0)
         it, rn = cg.solve(d_b.data_ptr(), d_x.data_ptr(), rtol, iters)
         return it, rn, d_x.cpu().numpy()
+
+    # the solve started in the walk as well (start residual in the INIT form of the update walk, p0 = D^-1 r0
+    # and p0.(A p0) from the FIRST form of the fused launch): the same rows, but rho0 is folded from other
+    # partial sums, so x agrees to rounding instead of bit for bit
+    for iters in (1, 2, 7, 20):
+        _, rn0, x_ref = solve("1", "2", iters)
+        assert cg.flavour() & 32 == 0
+        _, rn1, x_st = solve("1", "2", iters, start="1")
+        assert cg.flavour() & 56 == 56, cg.flavour()
+        assert np.abs(x_ref - x_st).max() <= 1e-12 * np.abs(x_ref).max(), iters
+        assert abs(rn0 - rn1) <= 1e-10 * rn0
+    it0, rn0, x_ref = solve("1", "2", n, 1e-9)
+    it1, rn1, x_st = solve("1", "2", n, 1e-9, start="1")
+    assert abs(it0 - it1) <= 1 and np.abs(x_ref - x_st).max() <= 1e-8 * np.abs(x_ref).max()
+    # zero iterations: the start launch alone (residual norm), x untouched
+    it0, rn0, x_ref = solve("1", "2", 0)
+    it1, rn1, x_st = solve("1", "2", 0, start="1")
+    assert it0 == it1 == 0 and abs(rn0 - rn1) <= 1e-13 * rn0 and np.array_equal(x_ref, x_st)
 
     for defer in ("0", "2"):
         it0, rn0, x_ref = solve("0", defer, 1)
