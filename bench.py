@@ -364,9 +364,9 @@ def main():
     spmv_name = {3: "spmv_pair_kernel<kSpmvDot> (q = A p, fused p.q; row-pair pattern coded CSR)",
                  2: "spmv_pattern_kernel<kSpmvDot> (q = A p, fused p.q; row-pattern coded CSR tiles)",
                  1: "spmv_dict_kernel<kSpmvDot> (q = A p, fused p.q; dictionary-coded CSR tiles)",
-                 0: "spmv_tiled2_kernel<kSpmvDot> (q = A p, fused p.q; plain CSR)"}[fmt]
+                 0: "spmv_stream_kernel<kSpmvDot> (q = A p, fused p.q; plain CSR, straight-line pipeline)"}[fmt]
     spmv_tag = {3: "spmv_pair_kernel<1,", 2: "spmv_pattern_kernel<1,", 1: "spmv_dict_kernel<1>",
-                0: "spmv_tiled2_kernel<1>"}[fmt]
+                0: "spmv_stream_kernel<1,"}[fmt]
     # bytes of the SpMV launch in its own format: the matrix once, x once, y once
     spmv_fmt_bytes = mat_bytes + 16 * n_rows
     if qfree:
@@ -485,7 +485,7 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 20
         line["roofline_csr_plain"] = {
-            "kernel": "spmv_tiled2_kernel<kSpmvPlain> (plain CSR, y = A x)", "bound": "hbm",
+            "kernel": "spmv_stream_kernel<kSpmvPlain> (plain CSR as stored, y = A x; spmv_stream.hip)", "bound": "hbm",
             "achieved": csr_spmv_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": csr_spmv_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": ms,
             "algorithmic_bytes_per_launch": csr_spmv_bytes,
@@ -523,7 +523,7 @@ def main():
         line["csr_plain_loop"] = {"value": a.steps / el6, "unit": "subdomain-iter/s",
                                   "ms_per_step": 1e3 * el6 / a.steps, "spmv_variant": 6,
                                   "note": "same workload and steps with the lossless matrix codings switched off: "
-                                          "plain CSR SpMV kernel, CG with a stored q (the general-matrix path)"}
+                                          "plain CSR SpMV kernel (spmv_stream_kernel), CG with a stored q (the general-matrix path)"}
         del s6
         torch.cuda.empty_cache()
     # time-to-residual(1e-6) at the authors' inexact setting (SURVEY 8d ii)

@@ -461,9 +461,24 @@ int schwz_csr_create(int64_t nrows, int64_t ncols, const schwz_idx *h_rp, const 
             return SCHWZ_ERR_INVALID;
         }
     }
+    // spmv_stream.hip: nonzero offset of every tile, and whether the straight-line kernel applies (every tile
+    // fits the 16-byte aligned window, no row longer than 32 entries)
+    std::vector<schwz_idx> tile_nz(tiles.size());
+    int stream_cap = 8;
+    {
+        int64_t longest = 0;
+        for (int64_t i = 0; i < nrows; ++i) longest = std::max<int64_t>(longest, h_rp[i + 1] - h_rp[i]);
+        for (size_t t = 0; t < tiles.size(); ++t) tile_nz[t] = h_rp[tiles[t]];
+        for (size_t t = 0; t + 1 < tiles.size(); ++t)
+            if ((tile_nz[t] & 3) + (tile_nz[t + 1] - tile_nz[t]) > kTileNnz || tiles[t + 1] - tiles[t] > kTileRows) stream_cap = 0;
+        if (longest > 32 || nrows == 0 || !order.empty()) stream_cap = 0;
+        else if (stream_cap && longest > 16) stream_cap = 32;
+        else if (stream_cap && longest > 8) stream_cap = 16;
+    }
     schwz_csr *A = new schwz_csr();
     int rc;
-    if ((rc = upload(h_rp, (size_t)nrows + 1, &A->d_rp)) || (rc = upload(h_col, (size_t)nnz, &A->d_col, 4)) ||
+    if ((rc = upload(tile_nz.data(), tile_nz.size(), &A->d_tile_nz)) ||
+        (rc = upload(h_rp, (size_t)nrows + 1, &A->d_rp)) || (rc = upload(h_col, (size_t)nnz, &A->d_col, 4)) ||
         (rc = upload(h_val, (size_t)nnz, &A->d_val, 4)) || (rc = upload(tiles.data(), tiles.size(), &A->d_tile)) ||
         (rc = upload(wtiles.data(), wtiles.size(), &A->d_wtile)) ||
         (!order.empty() && (rc = upload(order.data(), order.size(), &A->d_order)))) {
@@ -479,6 +494,8 @@ int schwz_csr_create(int64_t nrows, int64_t ncols, const schwz_idx *h_rp, const 
     A->v.ntiles = (int)tiles.size() - 1;
     A->h_tiles = tiles;
     A->v.tile_row = (const schwz_idx *)A->d_tile;
+    A->v.tile_nz = (const schwz_idx *)A->d_tile_nz;
+    A->v.stream_cap = stream_cap;
     A->v.tile_order = order.empty() ? nullptr : (const schwz_idx *)A->d_order;
     {
         // run length of the block-cyclic deal: 1/8 of the matrix bandwidth in tiles
@@ -525,6 +542,7 @@ void schwz_csr_destroy(schwz_csr *A)
     (void)hipFree(A->d_col);
     (void)hipFree(A->d_val);
     (void)hipFree(A->d_tile);
+    (void)hipFree(A->d_tile_nz);
     (void)hipFree(A->d_wtile);
     (void)hipFree(A->d_order);
     (void)hipFree(A->d_tile_dual);

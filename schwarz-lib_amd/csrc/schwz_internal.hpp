@@ -53,6 +53,10 @@ struct CsrView {
     int ntiles = 0;
     const schwz_idx *tile_row = nullptr;  // ntiles+1 row boundaries
     const schwz_idx *tile_order = nullptr;  // optional BFS visiting order (SCHWZ_TILE_ORDER=1)
+    // spmv_stream.hip: first nonzero of every tile (rp[tile_row[t]], ntiles+1 entries) and the masked-add count
+    // of its row sums (8 / 16 / 32 >= the longest row; 0: the matrix keeps spmv_tiled2_kernel)
+    const schwz_idx *tile_nz = nullptr;
+    int stream_cap = 0;
     int xcd_block = 0;  // tiles are dealt to the 8 XCDs block-cyclically in runs of this many (a power of two)
     int xcd_shift = 0;  // log2(xcd_block)
     // kSpmvResidDual: 1 where the tile's rows or columns reach past `dual_split` (where x2 may
@@ -203,6 +207,8 @@ int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipS
 int launch_spmv_dict(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s);
 int launch_spmv_pattern(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s);
 int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s);
+int launch_spmv_stream(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s, bool *done);
+int launch_spmv_stream_ablate(const CsrView &A, const SpmvArgs &a, int abl, hipStream_t s);
 bool pair_sweep_start_ok(const CsrView &A, int grid);
 
 // Jacobi scaling as the CG vector kernels see it.  The full 1/diag vector costs 8 B per row and
@@ -260,6 +266,7 @@ int pcg_last_stats(schwz_pcg *s, int *h_iters, double *h_resnorm);  // device sy
 struct schwz_csr {
     schwz::CsrView v;
     void *d_rp = nullptr, *d_col = nullptr, *d_val = nullptr, *d_tile = nullptr, *d_wtile = nullptr, *d_order = nullptr;
+    void *d_tile_nz = nullptr;
     void *d_code = nullptr, *d_vptr = nullptr, *d_dptr = nullptr, *d_vdict = nullptr, *d_ddict = nullptr;
     void *d_pat_id = nullptr, *d_tile_table = nullptr, *d_tbl_desc = nullptr, *d_tbl_len = nullptr, *d_tbl_val = nullptr,
          *d_tbl_delta = nullptr;

@@ -792,6 +792,7 @@ int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipS
     }
     if ((variant == 0 || variant == 8) && A.pat_id) return launch_spmv_pattern(A, mode, a, grid, s);
     if ((variant == 0 || variant == 7) && A.code) return launch_spmv_dict(A, mode, a, grid, s);
+    if (variant >= 80 && variant < 88 && mode == kSpmvPlain) return launch_spmv_stream_ablate(A, a, variant - 80, s);
     if (variant >= 10 && variant < 74 && mode == kSpmvPlain) {
         switch (variant - 10) {
 #define SCHWZ_ABL(W) \
@@ -829,6 +830,13 @@ int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipS
             break;
         }
     } else if (variant != 2) {
+        // variants 0 / 6: the straight-line pipeline of spmv_stream.hip where it applies (rows of at most 32
+        // entries, not the fused dual residual); variant 9 keeps spmv_tiled2_kernel for A/B runs
+        if (variant == 0 || variant == 6) {
+            bool done = false;
+            const int rc = launch_spmv_stream(A, mode, a, grid, s, &done);
+            if (rc || done) return rc;
+        }
         switch (mode) {
         case kSpmvPlain:
             hipLaunchKernelGGL(spmv_tiled2_kernel<kSpmvPlain>, dim3(grid), dim3(kBlock), 0, s, A, a);

@@ -178,7 +178,8 @@ def test_z_sweep_walk_at_bench_size_is_bit_identical_per_row(schwz, torch_cuda, 
     chained to the interior: nothing left to a companion launch).  One CG iteration -- every row's
     q_i = (A p)_i, the r update and x += alpha p -- gives the same bits with the walk and with the
     chunk-by-chunk gather launches; ten iterations agree to the order in which partial sums are
-    folded."""
+    folded.  A middle slab's solve inside the RAS loop starts with the fused dual residual, a stand-alone
+    solve (this test) in the walk (flavour bit 32)."""
     torch = torch_cuda
     if case == "cube_256":
         prob = schwz.Problem.laplacian(3, 256, 256, 256)
@@ -196,8 +197,9 @@ def test_z_sweep_walk_at_bench_size_is_bit_identical_per_row(schwz, torch_cuda, 
     b = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
     x0 = 0.1 * torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
 
-    def solve(sweep, iters):
+    def solve(sweep, iters, start="0"):
         monkeypatch.setenv("SCHWZ_CG_SWEEP", sweep)
+        monkeypatch.setenv("SCHWZ_CG_SWEEPSTART", start)
         x = x0.clone()
         it, rn = cg.solve(b.data_ptr(), x.data_ptr(), 0.0, iters)
         return rn, x
@@ -205,9 +207,15 @@ def test_z_sweep_walk_at_bench_size_is_bit_identical_per_row(schwz, torch_cuda, 
     rn0, x_ref = solve("0", 1)
     assert cg.flavour() & 24 == 0
     rn1, x_sw = solve("1", 1)
-    assert cg.flavour() & 24 == 24
+    assert cg.flavour() & 56 == 24
     assert torch.equal(x_ref, x_sw) and abs(rn0 - rn1) <= 1e-13 * rn0
+    # the solve STARTED in the walk as well (the default): rho_0 is folded from other partial sums, so one
+    # iteration agrees to rounding instead of bit for bit
+    rn2, x_st = solve("1", 1, start="1")
+    assert cg.flavour() & 56 == 56
+    assert float((x_ref - x_st).abs().max()) <= 1e-13 * float(x_ref.abs().max()) and abs(rn0 - rn2) <= 1e-13 * rn0
     rn0, x_ref = solve("0", 10)
-    rn1, x_sw = solve("1", 10)
-    assert float((x_ref - x_sw).abs().max()) <= 1e-12 * float(x_ref.abs().max())
-    assert abs(rn0 - rn1) <= 1e-10 * rn0
+    for start in ("0", "1"):
+        rn1, x_sw = solve("1", 10, start=start)
+        assert float((x_ref - x_sw).abs().max()) <= 1e-12 * float(x_ref.abs().max())
+        assert abs(rn0 - rn1) <= 1e-10 * rn0

@@ -88,6 +88,53 @@ def test_spmv_matches_oracle(schwz, oracle, torch_cuda, case, variant):
         assert np.abs(got - exp).max() <= RTOL_SPMV * max(scale, 1.0) * 50
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_len", [5, 8, 13, 16, 30, 32, 40])
+def test_plain_csr_stream_kernel_is_bit_identical_to_the_tiled_kernel(schwz, oracle, torch_cuda, monkeypatch, max_len):
+    """The straight-line plain-CSR kernel (spmv_stream.hip, variants 0 / 6 on matrices whose rows hold at most
+    32 entries) against spmv_tiled2_kernel (variant 9): same tiles, same products, same summation order, same
+    grid -- y bit for bit, and so the stored-q CG built on its fused modes (start residual, q = A p with the
+    partial p.q).  Ragged rows with empty ones (masked-add counts 8 / 16 / 32; rows of 40 keep the tiled
+    kernel), stencils with odd plane sizes, a matrix with a single tile."""
+    torch = torch_cuda
+    monkeypatch.setenv("SCHWZ_SPMV_PAIR", "0")
+    monkeypatch.setenv("SCHWZ_SPMV_PATTERN", "0")
+    monkeypatch.setenv("SCHWZ_SPMV_DICT", "0")
+    rng = np.random.default_rng(100 + max_len)
+    mats = [_ragged_matrix(rng, 7001, max_len), _ragged_matrix(rng, 130, max_len)]
+    if max_len == 8:
+        mats += [oracle.laplacian3d(37, 29, 23), oracle.laplacian2d(211)]
+    for rp, col, val in mats:
+        n = len(rp) - 1
+        A = schwz.Csr(rp, col, val)
+        assert A.format() == 0
+        x = rng.standard_normal(n)
+        d_x = _dev(torch, x)
+        ys = []
+        for variant in (6, 9, 0):
+            d_y = _dev(torch, np.zeros(n))
+            A.spmv(d_x.data_ptr(), d_y.data_ptr(), 1.0, 0.0, variant=variant)
+            torch.cuda.synchronize()
+            ys.append(d_y.cpu().numpy())
+        assert np.array_equal(ys[0], ys[1]) and np.array_equal(ys[0], ys[2])
+        exp = oracle.spmv(rp, col, val, x, 1.0, 0.0, np.zeros(n))
+        assert np.abs(ys[0] - exp).max() <= RTOL_SPMV * max(np.abs(exp).max(), 1.0) * 50
+    # the fused modes through CG on an SPD matrix (stored-q iteration: kSpmvResidInit, kSpmvDot)
+    rp, col, val = oracle.laplacian3d(37, 29, 23)
+    n = len(rp) - 1
+    b = rng.standard_normal(n)
+    x0 = 0.1 * rng.standard_normal(n)
+    A = schwz.Csr(rp, col, val)
+    assert A.format() == 0
+    cg = schwz.Pcg(A, 1)
+    d_b, d_x = _dev(torch, b), _dev(torch, x0)
+    it, rn = cg.solve(d_b.data_ptr(), d_x.data_ptr(), 0.0, 25)
+    assert it == 25 and cg.flavour() & 3 == 0
+    got = d_x.cpu().numpy()
+    exp, _, _ = oracle.pcg(rp, col, val, b, x0, 1, 0.0, 25)
+    assert np.abs(got - exp).max() <= RTOL_CG * np.abs(exp).max()
+
+
 def test_spmv_is_reproducible(schwz, oracle, torch_cuda):
     torch = torch_cuda
     rp, col, val = oracle.laplacian3d(40)

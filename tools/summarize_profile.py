@@ -23,7 +23,7 @@ import sys
 from collections import defaultdict
 
 TRACKED = ("spmv_pair_sweep_kernel<", "spmv_pair_dirdot_sweep_kernel<", "spmv_pair_kernel<8,", "spmv_pair_kernel<6,", "spmv_pair_kernel<7,", "spmv_pair_kernel<5,", "spmv_pair_kernel<1,", "spmv_pattern_kernel<1,",
-           "spmv_dict_kernel<1>", "spmv_tiled2_kernel<1>", "cg_update_kernel", "cg_direction_kernel")
+           "spmv_dict_kernel<1>", "spmv_tiled2_kernel<1>", "spmv_stream_kernel<1,", "cg_update_kernel", "cg_direction_kernel")
 
 
 def kernel_source_hash(root):
