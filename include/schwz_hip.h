@@ -154,7 +154,8 @@ void schwz_pcg_destroy(schwz_pcg *s);
 /* how the last solve iterated (bench.py needs it to name and price its launches): bits 0-1: 0 = q = A p
  * stored, 1 = q-free, three launches per iteration, 2 = q-free with the direction update fused into the
  * next iteration's p.(A p) launch (two launches); 4: x += sum alpha_k p_k deferred; 8 / 16: the update /
- * the fused launch walked the matrix in z-sweeps (csrc/spmv_pair.hip) */
+ * the fused launch walked the matrix in z-sweeps (csrc/spmv_pair.hip); 32: so did the start residual and
+ * the first direction of the solve */
 int schwz_pcg_flavour(const schwz_pcg *s);
 int schwz_pcg_solve(schwz_pcg *s, const double *d_b, double *d_x, double rtol,
                     int max_iters, int *h_iters, double *h_resnorm,

@@ -910,7 +910,9 @@ int pcg_begin(schwz_pcg *s, const double *d_b, double *d_x, double rtol, bool fu
     // the start launch in the z-sweep walk where the whole solve runs in it (not with the second product of
     // the fused check residual, which the walk does not have)
     s->p_pending = false;
-    const bool walk_start = !(fused && !same) && !pcg_is_general(s) && (a.diag_mode == 3 || !a.dinv);
+    // (with the second product of the fused check residual only where the upload built its plane flags)
+    const bool walk_start = !pcg_is_general(s) && (a.diag_mode == 3 || !a.dinv) &&
+                            (!(fused && !same) || pair_sweep_dual_ok(A, gs));
     if (walk_start && pcg_plan(s).sweep_start) {
         a.sweep_init = 1;
         a.p = nullptr;

@@ -126,6 +126,12 @@ struct CsrView {
     // window each far slot reads (2 bits per slot B0, B1, A0, A1: 0 none, 1 previous position, 2 next)
     const int *chain_plane = nullptr;
     const int *chain_far = nullptr;
+    // fused dual residual in the walk (pair_set_dual_split): 1 per chain position whose plane holds or couples
+    // to rows / columns >= the split (there b - A x2 may differ from b - A x); the chunks of those planes,
+    // walked chunk by chunk by a second small launch (kSpmvResidNorm, listed) -- nullptr / 0: not built
+    const int *chain_dual = nullptr;
+    const schwz_idx *dual_chunks = nullptr;
+    int dual_nchunks = 0, dual_blocks = 0;
 };
 
 // epilogues of the tiled SpMV kernel
@@ -177,7 +183,8 @@ struct SpmvArgs {
     // kSpmvCgUpdate with cg_x == nullptr: x is not touched, alpha is stored here instead (workgroup 0)
     double *alpha_out = nullptr;
     // set by launch_spmv_pair for the companion launch of the z-sweep walk: walk the chunks listed in
-    // CsrView::sweep_gen only; partial sums at [part_offset + blockIdx.x] of banks part_stride apart
+    // CsrView::sweep_gen only (2: CsrView::dual_chunks, kSpmvResidNorm); partial sums at
+    // [part_offset + blockIdx.x] of banks part_stride apart
     int sweep = 0;
     int part_offset = 0, part_stride = 0;
     // kSpmvResidInit in the z-sweep walk (r stored, p left to the first direction launch), and that first
@@ -210,6 +217,7 @@ int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hi
 int launch_spmv_stream(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s, bool *done);
 int launch_spmv_stream_ablate(const CsrView &A, const SpmvArgs &a, int abl, hipStream_t s);
 bool pair_sweep_start_ok(const CsrView &A, int grid);
+bool pair_sweep_dual_ok(const CsrView &A, int grid);
 
 // Jacobi scaling as the CG vector kernels see it.  The full 1/diag vector costs 8 B per row and
 // per kernel; matrices with few distinct diagonal values (every stencil) get a 1-byte code per
@@ -276,6 +284,8 @@ struct schwz_csr {
     void *d_pair_id = nullptr, *d_tile_ptable = nullptr, *d_ptbl_desc = nullptr, *d_ptbl_len = nullptr,
          *d_ptbl_val = nullptr, *d_ptbl_meta = nullptr, *d_chunk_dual = nullptr;
     void *d_tile_dual = nullptr;
+    void *d_chain_dual = nullptr, *d_dual_chunks = nullptr;
+    std::vector<int> h_chain_plane;  // host copy of CsrView::chain_plane (z-sweep walk built)
     std::vector<schwz_idx> h_tiles;  // host copy of the tile boundaries
     int pair_deal_shift = 0;         // log2 of the run length (in tiles) of the XCD deal the pair kernels derive theirs from
     double dict_fraction = 0.0;  // share of the nonzeros that are dictionary coded

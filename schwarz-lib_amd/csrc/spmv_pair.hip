@@ -392,12 +392,15 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
     if (SINGLE) stage_table(0);
     // listed walk: the chunks no z-sweep segment covers (CsrView::sweep_gen), the companion launch of
     // spmv_pair_sweep_kernel below; its partial sums go behind that kernel's (a.part_offset)
-    const bool listed = SINGLE && (MODE == kSpmvCgUpdate || MODE == kSpmvDirDotSym) && a.sweep != 0;
+    // (kSpmvResidNorm, a.sweep == 2: the chunks of the planes where the fused check residual needs its own
+    // product, CsrView::dual_chunks -- the second launch of a dual start in the walk)
+    const bool listed = SINGLE && (MODE == kSpmvCgUpdate || MODE == kSpmvDirDotSym || MODE == kSpmvResidNorm) && a.sweep != 0;
+    const bool dual_list = MODE == kSpmvResidNorm && a.sweep == 2;
     const int gen_first = listed ? (int)blockIdx.x : slot;
-    const int gen_count = listed ? A.sweep_ngen : slots;
+    const int gen_count = listed ? (dual_list ? A.dual_nchunks : A.sweep_ngen) : slots;
     const int gen_stride = listed ? (int)gridDim.x : per_xcd;
     for (int j = gen_first; j < gen_count; j += gen_stride) {
-        const int chunk = listed ? A.sweep_gen[j] : xcd_chunk(nchunks, sh, xcd, j);
+        const int chunk = listed ? (dual_list ? A.dual_chunks[j] : A.sweep_gen[j]) : xcd_chunk(nchunks, sh, xcd, j);
         if (chunk < 0) continue;
         const int tb = SINGLE ? 0 : A.chunk_ptable[chunk];
         const bool dual_t = dual && (!A.chunk_dual || A.chunk_dual[chunk]);
@@ -587,7 +590,10 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
 // windows of the start vector y, r = b - A y is stored to a.y, partial r.z and r.r -- p = D^-1 r is left
 // to the first fused direction launch (spmv_pair_dirdot_sweep_kernel<.., FIRST>), which reads r anyway.
 // ---------------------------------------------------------------------------------------------------
-template <int NHL, int NH, bool DIAGVEC, bool INIT = false>
+// DUAL (with INIT): third partial bank = sum of r_i^2 over the chain positions NOT flagged in chain_dual -- the
+// part of the fused check residual ||b - A x2||^2 that coincides with the start residual; the flagged planes
+// are added by a listed kSpmvResidNorm launch on x2 (launch_spmv_pair).
+template <int NHL, int NH, bool DIAGVEC, bool INIT = false, bool DUAL = false>
 __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, SpmvArgs a)
 {
 #pragma clang fp contract(off)
@@ -618,14 +624,16 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
     if (tid < A.canon_npat) cmask[tid] = A.canon_mask[tid];
     // partial-sum slots no workgroup of this launch or of its companion writes
     if (blockIdx.x == 0)
-        for (int i = (int)gridDim.x + a.part_offset + tid; i < a.part_stride; i += kBlock)
+        for (int i = (int)gridDim.x + a.part_offset + tid; i < a.part_stride; i += kBlock) {
             a.partials[i] = a.partials[a.part_stride + i] = 0.0;
+            if (DUAL) a.partials[2 * a.part_stride + i] = 0.0;
+        }
     lds_barrier();
     const int4 sg = A.sweep_seg[blockIdx.x];
     const int64_t PL = A.sweep_pl;
     const int band = sg.x, z0 = sg.y, z1 = sg.z;  // chain positions z0 <= z < z1
     const int64_t gmax = A.ncols - 2;
-    double acc0 = 0.0, acc1 = 0.0;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
     typedef const unsigned __attribute__((address_space(4))) *const_words;
     typedef const int __attribute__((address_space(4))) *const_ints;
     if (z0 < z1) {
@@ -719,6 +727,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
             load_halo(brow[2], hreg);
             load_own(brow[4], own_next);
             const int far = chain_far[z];
+            const bool plain_pos = DUAL ? ((const_ints)(uintptr_t)A.chain_dual)[z] == 0 : true;
             const double *cur = own_ring + (size_t)(z & 3) * T;
             const double *prv = own_ring + (size_t)((z + 3) & 3) * T;
             const double *nxt = own_ring + (size_t)((z + 1) & 3) * T;
@@ -777,6 +786,11 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
                 const double zz1 = a.diag_mode ? (DIAGVEC ? f.d.y : a.diag_uniform) * r1 : r1;
                 acc0 += r1 * zz1;
                 acc1 += r1 * r1;
+                if (DUAL) {
+                    const double q0 = r0 * r0, q1 = r1 * r1;
+                    acc2 += plain_pos ? q0 : 0.0;
+                    acc2 += plain_pos ? q1 : 0.0;
+                }
                 const pvd2 rn = {r0, r1};
                 __builtin_nontemporal_store(rn, reinterpret_cast<pvd2 *>(r_out + ra));
                 rr[h] = fetch(rbase, h);
@@ -797,6 +811,10 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
     if (tid == 0) {
         a.partials[blockIdx.x] = s0;
         a.partials[a.part_stride + blockIdx.x] = s1;
+    }
+    if (DUAL) {
+        const double s2 = block_sum(acc2, red);
+        if (tid == 0) a.partials[2 * a.part_stride + blockIdx.x] = s2;
     }
 }
 
@@ -1027,10 +1045,18 @@ bool pair_sweep_start_ok(const CsrView &A, int grid)
     return (nh == 1 || nh == 2) && nhl_upd <= 4 && nhl_dir <= 2;
 }
 
+// ... and with the fused dual residual: the flagged planes' chunk list exists and its launch fits the
+// partial-sum slots behind the walk's
+bool pair_sweep_dual_ok(const CsrView &A, int grid)
+{
+    return pair_sweep_start_ok(A, grid) && A.chain_dual && A.dual_chunks && A.dual_blocks > 0 &&
+           A.sweep_nslots + A.dual_blocks <= grid;
+}
+
 int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s)
 {
     const bool wide = A.ncols >= (int64_t(1) << 28);  // byte offsets of x beyond 32 bits
-    if (mode == kSpmvResidInit && a.sweep_init) {
+    if ((mode == kSpmvResidInit || mode == kSpmvResidDual) && a.sweep_init) {
         // CG start in the z-sweep walk (pcg_begin asks for it only where pair_sweep_start_ok holds and the
         // Jacobi diagonal is a scalar or absent): r = b - A x to a.y, partial r.z and r.r; p is not written
         if (!pair_sweep_start_ok(A, grid) || a.diag_mode == 1 || a.diag_mode == 2 || a.dinv) {
@@ -1042,12 +1068,25 @@ int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hi
         SpmvArgs b = a;
         b.part_stride = grid;
         b.part_offset = 0;
+        // fused check residual on a second vector (a subdomain with neighbours): the planes where it needs its
+        // own product are left out of the third partial bank here and added by a listed launch below
+        const bool with_dual = mode == kSpmvResidDual && a.x2 != nullptr;
+        if (with_dual && !pair_sweep_dual_ok(A, grid)) {
+            set_error("launch_spmv_pair: the z-sweep dual start launch does not apply to this matrix");
+            return SCHWZ_ERR_INVALID;
+        }
 #define SCHWZ_SWEEP_INIT(L_, H_)                                                                                          \
     {                                                                                                                    \
-        static const hipError_t e0 = hipFuncSetAttribute((const void *)spmv_pair_sweep_kernel<L_, H_, false, true>,      \
+        static const hipError_t e0 = hipFuncSetAttribute((const void *)spmv_pair_sweep_kernel<L_, H_, false, true, false>, \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);          \
+        static const hipError_t e1 = hipFuncSetAttribute((const void *)spmv_pair_sweep_kernel<L_, H_, false, true, true>, \
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);          \
         (void)e0;                                                                                                        \
-        hipLaunchKernelGGL((spmv_pair_sweep_kernel<L_, H_, false, true>), dim3(A.sweep_nslots), dim3(kBlock), lds, s, A, b); \
+        (void)e1;                                                                                                        \
+        if (with_dual)                                                                                                   \
+            hipLaunchKernelGGL((spmv_pair_sweep_kernel<L_, H_, false, true, true>), dim3(A.sweep_nslots), dim3(kBlock), lds, s, A, b); \
+        else                                                                                                             \
+            hipLaunchKernelGGL((spmv_pair_sweep_kernel<L_, H_, false, true, false>), dim3(A.sweep_nslots), dim3(kBlock), lds, s, A, b); \
     }
         if (nh == 1 && nhl == 1) SCHWZ_SWEEP_INIT(1, 1)
         else if (nh == 1 && nhl == 2) SCHWZ_SWEEP_INIT(2, 1)
@@ -1057,6 +1096,21 @@ int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hi
         else SCHWZ_SWEEP_INIT(4, 2)
 #undef SCHWZ_SWEEP_INIT
         SCHWZ_HIP_TRY(hipGetLastError());
+        if (with_dual) {
+            // ||b - A x2||^2 over the flagged planes: chunk by chunk on x2, partial sums into the third bank
+            // behind the walk's (the launch also writes zeros into the same slots of the second bank)
+            SpmvArgs c;
+            c.x = a.x2;
+            c.b = a.b;
+            c.row_limit = a.row_limit;
+            c.sweep = 2;
+            c.partials = a.partials + grid;
+            c.part_stride = grid;
+            c.part_offset = A.sweep_nslots;
+            hipLaunchKernelGGL((spmv_pair_kernel<kSpmvResidNorm, false, true>), dim3(A.dual_blocks), dim3(kBlock),
+                               kPairTableLds, s, A, c);
+            SCHWZ_HIP_TRY(hipGetLastError());
+        }
         return SCHWZ_OK;
     }
     if (mode == kSpmvDirDotSym && a.sweep_first) {
@@ -1526,6 +1580,7 @@ static int build_sweep(schwz_csr *A, int64_t nrows, const PairTable &tb, const P
     A->v.canon_mask = (const int *)A->d_canon_mask;
     A->v.canon_npat = tb.npat;
     A->v.chain_plane = (const int *)A->d_chain_plane;
+    A->h_chain_plane = chain_plane;
     A->v.chain_far = (const int *)A->d_chain_far;
     if (sym_ok) {
         if ((rc = upv(sval, &A->d_canon_sym_val)) || (rc = upv(smsk, &A->d_canon_sym_mask))) return rc;
@@ -1896,6 +1951,35 @@ int pair_set_dual_split(schwz_csr *A, const schwz_idx *h_rp, const schwz_idx *h_
     int rc = upv(flag, &A->d_chunk_dual);
     if (rc) return rc;
     A->v.chunk_dual = (const uint8_t *)A->d_chunk_dual;
+    // the same for the z-sweep walk: chain positions whose plane has a flagged chunk, and the list of those
+    // planes' chunks for the listed kSpmvResidNorm launch (launch_spmv_pair, dual start in the walk)
+    (void)hipFree(A->d_chain_dual);
+    (void)hipFree(A->d_dual_chunks);
+    A->d_chain_dual = A->d_dual_chunks = nullptr;
+    A->v.chain_dual = nullptr;
+    A->v.dual_chunks = nullptr;
+    A->v.dual_nchunks = A->v.dual_blocks = 0;
+    if (A->v.sweep_nslots > 0 && !A->h_chain_plane.empty() && A->v.sweep_pl > 0) {
+        const int cpp = (int)(A->v.sweep_pl / kPairRows);
+        std::vector<int> cdual(A->h_chain_plane.size(), 0);
+        std::vector<schwz_idx> list;
+        for (size_t p = 0; p < A->h_chain_plane.size(); ++p) {
+            const int k = A->h_chain_plane[p];
+            if (k < 0) continue;
+            bool f = false;
+            for (int c = k * cpp; c < (k + 1) * cpp && c < nchunks; ++c) f = f || flag[(size_t)c];
+            if (!f) continue;
+            cdual[p] = 1;
+            for (int c = k * cpp; c < (k + 1) * cpp && c < nchunks; ++c) list.push_back(c);
+        }
+        if (!list.empty()) {
+            if ((rc = upv(cdual, &A->d_chain_dual)) || (rc = upv(list, &A->d_dual_chunks))) return rc;
+            A->v.chain_dual = (const int *)A->d_chain_dual;
+            A->v.dual_chunks = (const schwz_idx *)A->d_dual_chunks;
+            A->v.dual_nchunks = (int)list.size();
+            A->v.dual_blocks = (int)std::min<size_t>(list.size(), 512);
+        }
+    }
     return SCHWZ_OK;
 }
 
@@ -1909,7 +1993,13 @@ void free_spmv_pair(schwz_csr *A)
     (void)hipFree(A->d_canon_sym_mask);
     (void)hipFree(A->d_chain_plane);
     (void)hipFree(A->d_chain_far);
-    A->d_chain_plane = A->d_chain_far = nullptr;
+    (void)hipFree(A->d_chain_dual);
+    (void)hipFree(A->d_dual_chunks);
+    A->d_chain_plane = A->d_chain_far = A->d_chain_dual = A->d_dual_chunks = nullptr;
+    A->v.chain_dual = nullptr;
+    A->v.dual_chunks = nullptr;
+    A->v.dual_nchunks = A->v.dual_blocks = 0;
+    A->h_chain_plane.clear();
     A->d_sweep_seg = A->d_sweep_gen = A->d_canon_val = A->d_canon_mask = A->d_canon_sym_val = A->d_canon_sym_mask = nullptr;
     A->v.canon_sym_val = nullptr;
     A->v.sweep_nslots = 0;

@@ -544,6 +544,11 @@ class Subdomain:
     def restrict(self, stream=0):
         check(lib.schwz_ras_restrict(self.h, _stream_arg(stream)))
 
+    def cg_flavour(self):
+        """How the last local CG solve iterated (schwz_ras_cg_flavour: bits 0-1 launches per iteration,
+        4 deferred x update, 8 / 16 z-sweep walk of the update / fused direction launch, 32 of the start)."""
+        return int(lib.schwz_ras_cg_flavour(self.h))
+
     def vector(self, which):
         p = C.c_void_p()
         n = C.c_int64(0)

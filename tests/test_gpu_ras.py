@@ -110,6 +110,32 @@ def test_ras_block_jacobi_and_ilu_match_oracle(schwz, oracle, torch_cuda, P, pre
     _check_against_oracle(oracle, oracle.laplacian3d(*shape), P, solver, m, out)
 
 
+@pytest.mark.parametrize("P", [1, 3])
+@pytest.mark.parametrize("inner", [(1e-10, -1), (0.0, 6)])
+def test_ras_with_the_z_sweep_walk_from_the_start_of_every_solve(schwz, oracle, torch_cuda, monkeypatch, P, inner):
+    """Slabs whose local solves run in the z-sweep walk from their first launch on (forced on a small grid:
+    SCHWZ_SPMV_SWEEP=2, deferred x update for every size): the start residual in the INIT form of the update
+    walk, for subdomains with neighbours together with the fused check residual (third partial bank from the
+    planes where x~ and y coincide + a listed launch on x~ over the planes next to the overlap), p0 from the
+    FIRST form of the fused direction launch, a state-only launch for the last iteration -- against the
+    oracle's RAS run, with converged and with truncated local solves."""
+    monkeypatch.setenv("SCHWZ_SPMV_PATTERN", "2")
+    monkeypatch.setenv("SCHWZ_SPMV_PAIR", "2")
+    monkeypatch.setenv("SCHWZ_SPMV_SWEEP", "2")
+    monkeypatch.setenv("SCHWZ_SWEEP_T", "512")
+    monkeypatch.setenv("SCHWZ_CG_DEFERX", "2")
+    local_tol, local_iters = inner
+    shape = (256, 4, 30)
+    solver, m, out = _run_gpu(
+        schwz, P, dict(laplacian_dim=3, laplacian_shape=shape),
+        dict(tolerance=1e-6, max_iters=400, local_precond="block-jacobi", precond_max_block_size=1,
+             local_solver_tolerance=local_tol, local_max_iters=local_iters))
+    for sd in solver.subdomains.values():
+        # 32: started in the walk, 16 / 8: fused direction launch / update launch walked, 4: deferred x
+        assert sd.cg_flavour() & 60 == 60, sd.cg_flavour()
+    _check_against_oracle(oracle, oracle.laplacian3d(*shape), P, solver, m, out, truncated_cg=local_tol == 0.0)
+
+
 def test_two_stage_local_criterion_matches_oracle(schwz, oracle, torch_cuda):
     """--reset_local_crit_iter / --updated_max_iters (solve.cpp:723-742): a cheap first stage
     (3 CG iterations per local solve) switches to converged local solves after outer iteration 4.
