@@ -361,6 +361,15 @@ int schwz_ras_unpack_f32(schwz_subdomain *sd, const float *d_recv, schwz_stream 
  * receive window (mapped with schwz_window_open), over xGMI when it lives on another GPU.  "get": the
  * unpack kernel of in-neighbour k loads from that neighbour's send window.  single != 0: fp32 wire
  * format (MixedValueType = float). */
+/* The pack of the next exchange while the local solve is still finishing: the solve makes the rows of
+ * the put lists final first and records an event; this call makes `stream` (a side stream) wait for it
+ * and gathers the send buffer from the solve's result (double, or float with `single`) -- the values
+ * schwz_ras_pack reads after schwz_ras_restrict.  The reference posts its MPI_Isend only after the local
+ * solve and the restriction have finished (restricted_schwarz.cpp:884-943 inside schwarz_base.cpp:387-452);
+ * here the RCCL send / recv runs beside the tail of the solve.  schwz_ras_early_pack_ok: 1 when the
+ * subdomain's solver (CG) records that event. */
+int schwz_ras_early_pack_ok(const schwz_subdomain *sd);
+int schwz_ras_pack_early(schwz_subdomain *sd, void *d_send, int single, schwz_stream stream);
 int schwz_ras_pack_neighbor(schwz_subdomain *sd, int k, void *d_dst, int single, schwz_stream stream);
 int schwz_ras_unpack_neighbor(schwz_subdomain *sd, int k, const void *d_src, int single, schwz_stream stream);
 /* Windows: device buffers that other rank processes of the node map into their address space -- the

@@ -254,9 +254,12 @@ struct PRing {
     const double *slot[kDeferDepth];
 };
 
+// The launch covers the pairs [pair0, pair1) (and the odd last row when `tail` is set): the last update of a
+// solve is cut into the caller's priority rows and the rest (schwz_pcg::prio_*).
 __global__ __launch_bounds__(kBlock) void cg_flush_x_kernel(int64_t n, double *__restrict__ x, const PRing ring,
                                                             const double *__restrict__ alpha_hist,
-                                                            const CgState *st, int b0, int count, int pending)
+                                                            const CgState *st, int b0, int count, int pending,
+                                                            int64_t pair0, int64_t pair1, int tail)
 {
 #pragma clang fp contract(off)
     __shared__ double alpha[kDeferDepth];
@@ -265,10 +268,10 @@ __global__ __launch_bounds__(kBlock) void cg_flush_x_kernel(int64_t n, double *_
     if (kmax <= 0) return;
     if ((int)threadIdx.x < kmax) alpha[threadIdx.x] = alpha_hist[(b0 + threadIdx.x) % kDeferDepth];
     __syncthreads();
-    const int64_t n2 = n >> 1;
+    const int64_t n2 = pair1;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     vd2 *x2 = reinterpret_cast<vd2 *>(x);
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
+    for (int64_t i = pair0 + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
         vd2 xv = __builtin_nontemporal_load(x2 + i);
         for (int k0 = 0; k0 < kmax; k0 += 4) {
             vd2 pv[4];
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(kBlock) void cg_flush_x_kernel(int64_t n, double *_
         }
         __builtin_nontemporal_store(xv, x2 + i);
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (tail && (n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         double xv = x[n - 1];
         for (int k = 0; k < kmax; ++k) {
             const double inc = alpha[k] * ring.slot[(b0 + k) % kDeferDepth][n - 1];
@@ -710,6 +713,7 @@ int schwz_pcg_create_ex(const schwz_csr *A, int precond, int block_size, schwz_p
 void schwz_pcg_destroy(schwz_pcg *s)
 {
     if (!s) return;
+    if (s->prio_event) (void)hipEventDestroy(s->prio_event);
     (void)hipFree(s->r);
     (void)hipFree(s->p);
     (void)hipFree(s->q);
@@ -965,9 +969,26 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
     for (int k = 0; k < kDeferDepth; ++k)
         ring.slot[k] = k == 0 ? s->p : (k == 1 ? s->q : (s->p_ring ? s->p_ring + (int64_t)(k - 2) * n_pad : s->p));
     auto slot = [&](int it) -> double * { return const_cast<double *>(ring.slot[it % kDeferDepth]); };
-    auto flush_x = [&](int b0, int count, int pending, hipStream_t q) {
+    bool prio_recorded = false;
+    auto flush_x = [&](int b0, int count, int pending, hipStream_t q, bool last = false) {
+        const int64_t n2 = n >> 1;
+        if (last && s->prio_on && s->prio_event && q == st && !prio_recorded) {
+            // the caller's priority rows first, the event, then the rest (the same bits: every element is
+            // updated by exactly one lane of exactly one of the launches)
+            const int64_t lo = std::min(s->prio_lo >> 1, n2), hi = std::max(std::min(s->prio_hi >> 1, n2), lo);
+            if (lo > 0)
+                hipLaunchKernelGGL(cg_flush_x_kernel, dim3(grid_for(lo)), dim3(kBlock), 0, q, n, d_x, ring, s->alpha_hist,
+                                   s->state, b0, count, pending, (int64_t)0, lo, 0);
+            hipLaunchKernelGGL(cg_flush_x_kernel, dim3(grid_for(n2 - hi + 1)), dim3(kBlock), 0, q, n, d_x, ring,
+                               s->alpha_hist, s->state, b0, count, pending, hi, n2, 1);
+            if (hipEventRecord(s->prio_event, q) == hipSuccess) prio_recorded = true;
+            if (hi > lo)
+                hipLaunchKernelGGL(cg_flush_x_kernel, dim3(grid_for(hi - lo)), dim3(kBlock), 0, q, n, d_x, ring,
+                                   s->alpha_hist, s->state, b0, count, pending, lo, hi, 0);
+            return;
+        }
         hipLaunchKernelGGL(cg_flush_x_kernel, dim3(gv), dim3(kBlock), 0, q, n, d_x, ring, s->alpha_hist, s->state, b0,
-                           count, pending);
+                           count, pending, (int64_t)0, n2, 1);
     };
     double *const pbuf[2] = {s->p, fusedir ? s->q : s->p};
     // SCHWZ_CG_LASTDIR=1: the last iteration of a solve updates the search direction like every other one
@@ -1049,7 +1070,7 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
             } else if (deferx) {
                 // the ring is full: apply its kDeferDepth increments before slot (it + 1) % depth,
                 // the oldest direction, is overwritten
-                if ((it + 1) % kDeferDepth == 0) flush_x(it + 1 - kDeferDepth, kDeferDepth, it, q);
+                if ((it + 1) % kDeferDepth == 0) flush_x(it + 1 - kDeferDepth, kDeferDepth, it, q, instrument && it == max_iters - 1);
                 if (instrument && it == max_iters - 1 && last_state_only)  // nobody reads the direction after the last iteration
                     hipLaunchKernelGGL(cg_state_advance_kernel, dim3(1), dim3(kBlock), 0, q, part_vec, gs, s->state, it, rtol);
                 else
@@ -1169,9 +1190,12 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
     // the increments of the last, partly filled ring (iterations past a tolerance stop are not
     // counted by CgState::iters and add nothing)
     if (deferx && it % kDeferDepth != 0) {
-        flush_x(it - it % kDeferDepth, it % kDeferDepth, -1, st);
+        flush_x(it - it % kDeferDepth, it % kDeferDepth, -1, st, true);
         SCHWZ_HIP_TRY(hipGetLastError());
     }
+    // priority rows without a split update (x updated inside the iteration, or no iteration at all): final
+    // behind the last launch
+    if (s->prio_on && s->prio_event && !prio_recorded) SCHWZ_HIP_TRY(hipEventRecord(s->prio_event, st));
     return SCHWZ_OK;
 }
 

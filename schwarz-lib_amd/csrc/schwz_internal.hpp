@@ -332,6 +332,13 @@ struct schwz_pcg {
     bool ring_failed = false;
     // the start launch of the running solve left p to the first fused direction launch (z-sweep start)
     bool p_pending = false;
+    // Rows the caller wants final FIRST (a subdomain's boundary rows, which its neighbours wait for): the
+    // last x update of a solve takes [0, prio_lo) and [prio_hi, n) ahead of the rest and records prio_event
+    // in between, so that the halo pack + send can run beside the remaining update (schwz_ras_pack_early).
+    // Without a deferred x update the event is recorded behind the last launch of the solve.
+    bool prio_on = false;
+    int64_t prio_lo = 0, prio_hi = 0;  // even
+    hipEvent_t prio_event = nullptr;
     // how the last solve iterated: bits 0-1: 0 stored q, 1 q-free (three launches), 2 q-free with the fused
     // direction + p.(A p) launch; 4: deferred x update; 8: z-sweep walk of the update launch; 16: of the fused launch;
     // 32: of the start launch and the first direction as well

@@ -116,6 +116,37 @@ int schwz_subdomain_to_device(schwz_subdomain *sd, const double *h_local_rhs, co
         } else {
             if ((rc = schwz_pcg_create_ex(sd->A, opt->precond, bsz, &sd->cg))) return rc;
             sd->cg->variant = opt->spmv_variant;
+            // Rows the neighbours wait for (the put lists: interior rows next to the subdomain boundary) become
+            // final ahead of the rest of the solution, so that the next halo exchange can start beside the tail
+            // of the solve (schwz_ras_pack_early).  Two ranges [0, lo) and [hi, n) around the widest gap of the
+            // sorted put ids.
+            if (sd->num_send > 0) {
+                std::vector<schwz_idx> ids(put_idx);
+                std::sort(ids.begin(), ids.end());
+                int64_t lo = 0, hi = n, gap = -1;
+                int64_t prev = -1;
+                for (size_t k = 0; k <= ids.size(); ++k) {
+                    const int64_t cur = k < ids.size() ? (int64_t)ids[k] : n;
+                    if (cur - prev > gap) {
+                        gap = cur - prev;
+                        lo = prev + 1;
+                        hi = cur;
+                    }
+                    prev = cur;
+                }
+                lo = (lo + 1) & ~int64_t(1);
+                hi = hi & ~int64_t(1);
+                if (hi < lo) hi = lo;
+                if (ids.back() < sd->local_size) {
+                    // (put lists spread over more than a quarter of the rows, an irregular partition: no
+                    // split, the event follows the whole update and the exchange overlaps the restriction only)
+                    const bool split = lo + (n - hi) <= n / 4;
+                    sd->cg->prio_lo = split ? lo : (n & ~int64_t(1));
+                    sd->cg->prio_hi = split ? hi : (n & ~int64_t(1));
+                    SCHWZ_HIP_TRY(hipEventCreateWithFlags(&sd->cg->prio_event, hipEventDisableTiming));
+                    sd->cg->prio_on = true;
+                }
+            }
         }
     } else {
         // Solve::compute_local_factors + the Ginkgo TRS setup (solve.cpp:75-143,281-399)
@@ -172,6 +203,26 @@ int schwz_ras_unpack_f32(schwz_subdomain *sd, const float *d_recv, schwz_stream 
     if (sd->num_recv == 0) return SCHWZ_OK;
     SCHWZ_REQUIRE(d_recv, "schwz_ras_unpack_f32: null recv buffer");
     return launch_scatter_f32(sd->num_recv, sd->d_get_idx, d_recv, sd->d_x, (hipStream_t)stream);
+}
+
+// The pack of the NEXT exchange, beside the tail of the running local solve: waits (on `stream`, typically a
+// side stream) for the event the solve records once the rows of the put lists are final, and gathers them
+// from the solve's result y -- which the restriction copies to x~ unchanged, so the buffer holds what
+// schwz_ras_pack would read after schwz_ras_restrict.
+int schwz_ras_early_pack_ok(const schwz_subdomain *sd)
+{
+    return sd && sd->on_device && sd->cg && sd->cg->prio_on && sd->cg->prio_event ? 1 : 0;
+}
+
+int schwz_ras_pack_early(schwz_subdomain *sd, void *d_send, int single, schwz_stream stream)
+{
+    REQUIRE_DEVICE(sd, "schwz_ras_pack_early");
+    SCHWZ_REQUIRE(schwz_ras_early_pack_ok(sd), "schwz_ras_pack_early: this subdomain's solver records no boundary event");
+    if (sd->num_send == 0) return SCHWZ_OK;
+    SCHWZ_REQUIRE(d_send, "schwz_ras_pack_early: null send buffer");
+    SCHWZ_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, sd->cg->prio_event, 0));
+    if (single) return launch_gather_f32(sd->num_send, sd->d_put_idx, sd->d_y, (float *)d_send, (hipStream_t)stream);
+    return schwz_gather(sd->num_send, sd->d_put_idx, sd->d_y, (double *)d_send, SCHWZ_OP_COPY, stream);
 }
 
 // One neighbour's part of the halo, to / from ANY device address -- the receiver's window in the

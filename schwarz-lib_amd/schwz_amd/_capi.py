@@ -45,6 +45,7 @@ SYMBOLS = [
     "schwz_cholesky", "schwz_ilu0", "schwz_isai", "schwz_free",
     "schwz_subdomain_to_device", "schwz_ras_pack", "schwz_ras_unpack", "schwz_ras_pack_f32",
     "schwz_ras_unpack_f32", "schwz_ras_pack_neighbor", "schwz_ras_unpack_neighbor",
+    "schwz_ras_early_pack_ok", "schwz_ras_pack_early",
     "schwz_window_alloc", "schwz_window_free", "schwz_window_export", "schwz_window_open", "schwz_window_close",
     "schwz_host_atomic_add_i32", "schwz_host_atomic_load_i32", "schwz_host_atomic_store_i32",
     "schwz_host_atomic_min_f64",
@@ -167,6 +168,8 @@ _sig("schwz_ras_pack_f32", i32, [vp, vp, vp])
 _sig("schwz_ras_unpack_f32", i32, [vp, vp, vp])
 _sig("schwz_ras_update_boundary", i32, [vp, vp])
 _sig("schwz_ras_pack_neighbor", i32, [vp, i32, vp, i32, vp])
+_sig("schwz_ras_early_pack_ok", i32, [vp])
+_sig("schwz_ras_pack_early", i32, [vp, vp, i32, vp])
 _sig("schwz_ras_unpack_neighbor", i32, [vp, i32, vp, i32, vp])
 _sig("schwz_window_alloc", i32, [i64, pvp])
 _sig("schwz_window_free", i32, [vp])

@@ -20,6 +20,10 @@ class InProcessComm:
         self.rank = 0
         self.local_ranks = list(range(self.size))
         self.is_root = True
+        self._side = None
+
+    def supports_early_exchange(self):
+        return True
 
     def handshake(self, get_lists):
         """get_lists: {me: [(p, ids), ...]} -> put lists {me: [(q, ids), ...]}
@@ -43,7 +47,23 @@ class InProcessComm:
         return None
 
     def finish_exchange(self, handle):
-        pass
+        if handle is not None:  # an early exchange: the compute stream meets the side stream again
+            import torch
+            torch.cuda.current_stream().wait_event(handle)
+
+    def start_exchange_early(self, sends, recvs, pack):
+        """The exchange that belongs to the START of the next iteration, posted beside the tail of the
+        running local solves: `pack(stream)` makes the side stream wait for the solvers' boundary events
+        and fills the send buffers from the solves' results; the copies follow on the same stream."""
+        import torch
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream()
+        with torch.cuda.stream(self._side):
+            pack(self._side.cuda_stream)
+            self.exchange(sends, recvs)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        return ev
 
     def start_flags(self, values, neighbours):
         """values: {me: (mask, stop_at)}; neighbours: {me: (out_ranks, in_ranks)}.
@@ -192,6 +212,28 @@ class TorchDistComm:
             w.wait()
         for buf, h in post:
             buf.copy_(h, non_blocking=True)
+
+    def supports_early_exchange(self):
+        """Device-buffer send / recv on a side stream (nccl); the host-staged path has nothing to overlap."""
+        return not self.stage_through_host and self.device.type != "cpu"
+
+    def start_exchange_early(self, sends, recvs, pack):
+        """The exchange that belongs to the START of the next iteration, posted beside the tail of the
+        running local solve: `pack(stream)` makes the side stream wait for the solver's boundary event and
+        fills the send buffer from the solve's result; the grouped ncclSend / ncclRecv follow on that
+        stream.  finish_exchange() makes the compute stream wait for them."""
+        torch, dist = self._torch, self._dist
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        ops = []
+        for (src, dst), buf in sorted(sends.items()):
+            ops.append(dist.P2POp(dist.isend, buf, dst, group=self.group))
+        for (src, dst), buf in sorted(recvs.items()):
+            ops.append(dist.P2POp(dist.irecv, buf, src, group=self.group))
+        with torch.cuda.stream(self._side):
+            pack(self._side.cuda_stream)
+            works = dist.batch_isend_irecv(ops) if ops else []
+        return works, []
 
     def exchange(self, sends, recvs):
         self.finish_exchange(self.start_exchange(sends, recvs))

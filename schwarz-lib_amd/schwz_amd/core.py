@@ -497,6 +497,15 @@ class Subdomain:
     def unpack_f32(self, d_recv, stream=0):
         check(lib.schwz_ras_unpack_f32(self.h, ptr(d_recv), _stream_arg(stream)))
 
+    def early_pack_ok(self):
+        """Whether the local solver records the event pack_early waits for (CG with put lists)."""
+        return bool(lib.schwz_ras_early_pack_ok(self.h))
+
+    def pack_early(self, d_send, single=False, stream=0):
+        """The pack of the NEXT exchange beside the tail of the running solve (schwz_ras_pack_early):
+        `stream` waits until the rows of the put lists are final, then gathers them from the solve's result."""
+        check(lib.schwz_ras_pack_early(self.h, ptr(d_send), int(bool(single)), _stream_arg(stream)))
+
     def pack_neighbor(self, k, dst, single=False, stream=0):
         """Out-neighbour k's halo values to the device address `dst` (its receive window)."""
         check(lib.schwz_ras_pack_neighbor(self.h, int(k), ptr(dst), int(bool(single)), _stream_arg(stream)))

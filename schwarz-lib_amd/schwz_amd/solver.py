@@ -8,6 +8,7 @@ driven by benchmarking/bench_ras.cpp:48-197.  All arithmetic runs in
 libschwz_hip.so on the GPU; this file only orders the launches and talks to
 the communication layer.
 """
+import os
 import time
 from dataclasses import dataclass, field
 
@@ -422,11 +423,42 @@ class SolverRAS:
 
     def _exchange(self):
         stream = self.backend.stream()
+        if getattr(self, "_early", None) is not None:
+            # this exchange was posted beside the tail of the last local solves (_post_early_exchange):
+            # the same values, already on their way
+            handle, self._early = self._early, None
+            self.comm.finish_exchange(handle)
+            for me, sd in self.subdomains.items():
+                self._unpack(me, sd, stream)
+            return
         for me, sd in self.subdomains.items():
             self._pack(me, sd, stream)
         self.comm.exchange(self._sends, self._recvs)
         for me, sd in self.subdomains.items():
             self._unpack(me, sd, stream)
+
+    def _early_exchange_ok(self):
+        """The synchronous two-sided loop may post the exchange of iteration k + 1 beside the tail of the
+        local solves of iteration k: the solvers make the rows of the put lists final first and record an
+        event (schwz_ras_pack_early), the communicator sends device buffers from a side stream.  The values
+        are those the exchange at the start of iteration k + 1 would read after the restriction: the
+        iteration is the same bit for bit.  SCHWZ_EARLY_EXCHANGE=0 switches it off."""
+        if getattr(self, "_early_ok", None) is None:
+            comm = self.comm
+            self._early_ok = (os.environ.get("SCHWZ_EARLY_EXCHANGE", "1") != "0"
+                              and self.metadata.num_subdomains > 1
+                              and getattr(comm, "supports_early_exchange", lambda: False)()
+                              and all(hasattr(sd, "early_pack_ok") and sd.early_pack_ok()
+                                      for sd in self.subdomains.values()))
+        return self._early_ok
+
+    def _post_early_exchange(self):
+        single = self.settings.use_mixed_precision
+
+        def pack(stream):
+            for me, sd in self.subdomains.items():
+                sd.pack_early(self.send_buf[me].data_ptr(), single, stream)
+        self._early = self.comm.start_exchange_early(self._sends, self._recvs, pack)
 
     def begin_run(self):
         """State of SchwarzBase::run before its loop (schwarz_base.cpp:340-386)."""
@@ -450,6 +482,9 @@ class SolverRAS:
         self._mask = {me: 0 for me in self.subdomains}
         self._stop = {me: NEVER for me in self.subdomains}
         self._pending = None
+        if getattr(self, "_early", None) is not None:  # an exchange left over from an interrupted run
+            self._exchange()
+        self._early = None
         self._t_begin = time.perf_counter()
         if getattr(self, "_win", None) is not None:
             # a fresh run: the windows go back to their initial state (collectively, before anybody iterates)
@@ -858,6 +893,10 @@ class SolverRAS:
             for _, sd in locals_:
                 sd.local_solve(stream)
         self._log_local_solve(locals_)
+        # step 0 of the NEXT iteration, posted now: pack + send / recv on a side stream as soon as the
+        # solves have finalised their boundary rows, beside the rest of the solution update and step 4
+        if not cs.enable_onesided and self._early_exchange_ok():
+            self._post_early_exchange()
         t4 = time.perf_counter()
         # 4 restricted write-back
         for _, sd in locals_:

@@ -136,6 +136,43 @@ def test_ras_with_the_z_sweep_walk_from_the_start_of_every_solve(schwz, oracle, 
     _check_against_oracle(oracle, oracle.laplacian3d(*shape), P, solver, m, out, truncated_cg=local_tol == 0.0)
 
 
+@pytest.mark.parametrize("case", ["lap2d_P4", "slabs_walk_P3", "slabs_fp32_halos", "graph_partition"])
+def test_early_exchange_is_bit_identical_to_the_exchange_at_the_start_of_the_step(schwz, oracle, torch_cuda,
+                                                                                  monkeypatch, case):
+    """The synchronous loop posts the exchange of iteration k + 1 beside the tail of the local solves of
+    iteration k (the solvers finalise the rows of the put lists first and record an event; pack from the
+    solve's result, send / recv on a side stream; SCHWZ_EARLY_EXCHANGE).  Same values as the exchange at the
+    start of the next step: the whole run -- residual history, iteration count, solution -- is the same bit
+    for bit, with the x update inside the CG launches (small systems), with the deferred update cut into
+    boundary rows + rest (walk forced), with fp32 halos and on a graph partition."""
+    kw_s, kw_m, P = dict(), dict(tolerance=1e-7, max_iters=200, local_precond="block-jacobi",
+                                 precond_max_block_size=1, local_solver_tolerance=1e-10), 4
+    if case == "lap2d_P4":
+        kw_m["oned_laplacian_size"] = 40
+    elif case in ("slabs_walk_P3", "slabs_fp32_halos"):
+        for k, v in (("SCHWZ_SPMV_PATTERN", "2"), ("SCHWZ_SPMV_PAIR", "2"), ("SCHWZ_SPMV_SWEEP", "2"),
+                     ("SCHWZ_SWEEP_T", "512"), ("SCHWZ_CG_DEFERX", "2")):
+            monkeypatch.setenv(k, v)
+        kw_s.update(laplacian_dim=3, laplacian_shape=(256, 4, 30), use_mixed_precision=case == "slabs_fp32_halos")
+        kw_m.update(local_solver_tolerance=0.0, local_max_iters=7, tolerance=1e-5)
+        P = 3
+    else:
+        kw_s.update(partition=schwz.PARTITION_METIS)  # the library's own graph bisection: irregular put lists
+        kw_m["oned_laplacian_size"] = 36
+        P = 5
+    runs = {}
+    for early in ("1", "0"):
+        monkeypatch.setenv("SCHWZ_EARLY_EXCHANGE", early)
+        solver, m, out = _run_gpu(schwz, P, dict(kw_s), dict(kw_m))
+        assert solver._early_exchange_ok() == (early == "1")
+        runs[early] = (out["iter_count"], np.array(m.post_process_data["global_residual_vector_out"]),
+                       out["solution"].copy(), out["residual_norm"])
+    assert runs["1"][0] == runs["0"][0] and runs["1"][0] > 3
+    assert np.array_equal(runs["1"][1], runs["0"][1])
+    assert np.array_equal(runs["1"][2], runs["0"][2])
+    assert runs["1"][3] == runs["0"][3]
+
+
 def test_two_stage_local_criterion_matches_oracle(schwz, oracle, torch_cuda):
     """--reset_local_crit_iter / --updated_max_iters (solve.cpp:723-742): a cheap first stage
     (3 CG iterations per local solve) switches to converged local solves after outer iteration 4.
