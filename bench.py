@@ -329,6 +329,7 @@ def main():
                             a.spmv_variant, overlapped=a.overlapped, mixed=a.mixed_halo)
     setup_s = time.perf_counter() - t_setup
     sd = solver.subdomains[comm.local_ranks[0]]
+    early_exchange = (not a.overlapped) and solver._early_exchange_ok()
     # timed region: W warmup steps, then exactly K steps, no instrumentation
     elapsed = timed_steps(solver, comm, torch, a.warmup, a.steps)
     # roofline leg: the same K steps again with a HIP-event pair around every launch of the
@@ -454,7 +455,8 @@ def main():
                    "cg_launches_per_iteration": (2 if int(lib.schwz_ras_cg_flavour(sd.h)) & 3 == 2 else 3),
                    "exchange": ("one-sided overlapped, decentralised stop" if a.overlapped
                                 else "two-sided, all-gathered residual norms") +
-                               (", fp32 halos" if a.mixed_halo else ""),
+                               (", fp32 halos" if a.mixed_halo else "") +
+                               (", posted on a side stream beside the tail of the local solve" if early_exchange else ""),
                    "exchange_backend": (None if backend is None else
                                         ("nccl (RCCL, one GPU per rank)" if backend == "nccl" else
                                          backend + " (ranks share %d GPU(s), halos staged through host: "

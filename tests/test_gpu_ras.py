@@ -610,6 +610,21 @@ def test_torchdist_comm_on_the_nccl_backend_single_rank(schwz, oracle, torch_cud
         "    comm.finish_exchange(h)\n"
         "    torch.cuda.synchronize()\n"
         "    assert torch.equal(src, dst), ov\n"
+        "# ... and on the side stream of the early exchange of the synchronous loop: the pack callback\n"
+        "# runs on that stream (here: it fills the send buffer behind an event of the compute stream)\n"
+        "assert comm.supports_early_exchange()\n"
+        "send, dst = torch.zeros_like(src), torch.zeros_like(src)\n"
+        "big = torch.randn(1 << 24, device='cuda')\n"
+        "ev = torch.cuda.Event()\n"
+        "for _ in range(4): big = big * 1.0001\n"
+        "ev.record()\n"
+        "def pack(raw_stream):\n"
+        "    torch.cuda.current_stream().wait_event(ev)\n"
+        "    send.copy_(src)\n"
+        "h = comm.start_exchange_early({(0, 0): send}, {(0, 0): dst}, pack)\n"
+        "comm.finish_exchange(h)\n"
+        "torch.cuda.synchronize()\n"
+        "assert torch.equal(src, dst)\n"
         "print(json.dumps(dict(iters=out['iter_count'], conv=bool(out['converged']),\n"
         "                      rel=out['residual_norm'] / out['rhs_norm'], n=int(out['solution'].size))))\n"
         "dist.destroy_process_group()\n" % os.path.join(os.path.dirname(os.path.dirname(__file__)), "schwarz-lib_amd"))
