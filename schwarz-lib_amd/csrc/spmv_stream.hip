@@ -28,7 +28,7 @@
 namespace schwz {
 
 // ABL (measurement builds, variants 80-87 of schwz_csr_spmv): bit 0 no y store, bit 1 no x gather, bit 2 no
-// row-pointer loads
+// row-pointer loads (7-entry rows assumed)
 template <int MODE, int CAP, int ABL = 0>
 __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(CsrView A, SpmvArgs a)
 {
@@ -37,6 +37,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(CsrView A, SpmvArgs
     // masked reads of the last rows may touch)
     __shared__ __attribute__((aligned(16))) double vals[kTileNnz + 4 + CAP];
     __shared__ __attribute__((aligned(16))) int cols[kTileNnz + 4 + CAP];
+    __shared__ int rstart[kBlock + 1];  // first entry of every row of the tile (window-relative)
     __shared__ double red[4];
     if (MODE == kSpmvDot || MODE == kSpmvResidInit) {
         if (a.stop_iter && a.it >= *a.stop_iter) return;
@@ -90,13 +91,9 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(CsrView A, SpmvArgs
         P##v3 = *reinterpret_cast<const vd2 *>(A.val + i1_ + 2);                                     \
         P##c1 = *reinterpret_cast<const vi4 *>(A.col + i1_);                                         \
         const int rowc_ = min((M).r0 + tid, (M).r1 - 1);                                             \
-        if (ABL & 4) {                                                                               \
-            P##b0 = 7 * tid;                                                                         \
-            P##b1 = 7 * tid + 7;                                                                     \
-        } else {                                                                                     \
-            P##b0 = A.rp[rowc_] - s2_;                                                               \
-            P##b1 = A.rp[rowc_ + 1] - s2_;                                                           \
-        }                                                                                            \
+        /* ONE row-pointer load per lane: the end of a row is the start of the next lane's, handed */ \
+        /* over through LDS in the step; the tile's last row ends where the tile does (M.e) */      \
+        P##b0 = (ABL & 4) ? 7 * tid : A.rp[rowc_] - s2_;                                             \
         P##o0 = P##o1 = 0.0;                                                                         \
         if (MODE == kSpmvDot) P##o0 = a.x[rowc_];                                                    \
         if (MODE == kSpmvResidInit || MODE == kSpmvResidNorm) P##o0 = a.b[rowc_];                   \
@@ -113,9 +110,10 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(CsrView A, SpmvArgs
         // latency of its gathers.)
 #define SCHWZ_STREAM_STEP(M, MN, P)                                                                  \
     {                                                                                                \
-        const int b0 = P##b0, b1 = P##b1;                                                            \
+        const int b0 = P##b0;                                                                        \
         const double o0 = P##o0, o1 = P##o1;                                                         \
         lds_barrier(); /* every lane is done with the previous tile's entries */                     \
+        rstart[tid] = b0;                                                                            \
         *reinterpret_cast<vd2 *>(&vals[4 * tid]) = P##v0;                                            \
         *reinterpret_cast<vd2 *>(&vals[4 * tid + 2]) = P##v1;                                        \
         *reinterpret_cast<vi4 *>(&cols[4 * tid]) = P##c0;                                            \
@@ -123,6 +121,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(CsrView A, SpmvArgs
         *reinterpret_cast<vd2 *>(&vals[4 * (tid + kBlock) + 2]) = P##v3;                             \
         *reinterpret_cast<vi4 *>(&cols[4 * (tid + kBlock)]) = P##c1;                                 \
         lds_barrier();                                                                               \
+        const int b1 = (M).r0 + tid + 1 < (M).r1 ? rstart[tid + 1] : (M).e - ((M).s & ~3);          \
         double sum = 0.0;                                                                            \
         _Pragma("unroll") for (int j0 = 0; j0 < CAP; j0 += 8)                                        \
         {                                                                                            \
@@ -172,7 +171,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(CsrView A, SpmvArgs
     }
         vd2 Av0, Av1, Av2, Av3, Bv0, Bv1, Bv2, Bv3;
         vi4 Ac0, Ac1, Bc0, Bc1;
-        int Ab0, Ab1, Bb0, Bb1;
+        int Ab0, Bb0;
         double Ao0, Ao1, Bo0, Bo1;
         Meta m0 = meta(0), m1 = meta(1);
         SCHWZ_STREAM_ISSUE(m0, A)
