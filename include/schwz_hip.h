@@ -227,6 +227,16 @@ int schwz_problem_laplacian(int dim, int64_t nx, int64_t ny, int64_t nz,
 int schwz_problem_from_csr(int64_t N, const int64_t *h_row_ptr,
                            const schwz_idx *h_col, const double *h_val,
                            schwz_problem **out);
+/* Distributed ingest: the reference reads the whole file on every rank and keeps the whole matrix there
+ * (initialization.cpp:204-213).  Here one rank may parse and partition, cut out what every
+ * subdomain reads -- its interior and overlap rows, schwz_problem_extract_rows -- and hand each rank a row
+ * source that holds only that part (row ids ascending, CSR over those rows, columns global and ascending);
+ * schwz_subdomain_setup on it gives the same subdomain as on the whole matrix and fails if it needs a row
+ * that is not there.  extract_rows: first call with h_col == NULL fills h_row_ptr (nrows + 1 entries). */
+int schwz_problem_from_rows(int64_t N, int64_t nrows, const int64_t *h_row_ids, const int64_t *h_row_ptr,
+                            const schwz_idx *h_col, const double *h_val, schwz_problem **out);
+int schwz_problem_extract_rows(const schwz_problem *p, int64_t nrows, const int64_t *h_row_ids,
+                               int64_t *h_row_ptr, schwz_idx *h_col, double *h_val);
 /* Matrix-Market file branch (initialization.cpp:204-213): gko::read +
  * sort_by_column_index */
 int schwz_problem_from_matrix_market(const char *path, schwz_problem **out);

@@ -74,7 +74,7 @@ using namespace schwz;
 
 int64_t schwz_problem::nnz() const
 {
-    if (kind == 0) return rp.empty() ? 0 : rp.back();
+    if (kind == 0 || kind == 1) return rp.empty() ? 0 : rp.back();
     if (kind == 2) return 5 * N - 4 * nx;
     return 7 * N - 2 * (nx * ny + ny * nz + nx * nz);
 }
@@ -84,6 +84,18 @@ int schwz_problem::row(int64_t g, int64_t *cols, double *vals) const
     int c = 0;
     if (kind == 0) {
         for (int64_t j = rp[g]; j < rp[g + 1]; ++j) {
+            cols[c] = col[j];
+            vals[c] = val[j];
+            ++c;
+        }
+    } else if (kind == 1) {
+        const auto it = std::lower_bound(present.begin(), present.end(), g);
+        if (it == present.end() || *it != g) {
+            if (missing_row < 0) missing_row = g;
+            return 0;
+        }
+        const int64_t k = it - present.begin();
+        for (int64_t j = rp[(size_t)k]; j < rp[(size_t)k + 1]; ++j) {
             cols[c] = col[j];
             vals[c] = val[j];
             ++c;
@@ -162,6 +174,68 @@ int schwz_problem_laplacian(int dim, int64_t nx, int64_t ny, int64_t nz, schwz_p
         p->max_row_nnz = 7;
     }
     *out = p;
+    return SCHWZ_OK;
+}
+
+// Distributed ingest: a process holds the rows its subdomain reads -- interior and overlap
+// rows -- of a matrix one rank parsed and partitioned; the rest of the setup (index sets, local and
+// interface matrices, lists) runs on that part exactly as on the whole matrix.
+int schwz_problem_from_rows(int64_t N, int64_t nrows, const int64_t *row_ids, const int64_t *rp,
+                            const schwz_idx *col, const double *val, schwz_problem **out)
+{
+    SCHWZ_REQUIRE(out && N >= 0 && nrows >= 0 && nrows <= N && rp && (nrows == 0 || row_ids),
+                  "schwz_problem_from_rows: bad arguments");
+    SCHWZ_REQUIRE(rp[0] == 0, "schwz_problem_from_rows: row_ptr must start at 0");
+    for (int64_t i = 0; i < nrows; ++i) {
+        SCHWZ_REQUIRE(row_ids[i] >= 0 && row_ids[i] < N && (i == 0 || row_ids[i - 1] < row_ids[i]),
+                      "schwz_problem_from_rows: row ids must be ascending and inside the matrix");
+        SCHWZ_REQUIRE(rp[i + 1] >= rp[i], "schwz_problem_from_rows: row_ptr not monotone");
+    }
+    const int64_t nnz = rp[nrows];
+    SCHWZ_REQUIRE(nnz == 0 || (col && val), "schwz_problem_from_rows: null column / value array");
+    auto *p = new schwz_problem();
+    p->kind = 1;
+    p->N = N;
+    p->present.assign(row_ids, row_ids + nrows);
+    p->rp.assign(rp, rp + nrows + 1);
+    p->col.assign(col, col + nnz);
+    p->val.assign(val, val + nnz);
+    for (int64_t i = 0; i < nrows; ++i) {
+        p->max_row_nnz = std::max(p->max_row_nnz, (int)(rp[i + 1] - rp[i]));
+        for (int64_t j = rp[i]; j < rp[i + 1]; ++j)
+            if (col[j] < 0 || col[j] >= N || (j > rp[i] && col[j - 1] >= col[j])) {
+                delete p;
+                set_error("schwz_problem_from_rows: columns must be ascending and inside the matrix");
+                return SCHWZ_ERR_INVALID;
+            }
+    }
+    *out = p;
+    return SCHWZ_OK;
+}
+
+// The rows `row_ids` of a problem as CSR arrays (what the parsing rank sends to the others).  Call once
+// with col_out == nullptr for the row pointers (rp_out[nrows] = entries needed), then with the arrays.
+int schwz_problem_extract_rows(const schwz_problem *p, int64_t nrows, const int64_t *row_ids, int64_t *rp_out,
+                               schwz_idx *col_out, double *val_out)
+{
+    SCHWZ_REQUIRE(p && nrows >= 0 && rp_out && (nrows == 0 || row_ids), "schwz_problem_extract_rows: bad arguments");
+    std::vector<int64_t> c((size_t)p->max_row_nnz + 1);
+    std::vector<double> v((size_t)p->max_row_nnz + 1);
+    rp_out[0] = 0;
+    for (int64_t i = 0; i < nrows; ++i) {
+        SCHWZ_REQUIRE(row_ids[i] >= 0 && row_ids[i] < p->N, "schwz_problem_extract_rows: row outside the matrix");
+        const int len = p->row(row_ids[i], c.data(), v.data());
+        if (col_out)
+            for (int k = 0; k < len; ++k) {
+                col_out[rp_out[i] + k] = (schwz_idx)c[(size_t)k];
+                val_out[rp_out[i] + k] = v[(size_t)k];
+            }
+        rp_out[i + 1] = rp_out[i] + len;
+    }
+    if (p->missing_row >= 0) {
+        set_error("schwz_problem_extract_rows: a requested row is not held by this process");
+        return SCHWZ_ERR_INVALID;
+    }
     return SCHWZ_OK;
 }
 
@@ -694,6 +768,12 @@ int schwz_subdomain_setup(const schwz_problem *p, int P, int me, int overlap, co
             sd->nbr_in.push_back(q);
             sd->get.push_back(std::move(lst));
         }
+    }
+    if (p->missing_row >= 0) {  // a row source that holds part of the matrix only (schwz_problem_from_rows)
+        delete sd;
+        set_error("schwz_subdomain_setup: the problem does not hold a row this subdomain reads (row " +
+                  std::to_string(p->missing_row) + ")");
+        return SCHWZ_ERR_INVALID;
     }
     *out = sd;
     return SCHWZ_OK;

@@ -386,7 +386,11 @@ struct schwz_trs {
 
 // host-side global problem (explicit CSR or analytic stencil)
 struct schwz_problem {
-    int kind = 0;  // 0 csr, 2 lap2d, 3 lap3d
+    int kind = 0;  // 0 csr, 1 csr rows of a subset of the rows (distributed ingest), 2 lap2d, 3 lap3d
+    // kind 1: the global ids of the rows this process holds, ascending; rp / col / val cover those rows in
+    // that order.  Asking for another row is an error of the caller: row() returns 0 entries and notes it.
+    std::vector<int64_t> present;
+    mutable int64_t missing_row = -1;
     int64_t N = 0;
     int64_t nx = 0, ny = 0, nz = 0;
     std::vector<int64_t> rp;

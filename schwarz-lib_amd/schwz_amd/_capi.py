@@ -42,6 +42,7 @@ SYMBOLS = [
     "schwz_subdomain_interface_matrix", "schwz_subdomain_get_list",
     "schwz_subdomain_add_put_list", "schwz_subdomain_put_list",
     "schwz_subdomain_send_offset", "schwz_subdomain_recv_offset",
+    "schwz_problem_from_rows", "schwz_problem_extract_rows",
     "schwz_cholesky", "schwz_ilu0", "schwz_isai", "schwz_free",
     "schwz_subdomain_to_device", "schwz_ras_pack", "schwz_ras_unpack", "schwz_ras_pack_f32",
     "schwz_ras_unpack_f32", "schwz_ras_pack_neighbor", "schwz_ras_unpack_neighbor",
@@ -136,6 +137,8 @@ _sig("schwz_trs_destroy", None, [vp])
 _sig("schwz_trs_solve", i32, [vp, vp, vp, vp])
 _sig("schwz_problem_laplacian", i32, [i32, i64, i64, i64, pvp])
 _sig("schwz_problem_from_csr", i32, [i64, vp, vp, vp, pvp])
+_sig("schwz_problem_from_rows", i32, [i64, i64, vp, vp, vp, vp, pvp])
+_sig("schwz_problem_extract_rows", i32, [vp, i64, vp, vp, vp, vp])
 _sig("schwz_problem_from_matrix_market", i32, [C.c_char_p, pvp])
 _sig("schwz_problem_destroy", None, [vp])
 _sig("schwz_problem_size", i64, [vp])

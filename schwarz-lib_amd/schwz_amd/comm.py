@@ -256,6 +256,18 @@ class TorchDistComm:
     def barrier(self):
         self._dist.barrier(group=self.host_group)
 
+    def broadcast_object(self, obj, src=0):
+        """A host object from rank `src` to every rank (setup only)."""
+        box = [obj if self.rank == src else None]
+        self._dist.broadcast_object_list(box, src=src, group=self.host_group)
+        return box[0]
+
+    def scatter_objects(self, objs, src=0):
+        """objs[r] (given on rank `src`) to rank r (setup only): the distributed ingest's per-rank rows."""
+        out = [None]
+        self._dist.scatter_object_list(out, objs if self.rank == src else None, src=src, group=self.host_group)
+        return out[0]
+
 
 class WindowComm(TorchDistComm):
     """TorchDistComm plus what the free-running one-sided mode needs (communicate.cpp's windows,

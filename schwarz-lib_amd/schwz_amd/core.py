@@ -314,6 +314,29 @@ class Problem:
         return cls(h)
 
     @classmethod
+    def from_rows(cls, N, row_ids, rp, col, val):
+        """A row source that holds the rows `row_ids` (ascending global ids) of an N x N matrix only:
+        what a rank receives in the distributed ingest (schwz_problem_from_rows)."""
+        row_ids = np.ascontiguousarray(row_ids, dtype=np.int64)
+        rp = np.ascontiguousarray(rp, dtype=np.int64)
+        col = np.ascontiguousarray(col, dtype=IDX)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        h = C.c_void_p()
+        check(lib.schwz_problem_from_rows(int(N), len(row_ids), ptr(row_ids), ptr(rp), ptr(col), ptr(val),
+                                          C.byref(h)))
+        return cls(h)
+
+    def extract_rows(self, row_ids):
+        """(rp, col, val) of the rows `row_ids`, columns global (schwz_problem_extract_rows)."""
+        row_ids = np.ascontiguousarray(row_ids, dtype=np.int64)
+        rp = np.zeros(len(row_ids) + 1, dtype=np.int64)
+        check(lib.schwz_problem_extract_rows(self.h, len(row_ids), ptr(row_ids), ptr(rp), None, None))
+        col = np.zeros(max(int(rp[-1]), 1), dtype=IDX)
+        val = np.zeros(max(int(rp[-1]), 1), dtype=np.float64)
+        check(lib.schwz_problem_extract_rows(self.h, len(row_ids), ptr(row_ids), ptr(rp), ptr(col), ptr(val)))
+        return rp, col[:rp[-1]], val[:rp[-1]]
+
+    @classmethod
     def from_matrix_market(cls, path):
         """initialization.cpp:204-213."""
         h = C.c_void_p()

@@ -164,6 +164,7 @@ class HipBackend:
     problem_laplacian = staticmethod(core.Problem.laplacian)
     problem_from_matrix_market = staticmethod(core.Problem.from_matrix_market)
     problem_from_csr = staticmethod(core.Problem.from_csr)
+    problem_from_rows = staticmethod(core.Problem.from_rows)
     partition_regular = staticmethod(core.partition_regular)
     partition_regular2d = staticmethod(core.partition_regular2d)
 
@@ -273,6 +274,43 @@ class SolverRAS:
         m.global_size = prob.N
         return prob
 
+    def _distributed_ingest(self):
+        """A matrix FILE on several rank processes: the root parses and partitions, every other rank
+        receives the rows its subdomain reads (SCHWZ_DISTRIBUTED_INGEST=0: every rank parses the file and
+        keeps the whole matrix, like the reference, initialization.cpp:204-213)."""
+        s, comm = self.settings, self.comm
+        return (self._user_matrix is None and s.matrix_filename != "null" and comm.size > 1
+                and len(comm.local_ranks) == 1 and hasattr(comm, "scatter_objects")
+                and hasattr(self.backend, "problem_from_rows")
+                and os.environ.get("SCHWZ_DISTRIBUTED_INGEST", "1") != "0")
+
+    def _ingest_distributed(self):
+        """Root: Matrix-Market file -> partition / permutation -> for every rank the interior and overlap
+        rows of its subdomain (what schwz_subdomain_setup reads), cut out of the permuted matrix.  Every
+        rank: a row source over its own part only (schwz_problem_from_rows); sizes, first_row and the
+        permutation are broadcast.  Nothing of global length but the permutation lives on a non-root rank."""
+        s, m, be, comm = self.settings, self.metadata, self.backend, self.comm
+        P = m.num_subdomains
+        meta, pieces = None, None
+        if comm.is_root:
+            full = be.problem_from_matrix_market(s.matrix_filename)
+            self._print("Matrix from file " + s.matrix_filename + " (parsed on the root, rows distributed)")
+            m.global_size = full.N
+            full = self._partition(full)
+            pieces = []
+            for r in range(P):
+                host_sd = core.Subdomain(full, P, r, s.overlap, m.first_row)
+                rows = np.sort(np.asarray(host_sd.local_to_global[:host_sd.local_size_x], dtype=np.int64))
+                pieces.append((rows,) + tuple(full.extract_rows(rows)))
+                host_sd.close()
+            meta = (full.N, np.asarray(m.first_row, dtype=np.int64),
+                    None if m.permutation is None else np.asarray(m.permutation, dtype=np.int64))
+            full.close()
+        N, first_row, perm = comm.broadcast_object(meta)
+        rows, rp, col, val = comm.scatter_objects(pieces)
+        m.global_size, m.first_row, m.permutation = int(N), first_row, perm
+        return be.problem_from_rows(int(N), rows, rp, col, val)
+
     def _partition(self, prob):
         """Initialize::partition (initialization.cpp:278-329) + the first_row /
         permutation part of setup_local_matrices (restricted_schwarz.cpp:84-152)."""
@@ -337,8 +375,11 @@ class SolverRAS:
             raise capi.NotImplementedSchwz(capi.ERR_NOT_IMPLEMENTED,
                                            "non_symmetric_matrix needs the iterative local solver (GMRES); "
                                            "the direct path is an LL^T factorization")
-        prob = self._setup_global_matrix()
-        prob = self._partition(prob)
+        if self._distributed_ingest():
+            prob = self._ingest_distributed()
+        else:
+            prob = self._setup_global_matrix()
+            prob = self._partition(prob)
         self.problem = prob
         P = m.num_subdomains
         for me in comm.local_ranks:

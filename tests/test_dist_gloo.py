@@ -263,3 +263,109 @@ def test_free_running_onesided_mode(oracle, name, tmp_path):
         others = [iters[r] for r in range(world) if r != slow]
         # the fast ranks ran ahead: they did clearly more iterations than the rank that sleeps
         assert min(others) > iters[slow]
+
+
+# ---------------------------------------------------------------------------------------------------
+# Distributed ingest of a Matrix-Market file: the root parses and partitions, every rank
+# receives the rows its subdomain reads and sets its subdomain up on that part alone.
+# ---------------------------------------------------------------------------------------------------
+
+class _HostBackend:
+    """What SolverRAS needs from a backend up to the subdomain index sets: the host-side entry points of the
+    product library (no GPU involved)."""
+
+    def __init__(self):
+        import schwz_amd.core as core
+        self.problem_from_matrix_market = core.Problem.from_matrix_market
+        self.problem_from_rows = core.Problem.from_rows
+        self.partition_regular = core.partition_regular
+        self.partition_regular2d = core.partition_regular2d
+
+
+def _ingest_worker(rank, world, port, path, partition, overlap, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "1"
+    for p in (HERE, os.path.join(os.path.dirname(HERE), "schwarz-lib_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import schwz_amd as S
+    import schwz_amd.core as core
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        s = S.Settings(matrix_filename=path, partition=partition, overlap=overlap, explicit_laplacian=False)
+        m = S.Metadata()
+        solver = S.SolverRAS(s, m, comm=S.TorchDistComm(), backend=_HostBackend(), quiet=True)
+        assert solver._distributed_ingest()
+        part = solver._ingest_distributed()
+        # this rank's subdomain from ITS part of the matrix ...
+        sd = core.Subdomain(part, world, rank, overlap, m.first_row)
+        # ... and from the whole file, parsed here only to check: same partition, same permutation
+        ref_solver = S.SolverRAS(S.Settings(matrix_filename=path, partition=partition, overlap=overlap,
+                                            explicit_laplacian=False), S.Metadata(),
+                                 comm=S.InProcessComm(world), backend=_HostBackend(), quiet=True)
+        full = ref_solver._partition(core.Problem.from_matrix_market(path))
+        ref = core.Subdomain(full, world, rank, overlap, ref_solver.metadata.first_row)
+        assert np.array_equal(np.asarray(m.first_row), np.asarray(ref_solver.metadata.first_row))
+        if ref_solver.metadata.permutation is None:
+            assert m.permutation is None
+        else:
+            assert np.array_equal(m.permutation, ref_solver.metadata.permutation)
+        assert part.N == full.N and part.nnz < full.nnz  # it really holds a part only
+        for a, b in zip(sd.local_matrix() + sd.interface_matrix(), ref.local_matrix() + ref.interface_matrix()):
+            assert np.array_equal(a, b)
+        assert np.array_equal(sd.local_to_global, ref.local_to_global)
+        assert [(q, list(ids)) for q, ids in sd.get_lists()] == [(q, list(ids)) for q, ids in ref.get_lists()]
+        # a row this rank was not sent is an error, not a silent empty row
+        other = int(ref_solver.metadata.first_row[(rank + world // 2 + 1) % world])
+        if other not in set(sd.local_to_global[:sd.local_size_x].tolist()):
+            cols, _ = part.row(other)
+            try:
+                core.Subdomain(part, world, (rank + world // 2 + 1) % world, overlap, m.first_row)
+                raise AssertionError("a subdomain was built from rows this rank does not hold")
+            except S.capi.SchwzError:
+                pass
+        open(os.path.join(out_dir, "ok_%d" % rank), "w").write("%d %d" % (part.nnz, full.nnz))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("partition,overlap", [("regular", 2), ("metis", 2), ("metis", 3)])
+def test_distributed_ingest_builds_the_same_subdomains(tmp_path, partition, overlap):
+    """One rank parses the Matrix-Market file and partitions; every rank receives the interior and overlap rows
+    of its subdomain only (schwz_problem_extract_rows / _from_rows over the gloo host group) and builds index
+    sets, local and interface matrices and get lists from that part: bit-identical to the subdomain built
+    from the whole matrix, with the same first_row and permutation on every rank."""
+    rng = np.random.default_rng(5)
+    n = 23  # a 2-D grid graph with a few random long-range couplings, unsymmetric values
+    N = n * n
+    entries = {}
+    for i in range(N):
+        entries[(i, i)] = 4.0 + rng.random()
+        for j in (i - 1 if i % n else -1, i + 1 if (i + 1) % n else -1, i - n, i + n):
+            if 0 <= j < N:
+                entries[(i, j)] = -1.0 - 0.1 * rng.random()
+    for _ in range(40):
+        i, j = int(rng.integers(N)), int(rng.integers(N))
+        entries[(i, j)] = entries.get((i, j), 0.0) + 0.01
+        entries[(j, i)] = entries.get((j, i), 0.0) + 0.02
+    path = str(tmp_path / "graph.mtx")
+    with open(path, "w") as f:
+        f.write("%%%%MatrixMarket matrix coordinate real general\n%d %d %d\n" % (N, N, len(entries)))
+        for (i, j), v in entries.items():
+            f.write("%d %d %.17g\n" % (i + 1, j + 1, v))
+    world = 3
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_ingest_worker, args=(r, world, port, path, partition, overlap, str(tmp_path)))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+        assert p.exitcode == 0, "worker failed with exit code %s" % p.exitcode
+    assert all(os.path.exists(str(tmp_path / ("ok_%d" % r))) for r in range(world))

@@ -775,3 +775,88 @@ def test_free_running_onesided_mode_through_hip_ipc_windows(schwz, oracle, torch
     x = np.load(sol)
     assert np.abs(x - ref["solution"]).max() <= (2e-3 if mixed else 1e-4) * np.abs(ref["solution"]).max()
     assert outs[0]["rel"] < (1e-2 if mixed else 1e-4)
+
+
+_INGEST_RANK = r"""
+import json, os, sys
+sys.path.insert(0, %(pkg)r)
+import numpy as np
+import torch, torch.distributed as dist
+import schwz_amd as S
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+comm = S.TorchDistComm(device=torch.device("cuda", 0))
+s = S.Settings(matrix_filename=%(path)r, partition=S.PARTITION_METIS, explicit_laplacian=False)
+m = S.Metadata(tolerance=1e-8, max_iters=400, local_precond="block-jacobi", precond_max_block_size=1,
+               local_solver_tolerance=1e-11)
+solver = S.SolverRAS(s, m, comm=comm, quiet=True)
+assert solver._distributed_ingest()
+solver.initialize()
+held = solver.problem.nnz
+out = solver.run()
+if comm.rank == 0:
+    np.save(%(sol)r, out["solution"])
+print(json.dumps(dict(rank=comm.rank, iters=out["iter_count"], conv=bool(out["converged"]), held=int(held),
+                      rel=out["residual_norm"] / out["rhs_norm"])), flush=True)
+dist.destroy_process_group()
+"""
+
+
+def test_ras_from_a_matrix_file_with_distributed_ingest(schwz, oracle, torch_cuda, tmp_path):
+    """Three rank processes sharing this GPU solve a system read from a Matrix-Market file: only the root
+    parses it; every rank sets its subdomain up on the rows it was sent.  The run is the one a
+    single process holding the whole matrix performs with the same partition: same iteration count, same
+    solution."""
+    import json
+    import subprocess
+    import sys
+    import socket
+    n = 28
+    rp, col, val = oracle.laplacian2d(n)
+    N = n * n
+    val = val.copy()
+    rng = np.random.default_rng(9)
+    for i in range(N):  # a symmetric positive definite variation of the stencil
+        for j in range(rp[i], rp[i + 1]):
+            if col[j] == i:
+                val[j] += 0.5 * rng.random()
+    path = str(tmp_path / "spd.mtx")
+    with open(path, "w") as f:
+        f.write("%%%%MatrixMarket matrix coordinate real general\n%d %d %d\n" % (N, N, rp[-1]))
+        for i in range(N):
+            for j in range(rp[i], rp[i + 1]):
+                f.write("%d %d %.17g\n" % (i + 1, col[j] + 1, val[j]))
+    world = 3
+    sol = str(tmp_path / "sol.npy")
+    script = tmp_path / "rank.py"
+    script.write_text(_INGEST_RANK % dict(
+        pkg=os.path.join(os.path.dirname(os.path.dirname(__file__)), "schwarz-lib_amd"), path=path, sol=sol))
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, e = p.communicate()
+        assert p.returncode == 0, o + e[-3000:]
+        outs.append(json.loads([ln for ln in o.splitlines() if ln.startswith("{")][-1]))
+    assert all(o["conv"] for o in outs) and len({o["iters"] for o in outs}) == 1
+    assert all(o["held"] < rp[-1] for o in outs)  # nobody but the (temporary) root copy held the whole matrix
+    # the same system, whole matrix in one process
+    solver, m, out = _run_gpu(schwz, world, dict(matrix_filename=path, partition=schwz.PARTITION_METIS,
+                                                 explicit_laplacian=False),
+                              dict(tolerance=1e-8, max_iters=400, local_precond="block-jacobi",
+                                   precond_max_block_size=1, local_solver_tolerance=1e-11))
+    assert out["converged"] and out["iter_count"] == outs[0]["iters"]
+    got = np.load(sol)
+    assert np.abs(got - out["solution"]).max() <= 1e-12 * np.abs(out["solution"]).max()
