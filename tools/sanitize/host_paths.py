@@ -20,6 +20,31 @@ for P in (1, 3, 8):
             sd = vp()
             rc = L.schwz_subdomain_setup(prob, P, me, ov, p(fr), C.byref(sd)); assert rc == 0, (rc, P, me)
             pass
+# distributed ingest: the rows a subdomain reads, cut out and used as the only row source
+L.schwz_subdomain_sizes.argtypes = [vp, vp]
+L.schwz_subdomain_local_to_global.argtypes = [vp, vp]
+L.schwz_problem_extract_rows.argtypes = [vp, i64, vp, vp, vp, vp]
+L.schwz_problem_from_rows.argtypes = [i64, i64, vp, vp, vp, vp, C.POINTER(vp)]
+for P, ov in ((3, 2), (5, 3)):
+    fr = oracle.first_rows_regular(N, P).astype(np.int64)
+    for me in range(P):
+        sd = vp()
+        assert L.schwz_subdomain_setup(prob, P, me, ov, p(fr), C.byref(sd)) == 0
+        sz = np.zeros(10, dtype=np.int64)
+        assert L.schwz_subdomain_sizes(sd, p(sz)) == 0
+        l2g = np.zeros(sz[1] + sz[3], dtype=np.int64)
+        assert L.schwz_subdomain_local_to_global(sd, p(l2g)) == 0
+        rows = np.sort(l2g[:sz[1]])
+        rpr = np.zeros(len(rows) + 1, dtype=np.int64)
+        assert L.schwz_problem_extract_rows(prob, len(rows), p(rows), p(rpr), None, None) == 0
+        cr = np.zeros(rpr[-1], dtype=col.dtype); vr = np.zeros(rpr[-1])
+        assert L.schwz_problem_extract_rows(prob, len(rows), p(rows), p(rpr), p(cr), p(vr)) == 0
+        part_prob = vp()
+        assert L.schwz_problem_from_rows(N, len(rows), p(rows), p(rpr), p(cr), p(vr), C.byref(part_prob)) == 0
+        sd2 = vp()
+        assert L.schwz_subdomain_setup(part_prob, P, me, ov, p(fr), C.byref(sd2)) == 0
+        sd3 = vp()  # another rank's subdomain from this part: refused (a row is missing)
+        rc3 = L.schwz_subdomain_setup(part_prob, P, (me + 1) % P, ov, p(fr), C.byref(sd3)); assert P != 3 or rc3 != 0, (P, ov, me)
 # factorizations
 out7 = [vp() for _ in range(7)]
 L.schwz_cholesky.argtypes = [i64, vp, vp, vp, C.c_int] + [C.POINTER(vp)] * 7
