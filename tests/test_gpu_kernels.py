@@ -812,11 +812,17 @@ def test_z_sweep_update_launch_matches_the_gather_walk(schwz, oracle, torch_cuda
     assert abs(it0 - it1) <= 1 and np.abs(x_ref - x_sw).max() <= 1e-8 * np.abs(x_ref).max()
 
 
-def test_pcg_accepts_a_right_hand_side_that_is_only_8_byte_aligned(schwz, oracle, torch_cuda):
+@pytest.mark.parametrize("walk", [False, True])
+def test_pcg_accepts_a_right_hand_side_that_is_only_8_byte_aligned(schwz, oracle, torch_cuda, monkeypatch, walk):
     """The CG start residual reads b with 16-byte loads; the caller's b need only be aligned like
-    a double (x must be 16-byte aligned, which the entry point checks)."""
+    a double (x must be 16-byte aligned, which the entry point checks).  Chunk-by-chunk start launch and
+    the start launch of the z-sweep walk (forced on a small grid)."""
     torch = torch_cuda
-    rp, col, val = oracle.laplacian3d(24, 24, 24)
+    if walk:
+        for k, v in (("SCHWZ_SPMV_PATTERN", "2"), ("SCHWZ_SPMV_PAIR", "2"), ("SCHWZ_SPMV_SWEEP", "2"),
+                     ("SCHWZ_SWEEP_T", "512"), ("SCHWZ_CG_DEFERX", "2")):
+            monkeypatch.setenv(k, v)
+    rp, col, val = oracle.laplacian3d(256, 4, 12) if walk else oracle.laplacian3d(24, 24, 24)
     n = len(rp) - 1
     rng = np.random.default_rng(3)
     b = rng.standard_normal(n)
@@ -832,6 +838,7 @@ def test_pcg_accepts_a_right_hand_side_that_is_only_8_byte_aligned(schwz, oracle
         it, rn = cg.solve(view.data_ptr(), d_x.data_ptr(), 0.0, 20)
         res.append((d_x.cpu().numpy(), rn))
     assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
+    assert (cg.flavour() & 32 != 0) == walk
     with pytest.raises(schwz.capi.SchwzError):
         d_x = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
         cg.solve(buf.data_ptr(), d_x[1:].data_ptr(), 0.0, 2)
