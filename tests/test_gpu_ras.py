@@ -171,6 +171,18 @@ def test_early_exchange_is_bit_identical_to_the_exchange_at_the_start_of_the_ste
     assert np.array_equal(runs["1"][1], runs["0"][1])
     assert np.array_equal(runs["1"][2], runs["0"][2])
     assert runs["1"][3] == runs["0"][3]
+    # a run that ends at max_iters with the next exchange already posted: finish_run consumes it
+    cut = {}
+    for early in ("1", "0"):
+        monkeypatch.setenv("SCHWZ_EARLY_EXCHANGE", early)
+        solver, m, out = _run_gpu(schwz, P, dict(kw_s), dict(kw_m, max_iters=4))
+        assert not out["converged"] and out["iter_count"] == 4
+        cut[early] = (out["solution"].copy(), out["residual_norm"])
+        out2 = solver.run()  # and a second run of the same solver starts from a clean exchange state
+        assert out2["iter_count"] == 4
+        cut[early] += (out2["solution"].copy(), out2["residual_norm"])
+    assert np.array_equal(cut["1"][0], cut["0"][0]) and cut["1"][1] == cut["0"][1]
+    assert np.array_equal(cut["1"][2], cut["0"][2]) and cut["1"][3] == cut["0"][3]
 
 
 def test_two_stage_local_criterion_matches_oracle(schwz, oracle, torch_cuda):
