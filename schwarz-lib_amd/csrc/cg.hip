@@ -79,8 +79,9 @@ __device__ __forceinline__ double diag_one(const DiagView &dg, const double *ddi
 }
 
 // x += alpha p ; r -= alpha q ; z = dinv r ; partials: r.z and r.r
-// U: 16-byte elements per lane in flight per trip; NT: non-temporal stores
-template <int U, bool NT>
+// U: 16-byte elements per lane in flight per trip; NT: non-temporal stores; NOX: x and p are not touched
+// (deferred x update of the stored-q iteration: alpha goes to *alpha_out instead, see cg_flush_x_kernel)
+template <int U, bool NT, bool NOX = false>
 __global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, double *__restrict__ x,
                                                            double *__restrict__ r,
                                                            const double *__restrict__ p,
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, double *__
                                                            const DiagView dg,
                                                            const double *pq_partials, int nparts_in,
                                                            const CgState *st, int it,
-                                                           double *partials_out)
+                                                           double *partials_out, double *alpha_out = nullptr)
 {
     __shared__ double red[4];
     __shared__ double ddict[256];
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, double *__
     const uint16_t *dc2 = reinterpret_cast<const uint16_t *>(dg.code);
     const double pq = fold_partials(pq_partials, nparts_in, red);
     const double alpha = st->rho[it & 1] / pq;
+    if (NOX && alpha_out && blockIdx.x == 0 && threadIdx.x == 0) *alpha_out = alpha;
     double a0 = 0.0, a1 = 0.0;
     const int64_t n2 = n >> 1;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
@@ -115,9 +117,11 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, double *__
         for (int u = 0; u < U; ++u) {
             const int64_t i = i0 + u * stride;
             if (i < n2) {
-                xv[u] = x2[i];
+                if (!NOX) {
+                    xv[u] = x2[i];
+                    pv[u] = p2[i];
+                }
                 rv[u] = r2[i];
-                pv[u] = p2[i];
                 qv[u] = q2[i];
                 dv[u] = diag_pair(dg, d2, dc2, ddict, i);
             }
@@ -126,9 +130,13 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, double *__
         for (int u = 0; u < U; ++u) {
             const int64_t i = i0 + u * stride;
             if (i < n2) {
-                xv[u] += alpha * pv[u];
+                if (!NOX) {
+                    // one fused multiply-add per element, spelled out: cg_flush_x_kernel (fused = 1) repeats it
+                    xv[u].x = __builtin_fma(alpha, pv[u].x, xv[u].x);
+                    xv[u].y = __builtin_fma(alpha, pv[u].y, xv[u].y);
+                    store2<NT>(x, i, xv[u]);
+                }
                 rv[u] -= alpha * qv[u];
-                store2<NT>(x, i, xv[u]);
                 store2<NT>(r, i, rv[u]);
                 vd2 z = rv[u];
                 if (dg.mode) z *= dv[u];
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(int64_t n, double *__
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const int64_t i = n - 1;
-        x[i] += alpha * p[i];
+        if (!NOX) x[i] = __builtin_fma(alpha, p[i], x[i]);
         const double rv = r[i] - alpha * q[i];
         r[i] = rv;
         const double z = dg.mode ? diag_one(dg, ddict, i) * rv : rv;
@@ -259,7 +267,7 @@ struct PRing {
 __global__ __launch_bounds__(kBlock) void cg_flush_x_kernel(int64_t n, double *__restrict__ x, const PRing ring,
                                                             const double *__restrict__ alpha_hist,
                                                             const CgState *st, int b0, int count, int pending,
-                                                            int64_t pair0, int64_t pair1, int tail)
+                                                            int64_t pair0, int64_t pair1, int tail, int fused)
 {
 #pragma clang fp contract(off)
     __shared__ double alpha[kDeferDepth];
@@ -282,8 +290,13 @@ __global__ __launch_bounds__(kBlock) void cg_flush_x_kernel(int64_t n, double *_
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (k0 + k < kmax) {
-                    const vd2 inc = alpha[k0 + k] * pv[k];
-                    xv = xv + inc;
+                    if (fused) {  // the stored-q iteration's update: x = fma(alpha, p, x)
+                        xv.x = __builtin_fma(alpha[k0 + k], pv[k].x, xv.x);
+                        xv.y = __builtin_fma(alpha[k0 + k], pv[k].y, xv.y);
+                    } else {      // the q-free update launch: product rounded, then added
+                        const vd2 inc = alpha[k0 + k] * pv[k];
+                        xv = xv + inc;
+                    }
                 }
         }
         __builtin_nontemporal_store(xv, x2 + i);
@@ -291,8 +304,13 @@ __global__ __launch_bounds__(kBlock) void cg_flush_x_kernel(int64_t n, double *_
     if (tail && (n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         double xv = x[n - 1];
         for (int k = 0; k < kmax; ++k) {
-            const double inc = alpha[k] * ring.slot[(b0 + k) % kDeferDepth][n - 1];
-            xv = xv + inc;
+            const double pk = ring.slot[(b0 + k) % kDeferDepth][n - 1];
+            if (fused) {
+                xv = __builtin_fma(alpha[k], pk, xv);
+            } else {
+                const double inc = alpha[k] * pk;
+                xv = xv + inc;
+            }
         }
         x[n - 1] = xv;
     }
@@ -863,10 +881,13 @@ static CgPlan pcg_plan(schwz_pcg *s)
     // iterations (and one at the end) applies x += sum_k alpha_k p_k in iteration order -- the same
     // bits, (depth + 2) / depth vectors of traffic per iteration instead of 2.
     // SCHWZ_CG_DEFERX=0: never, =2: every size (tests).
-    pl.deferx = pl.qfree && !s->ring_failed && (dx_mode == 2 || (dx_mode == 1 && n > kGraphRows));
+    // The stored-q iteration of the scalar-Jacobi / unpreconditioned CG (plain CSR and the other codings)
+    // defers x the same way; its ring cannot use s->q (it holds q), so it takes one more vector.
+    pl.deferx = !general && !s->ring_failed && (dx_mode == 2 || (dx_mode == 1 && n > kGraphRows));
     if (pl.deferx && !s->p_ring) {
         const size_t nb = (size_t)((n + 1) & ~int64_t(1)) * sizeof(double);
-        if (hipMalloc((void **)&s->p_ring, nb * (kDeferDepth - 2)) != hipSuccess ||
+        s->ring_has_q = pl.qfree;
+        if (hipMalloc((void **)&s->p_ring, nb * (kDeferDepth - (pl.qfree ? 2 : 1))) != hipSuccess ||
             hipMalloc((void **)&s->alpha_hist, kDeferDepth * sizeof(double)) != hipSuccess) {
             (void)hipGetLastError();  // not enough memory for the ring: the plain iteration
             (void)hipFree(s->p_ring);
@@ -967,9 +988,13 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
     PRing ring;
     const int64_t n_pad = (n + 1) & ~int64_t(1);
     for (int k = 0; k < kDeferDepth; ++k)
-        ring.slot[k] = k == 0 ? s->p : (k == 1 ? s->q : (s->p_ring ? s->p_ring + (int64_t)(k - 2) * n_pad : s->p));
+        ring.slot[k] = k == 0 ? s->p
+                                : (!s->p_ring ? s->p
+                                              : (s->ring_has_q ? (k == 1 ? s->q : s->p_ring + (int64_t)(k - 2) * n_pad)
+                                                               : s->p_ring + (int64_t)(k - 1) * n_pad));
     auto slot = [&](int it) -> double * { return const_cast<double *>(ring.slot[it % kDeferDepth]); };
     bool prio_recorded = false;
+    const int fused_x = qfree ? 0 : 1;  // how the in-launch update of this iteration forms x + alpha p
     auto flush_x = [&](int b0, int count, int pending, hipStream_t q, bool last = false) {
         const int64_t n2 = n >> 1;
         if (last && s->prio_on && s->prio_event && q == st && !prio_recorded) {
@@ -978,17 +1003,17 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
             const int64_t lo = std::min(s->prio_lo >> 1, n2), hi = std::max(std::min(s->prio_hi >> 1, n2), lo);
             if (lo > 0)
                 hipLaunchKernelGGL(cg_flush_x_kernel, dim3(grid_for(lo)), dim3(kBlock), 0, q, n, d_x, ring, s->alpha_hist,
-                                   s->state, b0, count, pending, (int64_t)0, lo, 0);
+                                   s->state, b0, count, pending, (int64_t)0, lo, 0, fused_x);
             hipLaunchKernelGGL(cg_flush_x_kernel, dim3(grid_for(n2 - hi + 1)), dim3(kBlock), 0, q, n, d_x, ring,
-                               s->alpha_hist, s->state, b0, count, pending, hi, n2, 1);
+                               s->alpha_hist, s->state, b0, count, pending, hi, n2, 1, fused_x);
             if (hipEventRecord(s->prio_event, q) == hipSuccess) prio_recorded = true;
             if (hi > lo)
                 hipLaunchKernelGGL(cg_flush_x_kernel, dim3(grid_for(hi - lo)), dim3(kBlock), 0, q, n, d_x, ring,
-                                   s->alpha_hist, s->state, b0, count, pending, lo, hi, 0);
+                                   s->alpha_hist, s->state, b0, count, pending, lo, hi, 0, fused_x);
             return;
         }
         hipLaunchKernelGGL(cg_flush_x_kernel, dim3(gv), dim3(kBlock), 0, q, n, d_x, ring, s->alpha_hist, s->state, b0,
-                           count, pending, (int64_t)0, n2, 1);
+                           count, pending, (int64_t)0, n2, 1, fused_x);
     };
     double *const pbuf[2] = {s->p, fusedir ? s->q : s->p};
     // SCHWZ_CG_LASTDIR=1: the last iteration of a solve updates the search direction like every other one
@@ -1080,6 +1105,18 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
                 hipLaunchKernelGGL((cg_direction_kernel<1, false>), dim3(gv), dim3(kBlock), 0, q, n, pbuf[it & 1], s->r,
                                    s->diag, part_vec, gs, s->state, it, rtol);
             }
+        } else if (!general && deferx) {
+            // stored q, x deferred: r -= alpha q (24 n bytes instead of 48-56 n), alpha to the history, the new
+            // direction into the next ring slot; the last iteration of a solve only advances the state
+            hipLaunchKernelGGL((cg_update_kernel<1, false, true>), dim3(gv), dim3(kBlock), 0, q, n, (double *)nullptr, s->r,
+                               (const double *)nullptr, s->q, s->diag, part_spmv, gs, s->state, it, part_vec,
+                               s->alpha_hist + it % kDeferDepth);
+            if ((it + 1) % kDeferDepth == 0) flush_x(it + 1 - kDeferDepth, kDeferDepth, it, q, instrument && it == max_iters - 1);
+            if (instrument && it == max_iters - 1 && last_state_only)
+                hipLaunchKernelGGL(cg_state_advance_kernel, dim3(1), dim3(kBlock), 0, q, part_vec, gv, s->state, it, rtol);
+            else
+                hipLaunchKernelGGL((cg_direction_kernel<1, false>), dim3(gv), dim3(kBlock), 0, q, n, slot(it), s->r,
+                                   s->diag, part_vec, gv, s->state, it, rtol, slot(it + 1));
         } else if (!general) {
             hipLaunchKernelGGL((cg_update_kernel<1, false>), dim3(gv), dim3(kBlock), 0, q, n, d_x, s->r, s->p, s->q,
                                s->diag, part_spmv, gs, s->state, it, part_vec);

@@ -330,6 +330,7 @@ struct schwz_pcg {
     double *p_ring = nullptr;      // kDeferDepth - 2 vectors; slots 0 and 1 of the ring are p and q
     double *alpha_hist = nullptr;  // kDeferDepth
     bool ring_failed = false;
+    bool ring_has_q = true;  // slot 1 of the ring is s->q (q-free iteration); false: the stored-q iteration's ring
     // the start launch of the running solve left p to the first fused direction launch (z-sweep start)
     bool p_pending = false;
     // Rows the caller wants final FIRST (a subdomain's boundary rows, which its neighbours wait for): the

@@ -679,23 +679,30 @@ def test_pcg_diagonal_representations_agree(schwz, oracle, torch_cuda, monkeypat
     assert np.abs(res[0][0] - exp).max() <= RTOL_CG * np.abs(exp).max()
 
 
+@pytest.mark.parametrize("coding", ["pairs", "plain_csr", "dictionary"])
 @pytest.mark.parametrize("n_edge", [(24, 20, 17), (21, 19, 15)])
-def test_deferred_x_update_is_bit_identical(schwz, oracle, torch_cuda, monkeypatch, n_edge):
+def test_deferred_x_update_is_bit_identical(schwz, oracle, torch_cuda, monkeypatch, n_edge, coding):
     """Large systems keep x out of the CG iteration: the search directions of up to 16 iterations
     stay in a ring, the update launch stores alpha_k, and one launch per full ring (and one at the
-    end) applies x += sum alpha_k p_k in iteration order.  Forced on a small system here
+    end) applies x += sum alpha_k p_k in iteration order -- in the q-free iteration of row-pair coded matrices
+    and in the stored-q iteration of the others (one more ring vector: q is in use).  Forced on a small system here
     (SCHWZ_CG_DEFERX=2) and compared bit for bit with the iteration that updates x itself: fixed
     iteration counts around the ring length, a tolerance stop inside a ring, even and odd n."""
     torch = torch_cuda
     rp, col, val = oracle.laplacian3d(*n_edge)
     n = len(rp) - 1
-    monkeypatch.setenv("SCHWZ_SPMV_PATTERN", "2")
-    monkeypatch.setenv("SCHWZ_SPMV_PAIR", "2")
+    if coding == "pairs":   # q-free iteration: x += alpha p rounded product by product
+        monkeypatch.setenv("SCHWZ_SPMV_PATTERN", "2")
+        monkeypatch.setenv("SCHWZ_SPMV_PAIR", "2")
+    else:                   # stored-q iteration (plain CSR / per-entry dictionaries): x = fma(alpha, p, x)
+        monkeypatch.setenv("SCHWZ_SPMV_PATTERN", "0")
+        monkeypatch.setenv("SCHWZ_SPMV_PAIR", "0")
+        monkeypatch.setenv("SCHWZ_SPMV_DICT", "0" if coding == "plain_csr" else "2")
     rng = np.random.default_rng(5)
     b = rng.standard_normal(n)
     x0 = 0.1 * rng.standard_normal(n)
     A = schwz.Csr(rp, col, val)
-    assert A.format() == 3
+    assert A.format() == {"pairs": 3, "plain_csr": 0, "dictionary": 1}[coding]
     cg = schwz.Pcg(A, 1)
 
     def solve(mode, iters, rtol):
@@ -706,7 +713,9 @@ def test_deferred_x_update_is_bit_identical(schwz, oracle, torch_cuda, monkeypat
 
     for iters in (1, 2, 15, 16, 17, 31, 32, 33, 50):
         it0, rn0, x_plain = solve("0", iters, 0.0)
+        assert cg.flavour() & 4 == 0
         it1, rn1, x_def = solve("2", iters, 0.0)
+        assert cg.flavour() & 4 == 4
         assert it0 == it1 == iters and rn0 == rn1
         assert np.array_equal(x_plain, x_def), iters
     exp, it_o, rn_o = oracle.pcg(rp, col, val, b, x0, 1, 0.0, 33)
