@@ -198,7 +198,7 @@ def kernel_source_hash():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "schwarz-lib_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".hpp", ".cpp")):
+        if name.endswith((".hip", ".hpp")):  # device code (host_setup.cpp is host-only)
             h.update(name.encode())
             h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
