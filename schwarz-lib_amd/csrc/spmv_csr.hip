@@ -764,8 +764,9 @@ int spmv_grid(const CsrView &A, int variant)
 int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipStream_t s)
 {
     if (A.nrows == 0) return SCHWZ_OK;
-    if (mode == kSpmvResidDual && variant != 0 && variant != 4 && variant != 6 && variant != 7 && variant != 8) {
-        set_error("launch_spmv: the fused dual-residual mode exists for variants 0, 4 and 6 only");
+    if (mode == kSpmvResidDual && variant != 0 && variant != 4 && variant != 6 && variant != 7 && variant != 8 &&
+        variant != 9) {
+        set_error("launch_spmv: the fused dual-residual mode exists for variants 0, 4, 6, 7, 8 and 9 only");
         return SCHWZ_ERR_INVALID;
     }
     const int grid = spmv_grid(A, variant);

@@ -412,7 +412,7 @@ int schwz_ras_check_and_solve_launch(schwz_subdomain *sd, schwz_stream stream)
     hipStream_t st = (hipStream_t)stream;
     const int64_t n = sd->local_size_x;
     if (n == 0) return SCHWZ_OK;
-    if (sd->opt.local_solver != SCHWZ_SOLVER_ITERATIVE || sd->gmres || (sd->opt.spmv_variant != 0 && sd->opt.spmv_variant != 4 && sd->opt.spmv_variant != 6 && sd->opt.spmv_variant != 7 && sd->opt.spmv_variant != 8)) {
+    if (sd->opt.local_solver != SCHWZ_SOLVER_ITERATIVE || sd->gmres || (sd->opt.spmv_variant != 0 && sd->opt.spmv_variant != 4 && sd->opt.spmv_variant != 6 && sd->opt.spmv_variant != 7 && sd->opt.spmv_variant != 8 && sd->opt.spmv_variant != 9)) {
         // no fused kernel for this configuration: the two steps back to back
         int rc = schwz_ras_local_residual_launch(sd, stream);
         if (rc) return rc;

@@ -185,6 +185,27 @@ def test_early_exchange_is_bit_identical_to_the_exchange_at_the_start_of_the_ste
     assert np.array_equal(cut["1"][2], cut["0"][2]) and cut["1"][3] == cut["0"][3]
 
 
+@pytest.mark.parametrize("P", [1, 3])
+def test_plain_csr_runs_are_bit_identical_with_the_stream_and_the_tiled_kernel(schwz, oracle, torch_cuda, P):
+    """Whole RAS runs on plain CSR (spmv_variant 6: spmv_stream_kernel in every mode it has -- start residual,
+    q = A p with the fused p.q -- and the tiled kernel for the fused dual residual of subdomains with
+    neighbours) against the same runs with the round-1 tiled kernel everywhere (variant 9): same tiles, same
+    grid, same partial sums -- the residual history and the solution are the same bits; and the oracle agrees."""
+    shape = (40, 33, 36)
+    runs = {}
+    for variant in (6, 9):
+        solver, m, out = _run_gpu(
+            schwz, P, dict(laplacian_dim=3, laplacian_shape=shape, spmv_variant=variant),
+            dict(tolerance=1e-7, max_iters=300, local_precond="block-jacobi", precond_max_block_size=1,
+                 local_solver_tolerance=1e-10))
+        runs[variant] = (out["iter_count"], np.array(m.post_process_data["global_residual_vector_out"]),
+                         out["solution"].copy())
+        if variant == 6:
+            _check_against_oracle(oracle, oracle.laplacian3d(*shape), P, solver, m, out)
+    assert runs[6][0] == runs[9][0]
+    assert np.array_equal(runs[6][1], runs[9][1]) and np.array_equal(runs[6][2], runs[9][2])
+
+
 def test_two_stage_local_criterion_matches_oracle(schwz, oracle, torch_cuda):
     """--reset_local_crit_iter / --updated_max_iters (solve.cpp:723-742): a cheap first stage
     (3 CG iterations per local solve) switches to converged local solves after outer iteration 4.
