@@ -534,8 +534,67 @@ void SchwarzBase<V, I, M>::run(std::shared_ptr<gko::matrix::Dense<V>> &solution)
     const int n_in = (int)im.nbr_in.size(), n_out = (int)im.nbr_out.size();
     std::vector<MPI_Request> reqs((size_t)(n_in + n_out));
 
+    // Early exchange of the synchronous loop (the Python host's SolverRAS._post_early_exchange):
+    // the exchange that belongs to the START of iteration k + 1 is posted beside the tail of the local solve
+    // of iteration k -- the solver finalises the rows of the put lists first and records an event,
+    // schwz_ras_pack_early waits for it on the side stream and reads the solve's result; the same values,
+    // the same iteration.  SCHWZ_EARLY_EXCHANGE=0: the reference's order.
+    bool early_pending = false;
+    int early_nreq = 0;
+    const char *early_env = std::getenv("SCHWZ_EARLY_EXCHANGE");
+    const bool early_ok = !(early_env && early_env[0] == '0') && P > 1 && !cs.enable_onesided &&
+                          schwz_ras_early_pack_ok(im.sd) != 0;
+    auto post_early = [&]() {
+        if (!im.side) {
+            HIP_CALL(hipStreamCreateWithFlags(&im.side, hipStreamNonBlocking));
+            HIP_CALL(hipEventCreateWithFlags(&im.ev_packed, hipEventDisableTiming));
+            HIP_CALL(hipEventCreateWithFlags(&im.ev_arrived, hipEventDisableTiming));
+        }
+        SCHWZ_CALL(schwz_ras_pack_early(im.sd, im.d_send, im.f32_wire ? 1 : 0, im.side));
+        if (im.nccl) {
+            NCCL_CALL(ncclGroupStart());
+            for (int k = 0; k < n_in; ++k)
+                NCCL_CALL(ncclRecv(im.wire(im.d_recv, im.recv_off[(size_t)k]),
+                                   (size_t)(im.recv_off[(size_t)k + 1] - im.recv_off[(size_t)k]), im.nccl_type(),
+                                   im.nbr_in[(size_t)k], im.nccl, im.side));
+            for (int k = 0; k < n_out; ++k)
+                NCCL_CALL(ncclSend(im.wire(im.d_send, im.send_off[(size_t)k]),
+                                   (size_t)(im.send_off[(size_t)k + 1] - im.send_off[(size_t)k]), im.nccl_type(),
+                                   im.nbr_out[(size_t)k], im.nccl, im.side));
+            NCCL_CALL(ncclGroupEnd());
+            HIP_CALL(hipEventRecord(im.ev_arrived, im.side));
+        } else {
+            // staged through pinned host memory: the device-to-host copy follows the pack on the side stream;
+            // the host waits for it (the boundary rows are final near the end of the solve) and posts the
+            // non-blocking MPI calls, which then run beside the restriction and the next iteration's start
+            if (im.sizes[9] > 0)
+                HIP_CALL(hipMemcpyAsync(im.h_send, im.d_send, (size_t)im.sizes[9] * im.wire_size(), hipMemcpyDeviceToHost, im.side));
+            HIP_CALL(hipStreamSynchronize(im.side));
+            early_nreq = 0;
+            for (int k = 0; k < n_in; ++k)
+                MPI_Irecv(im.wire(im.h_recv, im.recv_off[(size_t)k]), (int)(im.recv_off[(size_t)k + 1] - im.recv_off[(size_t)k]),
+                          im.mpi_type(), im.nbr_in[(size_t)k], 0, MPI_COMM_WORLD, &reqs[(size_t)early_nreq++]);
+            for (int k = 0; k < n_out; ++k)
+                MPI_Isend(im.wire(im.h_send, im.send_off[(size_t)k]), (int)(im.send_off[(size_t)k + 1] - im.send_off[(size_t)k]),
+                          im.mpi_type(), im.nbr_out[(size_t)k], 0, MPI_COMM_WORLD, &reqs[(size_t)early_nreq++]);
+        }
+        early_pending = true;
+    };
+
     // halo exchange: RCCL send/recv on the compute stream, or staged through pinned host memory
     auto exchange = [&]() {
+        if (early_pending) {  // already on its way (or arrived): only the unpack is left
+            early_pending = false;
+            if (im.nccl) {
+                HIP_CALL(hipStreamWaitEvent(im.stream, im.ev_arrived, 0));
+            } else {
+                MPI_Waitall(early_nreq, reqs.data(), MPI_STATUSES_IGNORE);
+                if (im.sizes[8] > 0)
+                    HIP_CALL(hipMemcpyAsync(im.d_recv, im.h_recv, (size_t)im.sizes[8] * im.wire_size(), hipMemcpyHostToDevice, im.stream));
+            }
+            SCHWZ_CALL(im.unpack(im.stream));
+            return;
+        }
         SCHWZ_CALL(im.pack(im.stream));
         if (im.nccl) {
             // one group = one fused launch; the stream orders it after the pack and before the
@@ -919,7 +978,10 @@ void SchwarzBase<V, I, M>::run(std::shared_ptr<gko::matrix::Dense<V>> &solution)
         } else {
             ppd.local_converged_iter_count.push_back(0);
         }
+        // step 4 first (it is only enqueued), then step 0 of the NEXT iteration: in the host-staged transport
+        // posting it waits for the solve's boundary rows
         SCHWZ_CALL(schwz_ras_restrict(im.sd, im.stream));
+        if (early_ok) post_early();
         const double t5 = now();
         timings[3].push_back((V)(t4 - t3));
         timings[4].push_back((V)(t5 - t4));
