@@ -410,6 +410,10 @@ class SolverRAS:
             off = sd.recv_offsets()
             for k, (p, _) in enumerate(sd.get_lists()):
                 self._recvs[(p, me)] = self.recv_buf[me][off[k]:off[k + 1]]
+        # out- / in-neighbour ranks per subdomain (the overlapped mode's flag messages go along these edges;
+        # put_lists() / get_lists() copy the id lists out of the library: not per iteration)
+        self._neighbour_ranks = {me: ([q for q, _ in sd.put_lists()], [p for p, _ in sd.get_lists()])
+                                 for me, sd in self.subdomains.items()}
         m.comm_data_struct = [
             (me, [(q, len(ids)) for q, ids in sd.put_lists()],
              [(p, len(ids)) for p, ids in sd.get_lists()], sd.num_send, sd.num_recv)
@@ -820,8 +824,7 @@ class SolverRAS:
             if self._mask[me] == full and self._stop[me] == NEVER:
                 self._stop[me] = it + P
         if not last:
-            neighbours = {me: ([q for q, _ in sd.put_lists()], [p for p, _ in sd.get_lists()])
-                          for me, sd in locals_}
+            neighbours = self._neighbour_ranks
             flags = comm.start_flags({me: (self._mask[me], self._stop[me]) for me, _ in locals_},
                                      neighbours)
             self._pending = dict(halo=halo, flags=flags)
