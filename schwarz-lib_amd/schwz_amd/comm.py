@@ -57,7 +57,7 @@ class InProcessComm:
         and fills the send buffers from the solves' results; the copies follow on the same stream."""
         import torch
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream()
+            self._side = torch.cuda.Stream(priority=-1)  # high priority: the small pack / copy kernels go first
         with torch.cuda.stream(self._side):
             pack(self._side.cuda_stream)
             self.exchange(sends, recvs)
@@ -198,7 +198,7 @@ class TorchDistComm:
         if overlap and ops and not self.stage_through_host and self.device.type != "cpu":
             torch = self._torch
             if self._side is None:
-                self._side = torch.cuda.Stream(device=self.device)
+                self._side = torch.cuda.Stream(device=self.device, priority=-1)
             self._side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._side):
                 works = dist.batch_isend_irecv(ops)
@@ -224,7 +224,8 @@ class TorchDistComm:
         stream.  finish_exchange() makes the compute stream wait for them."""
         torch, dist = self._torch, self._dist
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            # high priority: the pack kernel and the send / recv kernels are small and everybody waits for them
+            self._side = torch.cuda.Stream(device=self.device, priority=-1)
         ops = []
         for (src, dst), buf in sorted(sends.items()):
             ops.append(dist.P2POp(dist.isend, buf, dst, group=self.group))
