@@ -871,7 +871,8 @@ static CgPlan pcg_plan(schwz_pcg *s)
     const char *sweep_env = std::getenv("SCHWZ_CG_SWEEP");
     pl.sweep_on = !(sweep_env && sweep_env[0] == '0') && A.sweep_nslots > 0 && s->variant == 0 &&
                   A.ncols < (int64_t(1) << 28) && A.sweep_nslots + A.sweep_gen_blocks <= gs;
-    pl.sweep_dirdot = pl.sweep_on && A.canon_sym_val && (s->diag.mode == 0 || s->diag.mode == 3);
+    pl.sweep_dirdot = pl.sweep_on && A.canon_sym_val && (s->diag.mode == 0 || s->diag.mode == 3) &&
+                      A.sweep_nslots_dir + A.sweep_gen_blocks <= gs;
     pl.fusedir = pl.dot_mode == kSpmvDotSym &&
                  (fusedir_mode == 2 || (fusedir_mode == 1 && (n <= kGraphRows || pl.sweep_dirdot)));
     pl.flavour = !pl.qfree ? 0 : (pl.fusedir ? 2 : 1);

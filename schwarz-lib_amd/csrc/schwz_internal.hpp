@@ -112,6 +112,10 @@ struct CsrView {
     int sweep_T = 0, sweep_nx = 0, sweep_nslots = 0, sweep_ngen = 0, sweep_gen_blocks = 0;
     int64_t sweep_pl = 0;
     const int4 *sweep_seg = nullptr;
+    // the fused direction launch's own band height and segment table (spmv_pair_dirdot_sweep_kernel); equal to
+    // the update launch's unless SCHWZ_SWEEP_TDIR asks for taller bands
+    int sweep_T_dir = 0, sweep_nslots_dir = 0;
+    const int4 *sweep_seg_dir = nullptr;
     const schwz_idx *sweep_gen = nullptr;
     // per pattern of table 0: its entries in the nine slots [far before 0, far before 1, -NX, -1, 0, +1, +NX,
     // far after 0, far after 1] (9 PairVal) and the presence mask (bit k: row r has slot k, bit 16 + k: row r + 1)
@@ -279,6 +283,7 @@ struct schwz_csr {
     void *d_pat_id = nullptr, *d_tile_table = nullptr, *d_tbl_desc = nullptr, *d_tbl_len = nullptr, *d_tbl_val = nullptr,
          *d_tbl_delta = nullptr;
     void *d_pair_rle = nullptr;
+    void *d_sweep_seg_dir = nullptr;
     void *d_sweep_seg = nullptr, *d_sweep_gen = nullptr, *d_canon_val = nullptr, *d_canon_mask = nullptr,
          *d_canon_sym_val = nullptr, *d_canon_sym_mask = nullptr, *d_chain_plane = nullptr, *d_chain_far = nullptr;
     void *d_pair_id = nullptr, *d_tile_ptable = nullptr, *d_ptbl_desc = nullptr, *d_ptbl_len = nullptr,

@@ -856,7 +856,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
         for (int i = (int)gridDim.x + a.part_offset + tid; i < a.part_stride; i += kBlock)
             a.partials[i] = a.partials[a.part_stride + i] = 0.0;
     lds_barrier();
-    const int4 sg = A.sweep_seg[blockIdx.x];
+    const int4 sg = A.sweep_seg_dir[blockIdx.x];  // (its own table: the band height may differ from the update launch's)
     const int64_t PL = A.sweep_pl;
     const int band = sg.x, z0 = sg.y, z1 = sg.z;
     const int64_t gmax = A.ncols - 2;
@@ -1040,9 +1040,10 @@ bool pair_sweep_start_ok(const CsrView &A, int grid)
     if (!(A.pair_single && A.sweep_nslots > 0 && A.canon_sym_val && A.sweep_gen_blocks == 0 && A.sweep_nslots <= grid &&
           A.ncols < (int64_t(1) << 28)))
         return false;
-    const int nh = A.sweep_T / kPairRows;
+    const int nh = A.sweep_T / kPairRows, nh_dir = A.sweep_T_dir / kPairRows;
     const int nhl_upd = (A.sweep_nx + kBlock - 1) / kBlock, nhl_dir = (A.sweep_nx / 2 + kBlock - 1) / kBlock;
-    return (nh == 1 || nh == 2) && nhl_upd <= 4 && nhl_dir <= 2;
+    return (nh == 1 || nh == 2) && (nh_dir == 1 || nh_dir == 2 || nh_dir == 4) && nhl_upd <= 4 && nhl_dir <= 2 &&
+           A.sweep_nslots_dir <= grid;
 }
 
 // ... and with the fused dual residual: the flagged planes' chunk list exists and its launch fits the
@@ -1119,8 +1120,8 @@ int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hi
             set_error("launch_spmv_pair: the z-sweep first-direction launch does not apply to this matrix");
             return SCHWZ_ERR_INVALID;
         }
-        const int nhl = (A.sweep_nx / 2 + kBlock - 1) / kBlock, nh = A.sweep_T / kPairRows;
-        const size_t lds = (size_t)(4 * A.sweep_T + 2 * A.sweep_nx) * sizeof(double) + (size_t)A.canon_npat * (5 * 16 + 4);
+        const int nhl = (A.sweep_nx / 2 + kBlock - 1) / kBlock, nh = A.sweep_T_dir / kPairRows;
+        const size_t lds = (size_t)(4 * A.sweep_T_dir + 2 * A.sweep_nx) * sizeof(double) + (size_t)A.canon_npat * (5 * 16 + 4);
         SpmvArgs b = a;
         b.part_stride = grid;
         b.part_offset = 0;
@@ -1129,12 +1130,14 @@ int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hi
         static const hipError_t e0 = hipFuncSetAttribute((const void *)spmv_pair_dirdot_sweep_kernel<L_, H_, true>,      \
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);          \
         (void)e0;                                                                                                        \
-        hipLaunchKernelGGL((spmv_pair_dirdot_sweep_kernel<L_, H_, true>), dim3(A.sweep_nslots), dim3(kBlock), lds, s, A, b); \
+        hipLaunchKernelGGL((spmv_pair_dirdot_sweep_kernel<L_, H_, true>), dim3(A.sweep_nslots_dir), dim3(kBlock), lds, s, A, b); \
     }
         if (nh == 1 && nhl == 1) SCHWZ_DIRDOT_FIRST(1, 1)
         else if (nh == 1) SCHWZ_DIRDOT_FIRST(2, 1)
-        else if (nhl == 1) SCHWZ_DIRDOT_FIRST(1, 2)
-        else SCHWZ_DIRDOT_FIRST(2, 2)
+        else if (nh == 2 && nhl == 1) SCHWZ_DIRDOT_FIRST(1, 2)
+        else if (nh == 2) SCHWZ_DIRDOT_FIRST(2, 2)
+        else if (nhl == 1) SCHWZ_DIRDOT_FIRST(1, 4)
+        else SCHWZ_DIRDOT_FIRST(2, 4)
 #undef SCHWZ_DIRDOT_FIRST
         SCHWZ_HIP_TRY(hipGetLastError());
         return SCHWZ_OK;
@@ -1189,18 +1192,18 @@ int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hi
         }
     }
     if (mode == kSpmvDirDotSym && !wide && A.pair_single && A.sweep_nslots > 0 && A.canon_sym_val && a.diag_mode != 1 &&
-        a.diag_mode != 2 && A.sweep_nslots + A.sweep_gen_blocks <= grid) {
+        a.diag_mode != 2 && A.sweep_nslots_dir + A.sweep_gen_blocks <= grid) {
         const char *sweep_env = std::getenv("SCHWZ_CG_SWEEP");
         if (!(sweep_env && sweep_env[0] == '0')) {
-            const int nhl = (A.sweep_nx / 2 + kBlock - 1) / kBlock, nh = A.sweep_T / kPairRows;
-            const size_t lds = (size_t)(4 * A.sweep_T + 2 * A.sweep_nx) * sizeof(double) + (size_t)A.canon_npat * (5 * 16 + 4);
+            const int nhl = (A.sweep_nx / 2 + kBlock - 1) / kBlock, nh = A.sweep_T_dir / kPairRows;
+            const size_t lds = (size_t)(4 * A.sweep_T_dir + 2 * A.sweep_nx) * sizeof(double) + (size_t)A.canon_npat * (5 * 16 + 4);
             if (nhl <= 2) {
                 // the companion first: the z-sweep kernel's workgroup 0 advances CgState for both
                 if (A.sweep_gen_blocks > 0) {
                     SpmvArgs c = a;
                     c.sweep = 1;
                     c.part_stride = grid;
-                    c.part_offset = A.sweep_nslots;
+                    c.part_offset = A.sweep_nslots_dir;
                     hipLaunchKernelGGL((spmv_pair_kernel<kSpmvDirDotSym, false, true>), dim3(A.sweep_gen_blocks), dim3(kBlock),
                                        kPairTableLds, s, A, c);
                     SCHWZ_HIP_TRY(hipGetLastError());
@@ -1213,12 +1216,14 @@ int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hi
         static const hipError_t e0 = hipFuncSetAttribute((const void *)spmv_pair_dirdot_sweep_kernel<L_, H_>,            \
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);          \
         (void)e0;                                                                                                        \
-        hipLaunchKernelGGL((spmv_pair_dirdot_sweep_kernel<L_, H_>), dim3(A.sweep_nslots), dim3(kBlock), lds, s, A, b);    \
+        hipLaunchKernelGGL((spmv_pair_dirdot_sweep_kernel<L_, H_>), dim3(A.sweep_nslots_dir), dim3(kBlock), lds, s, A, b); \
     }
                 if (nh == 1 && nhl == 1) SCHWZ_DIRDOT_LAUNCH(1, 1)
                 else if (nh == 1) SCHWZ_DIRDOT_LAUNCH(2, 1)
-                else if (nhl == 1) SCHWZ_DIRDOT_LAUNCH(1, 2)
-                else SCHWZ_DIRDOT_LAUNCH(2, 2)
+                else if (nh == 2 && nhl == 1) SCHWZ_DIRDOT_LAUNCH(1, 2)
+                else if (nh == 2) SCHWZ_DIRDOT_LAUNCH(2, 2)
+                else if (nhl == 1) SCHWZ_DIRDOT_LAUNCH(1, 4)
+                else SCHWZ_DIRDOT_LAUNCH(2, 4)
 #undef SCHWZ_DIRDOT_LAUNCH
                 SCHWZ_HIP_TRY(hipGetLastError());
                 return SCHWZ_OK;
@@ -1529,42 +1534,81 @@ static int build_sweep(schwz_csr *A, int64_t nrows, const PairTable &tb, const P
     const int gen_blocks = (int)std::min<int64_t>((int64_t)gen.size(), std::max(256, std::min(1024, grid - seg_slots)));
     while (count(L) + kXcds > grid - gen_blocks && L < (1 << 20)) L += 4;
     struct Seg { int band, p0, p1; };
-    std::vector<Seg> segs;
-    for (const Run &r : runs) {
-        const int nseg = (r.p1 - r.p0 + L - 1) / L, len = (r.p1 - r.p0 + nseg - 1) / nseg;
-        for (int b = 0; b < bands; ++b)
-            for (int p = r.p0; p < r.p1; p += len) segs.push_back({b, p, std::min(p + len, r.p1)});
-    }
-    // deal: XCD x takes the bands [x * bands / 8, (x + 1) * bands / 8) (a band's window shares its NX-row
-    // halos with the neighbouring bands: the same L2), segment by segment along the chain
-    std::stable_sort(segs.begin(), segs.end(), [](const Seg &x, const Seg &y) { return x.p0 != y.p0 ? x.p0 < y.p0 : x.band < y.band; });
-    std::vector<std::vector<int4>> per_xcd(kXcds);
-    for (const Seg &sgm : segs) {
-        int4 v;
-        v.x = sgm.band;
-        v.y = sgm.p0;
-        v.z = sgm.p1;
-        v.w = 0;
-        size_t x;
-        if (bands >= 2 * kXcds) {
-            x = (size_t)((int64_t)sgm.band * kXcds / bands);
-        } else {  // few bands: round robin
-            x = 0;
-            for (size_t k = 1; k < (size_t)kXcds; ++k)
-                if (per_xcd[k].size() < per_xcd[x].size()) x = k;
+    // workgroup slots for bands of Tq rows and segments of about Lq chain positions
+    auto make_slots = [&](int Tq, int Lq) -> std::vector<int4> {
+        const int bands_q = (int)(PL / Tq);
+        std::vector<Seg> segs;
+        for (const Run &r : runs) {
+            const int nseg = (r.p1 - r.p0 + Lq - 1) / Lq, len = (r.p1 - r.p0 + nseg - 1) / nseg;
+            for (int b = 0; b < bands_q; ++b)
+                for (int p = r.p0; p < r.p1; p += len) segs.push_back({b, p, std::min(p + len, r.p1)});
         }
-        per_xcd[x].push_back(v);
-    }
-    size_t depth = 0;
-    for (const auto &l : per_xcd) depth = std::max(depth, l.size());
-    std::vector<int4> slots_v(depth * kXcds);
-    for (size_t q = 0; q < depth; ++q)
-        for (int x = 0; x < kXcds; ++x) {
+        // deal: XCD x takes the bands [x * bands / 8, (x + 1) * bands / 8) (a band's window shares its NX-row
+        // halos with the neighbouring bands: the same L2), segment by segment along the chain
+        std::stable_sort(segs.begin(), segs.end(), [](const Seg &x, const Seg &y) { return x.p0 != y.p0 ? x.p0 < y.p0 : x.band < y.band; });
+        std::vector<std::vector<int4>> per_xcd(kXcds);
+        for (const Seg &sgm : segs) {
             int4 v;
-            v.x = v.y = v.z = v.w = 0;
-            if (q < per_xcd[(size_t)x].size()) v = per_xcd[(size_t)x][q];
-            slots_v[q * kXcds + x] = v;
+            v.x = sgm.band;
+            v.y = sgm.p0;
+            v.z = sgm.p1;
+            v.w = 0;
+            size_t x;
+            if (bands_q >= 2 * kXcds) {
+                x = (size_t)((int64_t)sgm.band * kXcds / bands_q);
+            } else {  // few bands: round robin
+                x = 0;
+                for (size_t k = 1; k < (size_t)kXcds; ++k)
+                    if (per_xcd[k].size() < per_xcd[x].size()) x = k;
+            }
+            per_xcd[x].push_back(v);
         }
+        size_t depth = 0;
+        for (const auto &l : per_xcd) depth = std::max(depth, l.size());
+        std::vector<int4> out(depth * kXcds);
+        for (size_t q = 0; q < depth; ++q)
+            for (int x = 0; x < kXcds; ++x) {
+                int4 v;
+                v.x = v.y = v.z = v.w = 0;
+                if (q < per_xcd[(size_t)x].size()) v = per_xcd[(size_t)x][q];
+                out[q * kXcds + x] = v;
+            }
+        return out;
+    };
+    const std::vector<int4> slots_v = make_slots(T, L);
+    // The fused direction launch may take taller bands than the update launch (SCHWZ_SWEEP_TDIR=512|1024|2048):
+    // its window carries an NX-row halo of r AND p per band, so a band of twice the rows halves that share,
+    // while the update launch keeps four halo lines per window and prefers the shorter band.  A table of its
+    // own; equal to the update launch's when the band heights coincide.
+    // Measured in-box (tools/tdir_ab.sh): 256-wide planes, update bands of 512 rows: 1024-row bands for the fused
+    // launch -3 % per step (2048: +5 %); 512-wide planes, 1024 / 2048: +3 % (two workgroups per CU); 1024-wide
+    // planes, where a 1024-row band is a single x line, 2048: fused launch 0.773 -> 0.696 ms, -4 % per step.
+    const char *td_env = std::getenv("SCHWZ_SWEEP_TDIR");
+    int T_dir = td_env ? std::atoi(td_env) : (T == 512 ? 1024 : (NX >= 1024 ? 2048 : T));
+    if ((T_dir != 512 && T_dir != 1024 && T_dir != 2048) || PL % T_dir ||
+        (size_t)(4 * T_dir + 2 * NX) * sizeof(double) + (size_t)tb.npat * 84 > (size_t)(96 << 10))
+        T_dir = T;
+    std::vector<int4> slots_dir;
+    if (T_dir != T) {
+        const int bands_d = (int)(PL / T_dir);
+        int64_t steps_d = 0;
+        for (const Run &r : runs) steps_d += (int64_t)(r.p1 - r.p0) * bands_d;
+        const int per_cu_d = T_dir >= 2048 ? 1 : (T_dir == 1024 ? 2 : 3);
+        const char *ld_env = std::getenv("SCHWZ_SWEEP_LDIR");
+        int Ld = ld_env ? std::atoi(ld_env) : (int)std::max<int64_t>(8, (steps_d + per_cu_d * cus - 1) / (per_cu_d * cus));
+        if (Ld < 2) Ld = 16;
+        auto count_d = [&](int len) {
+            int64_t nq = 0;
+            for (const Run &r : runs) nq += (int64_t)((r.p1 - r.p0 + len - 1) / len) * bands_d;
+            return nq;
+        };
+        while (count_d(Ld) + kXcds > grid - gen_blocks && Ld < (1 << 20)) Ld += 4;
+        slots_dir = make_slots(T_dir, Ld);
+        if ((int64_t)slots_dir.size() + gen_blocks > grid) {
+            slots_dir.clear();
+            T_dir = T;
+        }
+    }
     // Rows the walk leaves out cost a companion launch per CG launch: measured with 256 x 256 planes, 8 / 4 / 1
     // slabs on one GPU when the boundary planes of a slab were still left out (tools/sweep_sizes.sh, bench.py
     // --ttr-subdomains): +13 % time at 2.2 M rows, +2 % at 4.3 M, -18 % at 16.8 M; without left-out rows the
@@ -1572,6 +1616,7 @@ static int build_sweep(schwz_csr *A, int64_t nrows, const PairTable &tb, const P
     const bool worth = gen.empty() || nrows >= 6000000 || sw_mode == 2;
     if (!worth || (int64_t)slots_v.size() + gen_blocks > grid || steps * T * 2 < nrows) return SCHWZ_OK;
     int rc;
+    if (!slots_dir.empty() && (rc = upv(slots_dir, &A->d_sweep_seg_dir))) return rc;
     if ((rc = upv(slots_v, &A->d_sweep_seg)) || (rc = upv(gen, &A->d_sweep_gen)) || (rc = upv(cval, &A->d_canon_val)) ||
         (rc = upv(cmsk, &A->d_canon_mask)) || (rc = upv(chain_plane, &A->d_chain_plane)) ||
         (rc = upv(chain_far, &A->d_chain_far)))
@@ -1595,6 +1640,9 @@ static int build_sweep(schwz_csr *A, int64_t nrows, const PairTable &tb, const P
     A->v.sweep_gen_blocks = gen_blocks;
     A->v.sweep_seg = (const int4 *)A->d_sweep_seg;
     A->v.sweep_gen = (const schwz_idx *)A->d_sweep_gen;
+    A->v.sweep_T_dir = slots_dir.empty() ? T : T_dir;
+    A->v.sweep_nslots_dir = slots_dir.empty() ? (int)slots_v.size() : (int)slots_dir.size();
+    A->v.sweep_seg_dir = slots_dir.empty() ? A->v.sweep_seg : (const int4 *)A->d_sweep_seg_dir;
     return SCHWZ_OK;
 }
 
@@ -1986,6 +2034,10 @@ int pair_set_dual_split(schwz_csr *A, const schwz_idx *h_rp, const schwz_idx *h_
 void free_spmv_pair(schwz_csr *A)
 {
     (void)hipFree(A->d_sweep_seg);
+    (void)hipFree(A->d_sweep_seg_dir);
+    A->d_sweep_seg_dir = nullptr;
+    A->v.sweep_seg_dir = nullptr;
+    A->v.sweep_T_dir = A->v.sweep_nslots_dir = 0;
     (void)hipFree(A->d_sweep_gen);
     (void)hipFree(A->d_canon_val);
     (void)hipFree(A->d_canon_mask);

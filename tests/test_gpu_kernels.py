@@ -739,7 +739,9 @@ def _slab_local_matrix(schwz, shape, P, me, overlap=2):
 @pytest.mark.parametrize("case", [("cube", (256, 4, 12), "512"), ("cube", (256, 4, 10), "1024"), ("cube", (512, 4, 8), "512"),
                                   ("cube", (512, 4, 8), "1024"), ("cube", (256, 8, 7), "512"), ("slab", (256, 4, 30), "512"),
                                   ("slab", (256, 4, 30), "1024"), ("end", (256, 4, 24), "512"),
-                                  ("slab4", (256, 4, 36), "512"), ("first", (256, 4, 24), "1024")])
+                                  ("slab4", (256, 4, 36), "512"), ("first", (256, 4, 24), "1024"),
+                                  # x lines of 1024 entries: the fused launch takes bands of 2048 rows (two lines)
+                                  ("cube", (1024, 4, 10), "1024"), ("slab", (1024, 4, 30), "1024")])
 def test_z_sweep_update_launch_matches_the_gather_walk(schwz, oracle, torch_cuda, monkeypatch, case):
     """The z-sweep walk of the q-free update launch (a band of rows swept through consecutive planes,
     every operand of the canonical stencil layout read from an LDS ring of plane windows) against the
