@@ -1013,3 +1013,51 @@ def test_gather_scatter_every_reference_instantiation(schwz, torch_cuda, vt, it)
         exp = big0.copy()
         exp[idx] = ref(big0[idx], src_s)
         assert np.array_equal(d_big.cpu().numpy(), exp)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_z_sweep_walk_on_random_grid_shapes(schwz, oracle, torch_cuda, monkeypatch, seed):
+    """Random grid shapes and slab cuts through the z-sweep walk (forced on small matrices): x lines of 256 /
+    512 / 1024 entries, 4-8 lines per plane, cubes and first / middle / last slabs of 2-4 with overlap 2 or 4.
+    Wherever the upload builds the walk, one CG iteration (start launch chunk by chunk) is bit-identical to
+    the gather walk, the solve that starts in the walk agrees to rounding, and 12 iterations match the oracle."""
+    torch = torch_cuda
+    rng = np.random.default_rng(1000 + seed)
+    nx = int(rng.choice([256, 256, 512, 1024]))
+    ny = int(rng.choice({256: [4, 6, 8], 512: [4, 5, 6], 1024: [4, 5]}[nx]))  # whole chunks of 512 rows per plane
+    nz = int(rng.integers(9, 30))
+    P = int(rng.integers(1, 5))
+    me = int(rng.integers(0, P))
+    overlap = int(rng.choice([2, 2, 4]))
+    monkeypatch.setenv("SCHWZ_SPMV_PATTERN", "2")
+    monkeypatch.setenv("SCHWZ_SPMV_PAIR", "2")
+    monkeypatch.setenv("SCHWZ_SPMV_SWEEP", "2")
+    if P == 1:
+        rp, col, val = oracle.laplacian3d(nx, ny, nz)
+    else:
+        rp, col, val = _slab_local_matrix(schwz, (nx, ny, nz * P), P, me, overlap=overlap)
+    n = len(rp) - 1
+    A = schwz.Csr(rp, col, val)
+    assert A.format() == 3
+    if A.sweep_slots() == 0:
+        pytest.skip("no walk for %dx%dx%d, P=%d me=%d overlap=%d" % (nx, ny, nz, P, me, overlap))
+    b = rng.standard_normal(n)
+    x0 = 0.1 * rng.standard_normal(n)
+    cg = schwz.Pcg(A, 1)
+
+    def solve(sweep, iters, start="0"):
+        monkeypatch.setenv("SCHWZ_CG_SWEEP", sweep)
+        monkeypatch.setenv("SCHWZ_CG_DEFERX", "2")
+        monkeypatch.setenv("SCHWZ_CG_SWEEPSTART", start)
+        d_b, d_x = _dev(torch, b), _dev(torch, x0)
+        it, rn = cg.solve(d_b.data_ptr(), d_x.data_ptr(), 0.0, iters)
+        return rn, d_x.cpu().numpy()
+
+    rn0, x_ref = solve("0", 1)
+    rn1, x_sw = solve("1", 1)
+    assert cg.flavour() & 8 == 8, (cg.flavour(), nx, ny, nz, P, me, overlap)
+    assert np.array_equal(x_ref, x_sw), (nx, ny, nz, P, me, overlap)
+    rn2, x_st = solve("1", 1, start="1")
+    assert np.abs(x_ref - x_st).max() <= 1e-13 * np.abs(x_ref).max()
+    exp, _, _ = oracle.pcg(rp, col, val, b, x0, 1, 0.0, 12)
+    assert np.abs(solve("1", 12, start="1")[1] - exp).max() <= RTOL_CG * np.abs(exp).max()
