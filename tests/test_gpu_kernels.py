@@ -1015,7 +1015,7 @@ def test_gather_scatter_every_reference_instantiation(schwz, torch_cuda, vt, it)
         assert np.array_equal(d_big.cpu().numpy(), exp)
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SCHWZ_FUZZ_SEEDS", "10"))))  # more seeds: a fuzz run
 def test_z_sweep_walk_on_random_grid_shapes(schwz, oracle, torch_cuda, monkeypatch, seed):
     """Random grid shapes and slab cuts through the z-sweep walk (forced on small matrices): x lines of 256 /
     512 / 1024 entries, 4-8 lines per plane, cubes and first / middle / last slabs of 2-4 with overlap 2 or 4.
