@@ -73,6 +73,18 @@ def parse(argv=None):
                     help="wall-clock cap of each time-to-residual run (reported as not converged past it)")
     ap.add_argument("--cpu-iters", type=int, default=30,
                     help="outer iterations of the CPU sample (about 10-30 s of CPU work)")
+    ap.add_argument("--cpu-subdomains", default="2,4,8",
+                    help="N=1: CPU samples of the same grid cut into this many z-slabs as well (SURVEY 8d: P in 1,2,4,8)")
+    ap.add_argument("--no-mirror", action="store_true",
+                    help="skip the C++ mirror leg (the reference's unchanged bench_ras on libschwz.so)")
+    ap.add_argument("--mirror-iters", type=int, default=200)
+    ap.add_argument("--no-shapes", action="store_true",
+                    help="N=1: plain-CSR SpMV on this grid only, not on the per-GPU slabs of configs[2] / configs[4]")
+    ap.add_argument("--csr-shapes", default="512,512,64;1024,1024,128",
+                    help="N=1: further per-GPU shapes of the plain-CSR SpMV figure (configs[2] / configs[4] slabs)")
+    ap.add_argument("--strong-grid", default="512,512,512",
+                    help="grid of the strong-scaling leg every N runs after its weak-scaling leg ('' = skip)")
+    ap.add_argument("--strong-steps", type=int, default=10)
     return ap.parse_args(argv)
 
 
@@ -173,23 +185,83 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("SCHWZ_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(shape, inner, iters):
+def cpu_baseline(shape, inner, iters, subdomains=()):
     """The oracle (CPU restatement, kind 'port') on a bounded sample of the same
-    workload: the same grid and settings, `iters` outer iterations."""
+    workload: the same grid and settings, `iters` outer iterations; then the same grid cut into
+    P z-slabs (P in {1, 2, 4, 8}), the P subdomains taken in turn by all `cores`
+    OpenMP threads (the throughput of P ranks x cores/P threads on these cores), a third of the
+    iterations each."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import oracle as O
     cores = host_cores()
     rp, col, val = O.laplacian3d(*shape)
     N = len(rp) - 1
-    st = O.make_settings(max_iters=iters, tol=1e-30, precond=O.PRECOND_JACOBI, local_tol=0.0,
-                         local_max_iters=inner, num_threads=cores)
-    r = O.ras_run(rp, col, val, np.ones(N), 1, O.first_rows_regular(N, 1), st, history=False)
-    return dict(value=r["iter_count"] / r["elapsed_s"], unit="subdomain-iter/s", cores=cores,
-                kind="port",
-                sample="%d outer iterations of the same %dx%dx%d workload (1 subdomain, %d CG "
-                       "iterations each), OpenMP oracle, %.1f s" %
-                       (r["iter_count"], shape[0], shape[1], shape[2], inner, r["elapsed_s"]))
+
+    def sample(P, k):
+        st = O.make_settings(max_iters=k, tol=1e-30, precond=O.PRECOND_JACOBI, local_tol=0.0,
+                             local_max_iters=inner, num_threads=cores)
+        r = O.ras_run(rp, col, val, np.ones(N), P, O.first_rows_regular(N, P), st, history=False)
+        return r["iter_count"], r["elapsed_s"]
+
+    k1, t1 = sample(1, iters)
+    out = dict(value=k1 / t1, unit="subdomain-iter/s", cores=cores, kind="port",
+               sample="%d outer iterations of the same %dx%dx%d workload (1 subdomain, %d CG "
+                      "iterations each), OpenMP oracle, %.1f s" % (k1, shape[0], shape[1], shape[2], inner, t1))
+    by_p = {"1": {"outer_iter_per_s": k1 / t1, "subdomain_iter_per_s": k1 / t1, "outer_iters": k1, "seconds": t1}}
+    for P in subdomains:
+        if P <= 1 or shape[2] // P < 4:
+            continue
+        k, t = sample(P, max(3, iters // 3))
+        by_p[str(P)] = {"outer_iter_per_s": k / t, "subdomain_iter_per_s": P * k / t, "outer_iters": k, "seconds": t}
+    out["by_subdomains"] = by_p
+    out["by_subdomains_note"] = ("same grid, P z-slabs (overlap 2), the restated reference loop with the P "
+                                 "subdomains taken in turn by all %d threads" % cores)
+    return out
+
+
+def mirror_bench_ras(size, inner, iters):
+    """The reference's own driver (benchmarking/bench_ras.cpp compiled UNCHANGED against
+    schwarz-lib_amd/host/include, linked with libschwz.so -- north_star's boundary) on the same workload,
+    as a child process under mpiexec.  Iterations/s from the loop time the mirror prints, the five timing
+    ids from the CSV the driver's own writer produces (bench_base.hpp:219-273)."""
+    import re
+    import shutil
+    import tempfile
+    binary = os.path.join(ROOT, "schwarz-lib_amd", "build", "bench_ras")
+    mpiexec = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
+    if not os.path.exists(binary) or not os.path.exists(mpiexec):
+        return {"skipped": "bench_ras binary or mpiexec missing (built where the reference checkout exists)"}
+    with tempfile.TemporaryDirectory() as tmp:
+        cmd = [mpiexec, "-n", "1", binary, "--executor=hip", "--matrix_filename=poisson3d:%d" % size,
+               "--enable_global_check", "--set_tol=1e-30", "--num_iters=%d" % iters, "--local_precond=block-jacobi",
+               "--precond_max_block_size=1", "--local_max_iters=%d" % inner, "--local_tol=0",
+               "--timings_file=%s" % os.path.join(tmp, "t")]
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=tmp)
+        except Exception as exc:
+            return {"error": str(exc)}
+        wall = time.perf_counter() - t0
+        m = re.search(r"outer loop: (\d+) iterations in ([0-9.eE+-]+) s, cg flavour (\d+)", p.stdout)
+        if p.returncode != 0 or not m:
+            return {"error": (p.stdout + p.stderr)[-400:], "returncode": p.returncode}
+        k, t, flav = int(m.group(1)), float(m.group(2)), int(m.group(3))
+        timings = {}
+        try:
+            for l in open(os.path.join(tmp, "t_00.csv")).read().splitlines()[1:]:
+                f = l.split(",")
+                timings[f[0]] = {"total_s": float(f[1]), "avg_s": float(f[2]), "min_s": float(f[3]),
+                                 "med_s": float(f[4]), "max_s": float(f[5])}
+        except Exception:
+            pass
+        med = sum(v["med_s"] for v in timings.values()) if timings else None
+        return {"value": k / t, "unit": "subdomain-iter/s", "ms_per_step": 1e3 * t / k, "outer_iters": k,
+                "loop_seconds": t, "wall_seconds_with_setup": wall, "cg_flavour": flav,
+                "ms_per_step_median": 1e3 * med if med else None, "timings": timings,
+                "command": " ".join(["mpiexec -n 1 bench_ras"] + cmd[4:-1] + ["--timings_file=t"]),
+                "note": "reference benchmarking/bench_ras.cpp, unchanged, on libschwz.so (C++ mirror over the C ABI); "
+                        "no warm-up: the first iterations (first-use allocations) are inside the loop time"}
 
 
 def kernel_source_hash():
@@ -278,6 +350,10 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    mirror = None
+    if a.gpus == 1 and not a.no_mirror and "WORLD_SIZE" not in os.environ:
+        # a child process, finished before this process touches the GPU
+        mirror = mirror_bench_ras(a.size, a.inner, a.mirror_iters)
     import torch
     import schwz_amd as schwz
     import ctypes
@@ -460,6 +536,7 @@ def main():
                    "rows_per_gpu": sd.local_size_x, "nnz_per_gpu": sd.nnz_local,
                    "spmv_variant": a.spmv_variant, "matrix_format": fmt_name,
                    "cg_launches_per_iteration": (2 if int(lib.schwz_ras_cg_flavour(sd.h)) & 3 == 2 else 3),
+                   "cg_flavour": int(lib.schwz_ras_cg_flavour(sd.h)),
                    "exchange": ("one-sided overlapped, decentralised stop" if a.overlapped
                                 else "two-sided, all-gathered residual norms") +
                                (", fp32 halos" if a.mixed_halo else "") +
@@ -479,27 +556,37 @@ def main():
                               launches.value, spmv_tag),
     }
     stream = torch.cuda.current_stream().cuda_stream
-    # the plain-CSR kernel on the same matrix (variant 6), timed on its own: the figure the
-    # north_star's ">= 60 % of the HBM roofline on the local CSR SpMV" refers to
-    if rank == 0 and (coded or a.spmv_variant == 0):
-        xs, _ = sd.vector(2)
+    # the plain-CSR kernel (variant 6), timed on its own: the figure the north_star's ">= 60 % of the HBM
+    # roofline on the local CSR SpMV" refers to -- on this run's matrix and (N = 1) on the slabs a GPU holds
+    # in configs[2] (512 x 512 x 64) and configs[4] (1024 x 1024 x 128), keyed by shape
+    def csr_plain_entry(handle, n, alg_bytes, shape_key):
+        xs_t = torch.randn(n, dtype=torch.float64, device="cuda")
+        keep = torch.empty(n, dtype=torch.float64, device="cuda")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        keep = torch.empty(sd.local_size_x, dtype=torch.float64, device="cuda")
         for _ in range(3):
-            check(lib.schwz_csr_spmv(csr_h, 1.0, xs, 0.0, keep.data_ptr(), 6, stream))
+            check(lib.schwz_csr_spmv(handle, 1.0, xs_t.data_ptr(), 0.0, keep.data_ptr(), 6, stream))
         e0.record()
         for _ in range(20):
-            check(lib.schwz_csr_spmv(csr_h, 1.0, xs, 0.0, keep.data_ptr(), 6, stream))
+            check(lib.schwz_csr_spmv(handle, 1.0, xs_t.data_ptr(), 0.0, keep.data_ptr(), 6, stream))
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 20
-        line["roofline_csr_plain"] = {
-            "kernel": "spmv_stream_kernel<kSpmvPlain> (plain CSR as stored, y = A x; spmv_stream.hip)", "bound": "hbm",
-            "achieved": csr_spmv_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": csr_spmv_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": ms,
-            "algorithmic_bytes_per_launch": csr_spmv_bytes,
-            "note": "north_star: >= 0.60 of the HBM roofline on the local CSR SpMV"}
-        del keep
+        tr, tr_src = pmc_traffic(tuple(int(t) for t in shape_key.split("x")), ("spmv_stream_kernel<0,",))
+        tr = tr["spmv_stream_kernel<0,"]
+        del xs_t, keep
+        return {"achieved": alg_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": ms,
+                "algorithmic_bytes_per_launch": alg_bytes, "rows": n,
+                "traffic": tr, "traffic_source": tr_src, "traffic_over_algorithmic": (tr / alg_bytes) if tr else None}
+
+    if rank == 0 and (coded or a.spmv_variant == 0):
+        plain = {"kernel": "spmv_stream_kernel<kSpmvPlain> (plain CSR as stored, y = A x; spmv_stream.hip)",
+                 "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "note": "north_star: >= 0.60 of the HBM roofline on the local CSR SpMV; bytes = SURVEY 8(d) B_spmv = "
+                         "12 nnz + 4 (rows + 1) + 16 rows; one entry per per-GPU shape", "shapes": {}}
+        own_key = ("%dx%dx%d" % shape) if N == 1 else a.slab.replace(",", "x")
+        plain["shapes"][own_key] = csr_plain_entry(csr_h, sd.local_size_x, csr_spmv_bytes, own_key)
+        line["roofline_csr_plain"] = plain
     # the box's own HBM ceilings (STREAM-style kernels of the library, 2 GiB), quoted beside the
     # 8 TB/s spec the roofline fractions are priced against
     if rank == 0:
@@ -524,6 +611,64 @@ def main():
             line["hbm_measured"] = {"error": str(exc)}
     del solver, sd
     torch.cuda.empty_cache()
+    if rank == 0 and N == 1 and not a.no_shapes and "roofline_csr_plain" in line:
+        # the other per-GPU shapes: the matrix of one z-slab as plain CSR (codings off for these uploads)
+        saved = {k: os.environ.get(k) for k in ("SCHWZ_SPMV_PAIR", "SCHWZ_SPMV_PATTERN", "SCHWZ_SPMV_DICT")}
+        os.environ.update({k: "0" for k in saved})
+        try:
+            for spec in [t for t in a.csr_shapes.split(";") if t.strip()]:
+                shp = tuple(int(t) for t in spec.split(","))
+                key = "%dx%dx%d" % shp
+                if key in line["roofline_csr_plain"]["shapes"]:
+                    continue
+                t_s = time.perf_counter()
+                prob = schwz.Problem.laplacian(3, *shp)
+                sdx = schwz.Subdomain(prob, 1, 0, 2, schwz.partition_regular(prob.N, 1))
+                rp_, col_, val_ = sdx.local_matrix()
+                Ax = schwz.Csr(rp_, col_, val_)
+                nrows, nnz = len(rp_) - 1, int(rp_[-1])
+                del rp_, col_, val_
+                ent = csr_plain_entry(Ax.h, nrows, 12 * nnz + 4 * (nrows + 1) + 16 * nrows, key)
+                ent["setup_s"] = time.perf_counter() - t_s
+                line["roofline_csr_plain"]["shapes"][key] = ent
+                Ax.close()
+                del Ax, sdx, prob
+                torch.cuda.empty_cache()
+        except Exception as exc:  # a side measurement: report, never break the line
+            line["roofline_csr_plain"]["shapes_error"] = str(exc)
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    if "roofline_csr_plain" in line:
+        fr = [e["frac"] for e in line["roofline_csr_plain"]["shapes"].values()]
+        line["roofline_csr_plain"]["min_frac"] = min(fr)
+    # strong-scaling leg (north_star: ">= 0.85 strong-scaling efficiency 1 -> 8 GPUs"): the SAME fixed grid on
+    # every N, z-slabs, same operating point; the ratio of this field between N = 8 and N = 1 is the efficiency x 8
+    if a.strong_grid and not a.strong:
+        try:
+            sg = tuple(int(t) for t in a.strong_grid.split(","))
+            t_s = time.perf_counter()
+            ss, _ = make_solver(schwz, comm, sg, a.inner, 1e-30, a.warmup + a.strong_steps + 4, 0.0, a.spmv_variant,
+                                overlapped=a.overlapped, mixed=a.mixed_halo)
+            ss.begin_run()
+            ss.step()
+            torch.cuda.synchronize()
+            comm.barrier()
+            s_setup = time.perf_counter() - t_s
+            el = timed_steps(ss, comm, torch, a.warmup, a.strong_steps)
+            if N > 1:
+                el = max(comm.allgather_scalars({rank: el}))
+            line["strong"] = {"grid": "%dx%dx%d" % sg, "subdomains": N, "outer_iter_per_s": a.strong_steps / el,
+                              "ms_per_step": 1e3 * el / a.strong_steps, "steps": a.strong_steps, "warmup": a.warmup,
+                              "setup_s": s_setup,
+                              "note": "fixed grid on every N (z-slabs, overlap 2): outer_iter_per_s(N) / outer_iter_per_s(1) / N "
+                                      "is the strong-scaling efficiency"}
+            del ss
+            torch.cuda.empty_cache()
+        except Exception as exc:
+            line["strong"] = {"error": str(exc)}
     # the whole step with every matrix coding off (spmv_variant 6: plain CSR, stored-q CG): what a
     # matrix that does not pattern-code (FEM, < 90 % coverage) runs at.  Same workload, same K steps.
     if N == 1 and not a.no_plain_loop and a.spmv_variant == 0 and coded:
@@ -553,7 +698,13 @@ def main():
                                                 a.ttr_budget_s)
             line["time_to_residual_by_subdomains"] = by_p
     if rank == 0 and N == 1 and not a.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(shape, a.inner, a.cpu_iters)
+        line["cpu_baseline"] = cpu_baseline(shape, a.inner, a.cpu_iters,
+                                            [int(t) for t in a.cpu_subdomains.split(",") if t.strip()])
+    if mirror is not None:
+        if "value" in mirror:
+            mirror["vs_python_host"] = mirror["value"] / line["value"]
+            mirror["same_cg_flavour_as_python_host"] = mirror["cg_flavour"] == line["config"]["cg_flavour"]
+        line["mirror_bench_ras"] = mirror
     sys.stdout.flush()
     if rank == 0:
         os.write(json_fd, (json.dumps(line) + "\n").encode())

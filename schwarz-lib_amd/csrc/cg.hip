@@ -804,12 +804,15 @@ int precond_apply(schwz_pcg *s, const double *in, double *out, hipStream_t st)
 
 static int pcg_apply_general(schwz_pcg *s, hipStream_t st) { return precond_apply(s, s->r, s->z, st); }
 
+int pcg_take_trs_error(schwz_pcg *s) { return s && s->ilu ? trs_take_error(s->ilu) : SCHWZ_OK; }
+
 int pcg_last_stats(schwz_pcg *s, int *h_iters, double *h_resnorm)
 {
     SCHWZ_HIP_TRY(hipDeviceSynchronize());
     SCHWZ_HIP_TRY(hipMemcpy(&s->h_state[0], s->state, sizeof(CgState), hipMemcpyDeviceToHost));
     *h_iters = s->h_state[0].iters;
     *h_resnorm = sqrt(s->h_state[0].rr);
+    if (*h_resnorm != *h_resnorm) return pcg_take_trs_error(s);
     return SCHWZ_OK;
 }
 
@@ -1261,6 +1264,7 @@ int schwz_pcg_solve(schwz_pcg *s, const double *d_b, double *d_x, double rtol, i
         SCHWZ_HIP_TRY(hipStreamSynchronize(st));
         if (h_iters) *h_iters = s->h_state[0].iters;
         if (h_resnorm) *h_resnorm = sqrt(s->h_state[0].rr);
+        if (s->h_state[0].rr != s->h_state[0].rr) return pcg_take_trs_error(s);
     }
     return SCHWZ_OK;
 }

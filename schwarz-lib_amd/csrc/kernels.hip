@@ -150,6 +150,51 @@ __global__ __launch_bounds__(kBlock) void stream_copy_kernel(int64_t n2, const d
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) dst[i] = src[i];
 }
 
+// one 16-byte element per thread, no loop: the shape the microarchitecture guide's 6.29 TB/s copy figure is
+// quoted for (mode 2); four independent 16-byte elements per thread, loads before stores (mode 3); the same
+// with non-temporal accesses (mode 4)
+__global__ __launch_bounds__(kBlock) void stream_copy1_kernel(int64_t n2, const double2 *__restrict__ src,
+                                                              double2 *__restrict__ dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n2) dst[i] = src[i];
+}
+
+template <bool NT>
+__global__ __launch_bounds__(kBlock) void stream_copy4_kernel(int64_t n2, const double2 *__restrict__ src,
+                                                              double2 *__restrict__ dst)
+{
+    typedef double vd2 __attribute__((ext_vector_type(2)));
+    const vd2 *s = reinterpret_cast<const vd2 *>(src);
+    vd2 *d = reinterpret_cast<vd2 *>(dst);
+    const int64_t base = (int64_t)blockIdx.x * (4 * kBlock) + threadIdx.x;
+    if (base + 3 * kBlock < n2) {
+        vd2 v0, v1, v2, v3;
+        if (NT) {
+            v0 = __builtin_nontemporal_load(s + base);
+            v1 = __builtin_nontemporal_load(s + base + kBlock);
+            v2 = __builtin_nontemporal_load(s + base + 2 * kBlock);
+            v3 = __builtin_nontemporal_load(s + base + 3 * kBlock);
+            __builtin_nontemporal_store(v0, d + base);
+            __builtin_nontemporal_store(v1, d + base + kBlock);
+            __builtin_nontemporal_store(v2, d + base + 2 * kBlock);
+            __builtin_nontemporal_store(v3, d + base + 3 * kBlock);
+        } else {
+            v0 = s[base];
+            v1 = s[base + kBlock];
+            v2 = s[base + 2 * kBlock];
+            v3 = s[base + 3 * kBlock];
+            d[base] = v0;
+            d[base + kBlock] = v1;
+            d[base + 2 * kBlock] = v2;
+            d[base + 3 * kBlock] = v3;
+        }
+    } else {
+        for (int k = 0; k < 4; ++k)
+            if (base + k * kBlock < n2) d[base + k * kBlock] = s[base + k * kBlock];
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void stream_read_kernel(int64_t n2, const double2 *__restrict__ src,
                                                              double *__restrict__ out)
 {
@@ -496,6 +541,16 @@ int schwz_csr_create(int64_t nrows, int64_t ncols, const schwz_idx *h_rp, const 
     A->v.tile_row = (const schwz_idx *)A->d_tile;
     A->v.tile_nz = (const schwz_idx *)A->d_tile_nz;
     A->v.stream_cap = stream_cap;
+    if (stream_cap && (int)tiles.size() - 1 > kMaxGrid) {
+        // scratch for the per-workgroup partial sums of the short-lived workgroups of spmv_stream.hip
+        const int cap = (int)tiles.size() + 8 * kXcds;
+        if (hipMalloc(&A->d_stream_part, (size_t)2 * cap * sizeof(double)) == hipSuccess) {
+            A->v.stream_part = (double *)A->d_stream_part;
+            A->v.stream_part_cap = cap;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     A->v.tile_order = order.empty() ? nullptr : (const schwz_idx *)A->d_order;
     {
         // run length of the block-cyclic deal: 1/8 of the matrix bandwidth in tiles
@@ -543,6 +598,7 @@ void schwz_csr_destroy(schwz_csr *A)
     (void)hipFree(A->d_val);
     (void)hipFree(A->d_tile);
     (void)hipFree(A->d_tile_nz);
+    (void)hipFree(A->d_stream_part);
     (void)hipFree(A->d_wtile);
     (void)hipFree(A->d_order);
     (void)hipFree(A->d_tile_dual);
@@ -595,8 +651,20 @@ int schwz_csr_spmv(const schwz_csr *A, double alpha, const double *d_x, double b
 int schwz_stream_probe(int64_t n, int mode, const double *d_src, double *d_dst, schwz_stream stream)
 {
     SCHWZ_REQUIRE(n >= 0 && d_src && d_dst, "schwz_stream_probe: bad arguments");
-    SCHWZ_REQUIRE(mode == 0 || mode == 1, "schwz_stream_probe: mode must be 0 (copy) or 1 (read)");
-    if (mode == 0)
+    SCHWZ_REQUIRE(mode >= 0 && mode <= 4,
+                  "schwz_stream_probe: mode must be 0 (grid-stride copy), 1 (read), 2 (copy, one element per thread), "
+                  "3 (copy, four per thread) or 4 (the same, non-temporal)");
+    const int64_t n2 = n / 2;
+    if (mode == 2)
+        hipLaunchKernelGGL(stream_copy1_kernel, dim3((unsigned)((n2 + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                           (hipStream_t)stream, n2, (const double2 *)d_src, (double2 *)d_dst);
+    else if (mode == 3)
+        hipLaunchKernelGGL(stream_copy4_kernel<false>, dim3((unsigned)((n2 + 4 * kBlock - 1) / (4 * kBlock))), dim3(kBlock),
+                           0, (hipStream_t)stream, n2, (const double2 *)d_src, (double2 *)d_dst);
+    else if (mode == 4)
+        hipLaunchKernelGGL(stream_copy4_kernel<true>, dim3((unsigned)((n2 + 4 * kBlock - 1) / (4 * kBlock))), dim3(kBlock),
+                           0, (hipStream_t)stream, n2, (const double2 *)d_src, (double2 *)d_dst);
+    else if (mode == 0)
         hipLaunchKernelGGL(stream_copy_kernel, dim3(kMaxGrid), dim3(kBlock), 0, (hipStream_t)stream, n / 2,
                            (const double2 *)d_src, (double2 *)d_dst);
     else

@@ -57,6 +57,10 @@ struct CsrView {
     // of its row sums (8 / 16 / 32 >= the longest row; 0: the matrix keeps spmv_tiled2_kernel)
     const schwz_idx *tile_nz = nullptr;
     int stream_cap = 0;
+    // spmv_stream.hip: per-workgroup partial sums of a launch whose grid exceeds the kMaxGrid slots the consumers
+    // fold (2 banks of stream_part_cap doubles; one launch at a time per matrix)
+    double *stream_part = nullptr;
+    int stream_part_cap = 0;
     int xcd_block = 0;  // tiles are dealt to the 8 XCDs block-cyclically in runs of this many (a power of two)
     int xcd_shift = 0;  // log2(xcd_block)
     // kSpmvResidDual: 1 where the tile's rows or columns reach past `dual_split` (where x2 may
@@ -195,6 +199,9 @@ struct SpmvArgs {
     // direction launch (kSpmvDirDotSym: p' = D^-1 r, CgState untouched); pcg_begin / pcg_iterate set them
     // where pair_sweep_start_ok holds
     int sweep_init = 0, sweep_first = 0;
+    // spmv_stream.hip: consecutive tiles per workgroup of a grid that covers the matrix once (0: persistent
+    // workgroups striding through their XCD's sequence, the form of round 2)
+    int seq = 0;
 };
 
 // launch grid of the streaming vector kernels: one lane per element up to kMaxGrid workgroups
@@ -271,6 +278,7 @@ int pcg_begin(schwz_pcg *s, const double *d_b, double *d_x, double rtol, bool fu
 int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream_t st);
 int precond_apply(schwz_pcg *s, const double *in, double *out, hipStream_t st);
 int pcg_last_stats(schwz_pcg *s, int *h_iters, double *h_resnorm);  // device sync + state copy
+int pcg_take_trs_error(schwz_pcg *s);  // ILU(0) sweeps: trs_take_error of the factor solves
 }  // namespace schwz
 
 // ---- opaque ABI types -------------------------------------------------------
@@ -279,6 +287,7 @@ struct schwz_csr {
     schwz::CsrView v;
     void *d_rp = nullptr, *d_col = nullptr, *d_val = nullptr, *d_tile = nullptr, *d_wtile = nullptr, *d_order = nullptr;
     void *d_tile_nz = nullptr;
+    void *d_stream_part = nullptr;
     void *d_code = nullptr, *d_vptr = nullptr, *d_dptr = nullptr, *d_vdict = nullptr, *d_ddict = nullptr;
     void *d_pat_id = nullptr, *d_tile_table = nullptr, *d_tbl_desc = nullptr, *d_tbl_len = nullptr, *d_tbl_val = nullptr,
          *d_tbl_delta = nullptr;
@@ -451,6 +460,10 @@ struct schwz_subdomain {
     double *d_h_scalar = nullptr;  // device alias of h_scalar
     hipEvent_t ev_scalar = nullptr;
 };
+
+namespace schwz {
+int trs_take_error(schwz_trs *t);  // trs.hip: SCHWZ_ERR_HIP (and the reason) if a flag-driven sweep timed out
+}
 
 namespace schwz {
 // host vector -> fresh device allocation; `pad` extra zeroed elements follow the data (the 16-byte

@@ -793,7 +793,7 @@ int launch_spmv(const CsrView &A, int mode, const SpmvArgs &a, int variant, hipS
     }
     if ((variant == 0 || variant == 8) && A.pat_id) return launch_spmv_pattern(A, mode, a, grid, s);
     if ((variant == 0 || variant == 7) && A.code) return launch_spmv_dict(A, mode, a, grid, s);
-    if (variant >= 80 && variant < 88 && mode == kSpmvPlain) return launch_spmv_stream_ablate(A, a, variant - 80, s);
+    if (variant >= 80 && variant < 80 + 256 && mode == kSpmvPlain) return launch_spmv_stream_ablate(A, a, variant - 80, s);
     if (variant >= 10 && variant < 74 && mode == kSpmvPlain) {
         switch (variant - 10) {
 #define SCHWZ_ABL(W) \

@@ -16,7 +16,16 @@
 //   * there is no branch in the loop: addresses are clamped instead of guarded (lanes past the tile's last
 //     row repeat its last row and store the same value to the same address), the row sum is CAP masked adds
 //     (an absent entry adds +0.0, which leaves a sum that began at +0.0 unchanged bit for bit).
-// Grid and tile deal are those of spmv_tiled2_kernel: the partial sums of the fused dots are the same numbers.
+// Workgroups are SHORT-LIVED (round 3): a workgroup takes a.seq = 3 consecutive tiles of its XCD's sequence and
+// ends, and the grid covers the matrix once.  The round-2 form (persistent workgroups striding through the
+// sequence, a.seq = 0, SCHWZ_STREAM_SEQ=0) lets the workgroups drift apart: the rows in flight spread over the
+// whole sweep, the x lines neighbouring tiles share are gone from the 4 MiB L2 (a line lives ~5 us there at
+// this stream rate) before the neighbour asks, and the y stores reach memory as scattered 2 KiB pieces.  With
+// workgroups that end after four tiles the dispatch order keeps the active rows a compact moving window:
+// 0.359 -> 0.322 ms at 256^3 and 0.380 -> 0.320 ms on the 512 x 512 x 64 slab together with non-temporal y
+// stores (profiles/r03_stream_seq.txt; two tiles per workgroup pay too much pipeline fill, eight drift again).
+// The y values are the same bits as before; the partial sums of the fused dots are per workgroup, and a grid
+// beyond the kMaxGrid slots the consumers fold is reduced to them by spmv_stream_fold_kernel in a fixed order.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -27,9 +36,12 @@
 
 namespace schwz {
 
-// ABL (measurement builds, variants 80-87 of schwz_csr_spmv): bit 0 no y store, bit 1 no x gather, bit 2 no
-// row-pointer loads (7-entry rows assumed)
-template <int MODE, int CAP, int ABL = 0>
+// ABL (measurement builds, variants 80 + ABL of schwz_csr_spmv): bit 0 no y store, bit 1 no x gather, bit 2 no
+// row-pointer loads (7-entry rows assumed), bit 3 y stored into a 256 KiB window (the stores are issued, the
+// bytes stay in L2), bit 4 x gathered from a 512 KiB window (the gathers are issued and hit L2), bit 5 the y
+// store of a tile issued after the NEXT tile's gathers (the in-order vmcnt wait for those gathers then does
+// not wait for the store's acknowledgement)
+template <int MODE, int CAP, int ABL = 0, bool NTY = false>
 __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(CsrView A, SpmvArgs a)
 {
 #pragma clang fp contract(off)
@@ -50,8 +62,12 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(CsrView A, SpmvArgs
     const int sh = A.xcd_shift;
     auto tile_at = [&](int j) -> int { return ((j >> sh) << (sh + 3)) + (xcd << sh) + (j & (A.xcd_block - 1)); };
     // tiles of this workgroup: k = 0 .. ntw - 1 (past-the-end slots only occur at the tail of the deal)
-    int ntw = slot < nslots ? (nslots - slot + per_xcd - 1) / per_xcd : 0;
-    while (ntw > 0 && tile_at(slot + (ntw - 1) * per_xcd) >= A.ntiles) --ntw;
+    // a.seq > 0: a workgroup takes a.seq CONSECUTIVE slots of its XCD's sequence and ends; the grid covers the
+    // matrix once and the dispatch order keeps the active rows a compact window
+    const int seq = a.seq;
+    auto slot_at = [&](int k) -> int { return seq ? slot * seq + k : slot + k * per_xcd; };
+    int ntw = seq ? max(0, min(seq, nslots - slot * seq)) : (slot < nslots ? (nslots - slot + per_xcd - 1) / per_xcd : 0);
+    while (ntw > 0 && tile_at(slot_at(ntw - 1)) >= A.ntiles) --ntw;
     // partial-sum slots the consumer folds (a.part_stride of them per bank) beyond this launch's grid
     if (MODE != kSpmvPlain && blockIdx.x == 0)
         for (int i = (int)gridDim.x + tid; i < a.part_stride; i += kBlock) a.partials[i] = a.partials[a.part_stride + i] = 0.0;
@@ -69,9 +85,13 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(CsrView A, SpmvArgs
         struct Meta {
             int r0, r1, s, e;
         };
-        auto meta = [&](int k) -> Meta {  // beyond the last tile: the last one again (loaded, never computed)
-            const int t = tile_at(slot + min(k, ntw - 1) * per_xcd);
-            return Meta{trow[t], trow[t + 1], tnz[t], tnz[t + 1]};
+        auto meta = [&](int k) -> Meta {
+            // beyond the workgroup's last tile: loaded (no branch in the loop), never computed -- one quad and
+            // one row of the last tile, so that every such load instruction touches a single line
+            const int t = tile_at(slot_at(min(k, ntw - 1)));
+            const bool past = k >= ntw;
+            const int r0 = trow[t], s0 = tnz[t];
+            return Meta{r0, past ? r0 + 1 : trow[t + 1], s0, past ? s0 : tnz[t + 1]};
         };
         // Two register sets (tiles k and k + 1 in flight / landed), named scalars and native vectors pasted
         // into the step by macro: as members of a struct passed to a lambda they stayed in scratch memory
@@ -84,12 +104,21 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(CsrView A, SpmvArgs
         const int s2_ = (M).s & ~3;                                                                  \
         const int last_ = max(((M).e - 1) & ~3, s2_);                                                \
         const int i0_ = min(s2_ + 4 * tid, last_), i1_ = min(s2_ + 4 * (tid + kBlock), last_);       \
-        P##v0 = *reinterpret_cast<const vd2 *>(A.val + i0_);                                         \
-        P##v1 = *reinterpret_cast<const vd2 *>(A.val + i0_ + 2);                                     \
-        P##c0 = *reinterpret_cast<const vi4 *>(A.col + i0_);                                         \
-        P##v2 = *reinterpret_cast<const vd2 *>(A.val + i1_);                                         \
-        P##v3 = *reinterpret_cast<const vd2 *>(A.val + i1_ + 2);                                     \
-        P##c1 = *reinterpret_cast<const vi4 *>(A.col + i1_);                                         \
+        if (ABL & 64) {                                                                              \
+            P##v0 = __builtin_nontemporal_load(reinterpret_cast<const vd2 *>(A.val + i0_));          \
+            P##v1 = __builtin_nontemporal_load(reinterpret_cast<const vd2 *>(A.val + i0_ + 2));      \
+            P##c0 = __builtin_nontemporal_load(reinterpret_cast<const vi4 *>(A.col + i0_));          \
+            P##v2 = __builtin_nontemporal_load(reinterpret_cast<const vd2 *>(A.val + i1_));          \
+            P##v3 = __builtin_nontemporal_load(reinterpret_cast<const vd2 *>(A.val + i1_ + 2));      \
+            P##c1 = __builtin_nontemporal_load(reinterpret_cast<const vi4 *>(A.col + i1_));          \
+        } else {                                                                                     \
+            P##v0 = *reinterpret_cast<const vd2 *>(A.val + i0_);                                     \
+            P##v1 = *reinterpret_cast<const vd2 *>(A.val + i0_ + 2);                                 \
+            P##c0 = *reinterpret_cast<const vi4 *>(A.col + i0_);                                     \
+            P##v2 = *reinterpret_cast<const vd2 *>(A.val + i1_);                                     \
+            P##v3 = *reinterpret_cast<const vd2 *>(A.val + i1_ + 2);                                 \
+            P##c1 = *reinterpret_cast<const vi4 *>(A.col + i1_);                                     \
+        }                                                                                            \
         const int rowc_ = min((M).r0 + tid, (M).r1 - 1);                                             \
         /* ONE row-pointer load per lane: the end of a row is the start of the next lane's, handed */ \
         /* over through LDS in the step; the tile's last row ends where the tile does (M.e) */      \
@@ -132,9 +161,11 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(CsrView A, SpmvArgs
                 vv[j] = vals[b0 + j0 + j];                                                           \
                 cc[j] = cols[b0 + j0 + j];                                                           \
             }                                                                                        \
-            _Pragma("unroll") for (int j = 0; j < 8; ++j) xx[j] = (ABL & 2) ? (double)cc[j] : a.x[cc[j]]; \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j)                                            \
+                xx[j] = (ABL & 2) ? (double)cc[j] : a.x[(ABL & 16) ? (cc[j] & 0xFFFF) : cc[j]];      \
             if (j0 == 0) {                                                                           \
                 __builtin_amdgcn_sched_barrier(0);                                                   \
+                if (ABL & 32) a.y[(ABL & 8) ? (prow & 0x7FFF) : prow] = psum;                        \
                 SCHWZ_STREAM_ISSUE(MN, P)                                                            \
                 __builtin_amdgcn_sched_barrier(0);                                                   \
             }                                                                                        \
@@ -149,10 +180,18 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(CsrView A, SpmvArgs
         if (MODE == kSpmvPlain) {                                                                    \
             if (ABL & 1)                                                                             \
                 acc0 += sum;                                                                         \
+            else if (ABL & 32) {                                                                     \
+                psum = a.alpha * sum;                                                                \
+                prow = rowc;                                                                         \
+            } else if ((ABL & 128) || NTY)                                                           \
+                __builtin_nontemporal_store(a.alpha * sum, a.y + rowc);                              \
             else                                                                                     \
-                a.y[rowc] = a.alpha * sum;                                                           \
+                a.y[(ABL & 8) ? (rowc & 0x7FFF) : rowc] = a.alpha * sum;                             \
         } else if (MODE == kSpmvDot) {                                                               \
-            a.y[rowc] = sum;                                                                         \
+            if (NTY)                                                                                 \
+                __builtin_nontemporal_store(sum, a.y + rowc);                                        \
+            else                                                                                     \
+                a.y[rowc] = sum;                                                                     \
             const double t = o0 * sum;                                                               \
             acc0 += mine ? t : 0.0;                                                                  \
         } else if (MODE == kSpmvResidInit) {                                                         \
@@ -174,6 +213,10 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(CsrView A, SpmvArgs
         int Ab0, Bb0;
         double Ao0, Ao1, Bo0, Bo1;
         Meta m0 = meta(0), m1 = meta(1);
+        // delayed store (ABL bit 5): the first step stores 0.0 to the rows its own tile stores again one step
+        // later (same lane, same address, program order)
+        double psum = 0.0;
+        int prow = min(m0.r0 + tid, m0.r1 - 1);
         SCHWZ_STREAM_ISSUE(m0, A)
         SCHWZ_STREAM_ISSUE(m1, B)
         Meta m2 = meta(2), m3 = meta(3);
@@ -187,6 +230,7 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(CsrView A, SpmvArgs
             m3 = meta(k + 5);
         }
         if (k < ntw) SCHWZ_STREAM_STEP(m0, m2, A)
+        if ((ABL & 32) && !(ABL & 1)) a.y[(ABL & 8) ? (prow & 0x7FFF) : prow] = psum;
 #undef SCHWZ_STREAM_STEP
 #undef SCHWZ_STREAM_ISSUE
     }
@@ -213,14 +257,66 @@ int launch_spmv_stream_ablate(const CsrView &A, const SpmvArgs &a, int abl, hipS
     const char *ge = std::getenv("SCHWZ_STREAM_GRID");
     int g = ge ? std::atoi(ge) : kMaxGrid;
     g = std::max(kXcds, std::min(g, kMaxGrid) / kXcds * kXcds);
+    SpmvArgs b = a;
+    const char *se = std::getenv("SCHWZ_STREAM_SEQ");
+    b.seq = se ? std::max(0, std::atoi(se)) : 0;
+    if (b.seq) {
+        const int sh = A.xcd_shift;
+        const int nslots = ((A.ntiles + (kXcds << sh) - 1) >> (sh + 3)) << sh;
+        g = kXcds * ((nslots + b.seq - 1) / b.seq);
+    }
     switch (abl) {
 #define SCHWZ_ABL(W) \
-    case W: hipLaunchKernelGGL((spmv_stream_kernel<kSpmvPlain, 8, W>), dim3(g), dim3(kBlock), 0, s, A, a); break;
+    case W: hipLaunchKernelGGL((spmv_stream_kernel<kSpmvPlain, 8, W>), dim3(g), dim3(kBlock), 0, s, A, b); break;
         SCHWZ_ABL(0) SCHWZ_ABL(1) SCHWZ_ABL(2) SCHWZ_ABL(3) SCHWZ_ABL(4) SCHWZ_ABL(5) SCHWZ_ABL(6) SCHWZ_ABL(7)
+        SCHWZ_ABL(8) SCHWZ_ABL(16) SCHWZ_ABL(24) SCHWZ_ABL(32) SCHWZ_ABL(40) SCHWZ_ABL(48) SCHWZ_ABL(56)
+        SCHWZ_ABL(64) SCHWZ_ABL(128) SCHWZ_ABL(192)
+    default: set_error("schwz_csr_spmv: no such stream ablation build"); return SCHWZ_ERR_INVALID;
 #undef SCHWZ_ABL
     }
     SCHWZ_HIP_TRY(hipGetLastError());
     return SCHWZ_OK;
+}
+
+// Folds the per-workgroup partial sums of a launch of `nin` workgroups (two banks, `nin` apart) into the `nout`
+// slots per bank the consumers read: slot i = the sum of the workgroups i, i + nout, ... in that order.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void spmv_stream_fold_kernel(const double *__restrict__ in, int nin,
+                                                                  double *__restrict__ out, int nout,
+                                                                  const int *stop_iter, int it)
+{
+    if (MODE == kSpmvDot || MODE == kSpmvResidInit) {
+        if (stop_iter && it >= *stop_iter) return;
+    }
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nout) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int j = i; j < nin; j += nout) {
+        s0 += in[j];
+        s1 += in[nin + j];
+    }
+    out[i] = s0;
+    out[nout + i] = s1;
+}
+
+// tiles per short-lived workgroup (SCHWZ_STREAM_SEQ; 0: the persistent form) and whether y leaves with
+// non-temporal stores (SCHWZ_STREAM_NTY: 0 never, 1 y = A x only, 2 the q = A p of the CG iteration as well)
+static int stream_seq_max()
+{
+    static const int v = [] {
+        const char *e = std::getenv("SCHWZ_STREAM_SEQ");
+        return e ? std::max(0, std::min(std::atoi(e), 64)) : 3;
+    }();
+    return v;
+}
+
+static int stream_nty()
+{
+    static const int v = [] {
+        const char *e = std::getenv("SCHWZ_STREAM_NTY");
+        return e ? std::atoi(e) : 1;
+    }();
+    return v;
 }
 
 // Launches the stream kernel where it applies; *done = false leaves the launch to spmv_tiled2_kernel.
@@ -236,7 +332,36 @@ int launch_spmv_stream(const CsrView &A, int mode, const SpmvArgs &a, int grid, 
     if (mode == kSpmvPlain && a.beta != 0.0) return SCHWZ_OK;
     SpmvArgs b = a;
     b.part_stride = grid;
-#define SCHWZ_STREAM_CASE(M, C) hipLaunchKernelGGL((spmv_stream_kernel<M, C>), dim3(grid), dim3(kBlock), 0, s, A, b);
+    // short-lived workgroups (stream_seq_max() consecutive tiles each) once the matrix has four tiles per
+    // workgroup of the persistent grid (2 M rows): below that launches, not memory, set the pace
+    int launch_grid = grid;
+    bool fold = false;
+    const int seq = stream_seq_max();
+    if (seq && A.ntiles >= 4 * kMaxGrid) {
+        const int sh = A.xcd_shift;
+        const int nslots = ((A.ntiles + (kXcds << sh) - 1) >> (sh + 3)) << sh;
+        const int g = kXcds * ((nslots + seq - 1) / seq);
+        if (mode == kSpmvPlain || (A.stream_part && g <= A.stream_part_cap)) {
+            b.seq = seq;
+            launch_grid = g;
+            if (mode != kSpmvPlain) {
+                fold = true;
+                b.partials = A.stream_part;
+                b.part_stride = g;
+            }
+        }
+    }
+    const bool nty = b.seq && ((mode == kSpmvPlain && stream_nty() >= 1) || (mode == kSpmvDot && stream_nty() >= 2));
+#define SCHWZ_STREAM_CASE(M, C)                                                                                   \
+    {                                                                                                             \
+        if (nty)                                                                                                  \
+            hipLaunchKernelGGL((spmv_stream_kernel<M, C, 0, true>), dim3(launch_grid), dim3(kBlock), 0, s, A, b); \
+        else                                                                                                      \
+            hipLaunchKernelGGL((spmv_stream_kernel<M, C, 0, false>), dim3(launch_grid), dim3(kBlock), 0, s, A, b); \
+        if (fold)                                                                                                 \
+            hipLaunchKernelGGL((spmv_stream_fold_kernel<M>), dim3((grid + kBlock - 1) / kBlock), dim3(kBlock), 0, s, \
+                               (const double *)b.partials, launch_grid, a.partials, grid, a.stop_iter, a.it);    \
+    }
 #define SCHWZ_STREAM_MODE(M)                                  \
     if (A.stream_cap <= 8) SCHWZ_STREAM_CASE(M, 8)            \
     else if (A.stream_cap <= 16) SCHWZ_STREAM_CASE(M, 16)     \

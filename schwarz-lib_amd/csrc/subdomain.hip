@@ -345,6 +345,12 @@ int schwz_ras_local_residual_wait(schwz_subdomain *sd, double *h_resnorm)
     }
     SCHWZ_HIP_TRY(hipEventSynchronize(sd->ev_scalar));
     *h_resnorm = std::sqrt(sd->h_scalar[0]);
+    if (*h_resnorm != *h_resnorm) {
+        // a NaN norm: say so specifically when it comes from a triangular sweep that gave up waiting
+        int rc = sd->cg ? pcg_take_trs_error(sd->cg) : SCHWZ_OK;
+        if (!rc && sd->trs) rc = trs_take_error(sd->trs);
+        if (rc) return rc;
+    }
     return SCHWZ_OK;
 }
 

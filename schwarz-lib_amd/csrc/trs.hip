@@ -256,6 +256,21 @@ __global__ __launch_bounds__(kBlock) void trs_flag_kernel(int64_t n, const schwz
     }
 }
 
+// A flag-driven sweep that waited longer than kTrsTimeoutTicks gave up with NaNs and set the error word: read
+// and clear it (callers stand at a point where the stream is idle: the NaN has already reached the host).
+int trs_take_error(schwz_trs *t)
+{
+    if (!t || !t->flags || !t->d_err) return SCHWZ_OK;
+    int e = 0;
+    SCHWZ_HIP_TRY(hipMemcpy(&e, t->d_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (!e) return SCHWZ_OK;
+    e = 0;
+    SCHWZ_HIP_TRY(hipMemcpy(t->d_err, &e, sizeof(int), hipMemcpyHostToDevice));
+    set_error("trs flag sweep timed out: a row waited more than 3 s for its dependencies (workgroups of the "
+              "persistent triangular sweep not resident together?); SCHWZ_TRS_FLAGS=0 selects the launch plan");
+    return SCHWZ_ERR_HIP;
+}
+
 }  // namespace schwz
 
 using namespace schwz;
@@ -436,12 +451,24 @@ int schwz_trs_create(int64_t n, const schwz_idx *l_rp, const schwz_idx *l_col, c
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
                 prop.multiProcessorCount > 0)
                 cus = prop.multiProcessorCount;
-            // every workgroup must be resident (the waits are on other workgroups' rows): one per CU, far
-            // below any residency limit of this kernel; SCHWZ_TRS_FLAG_GRID overrides (at most 4 per CU)
+            // Every workgroup must be resident (the waits are on other workgroups' rows).  The grid is one
+            // workgroup per CU (SCHWZ_TRS_FLAG_GRID overrides, at most 4 per CU) and is clamped to what the
+            // occupancy query says both sweeps can keep resident -- less one per CU beyond the first, because
+            // the query may answer one workgroup per CU too many at some SGPR counts (MI355X_MICROARCH.md,
+            // "Correctness boundaries").  No residency at all: the level-by-level launch plan.
+            int occ_l = 0, occ_u = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_l, trs_flag_kernel<true>, kBlock, 0) != hipSuccess ||
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_u, trs_flag_kernel<false>, kBlock, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                occ_l = occ_u = 0;
+            }
+            int per_cu = std::min(occ_l, occ_u);
+            if (per_cu > 1) --per_cu;
             const char *genv = std::getenv("SCHWZ_TRS_FLAG_GRID");
             int g = genv ? std::atoi(genv) : cus;
-            g = std::max(1, std::min(g, 4 * cus));
+            g = std::max(1, std::min(g, std::min(4, per_cu) * cus));
             t->flag_grid = (int)std::min<int64_t>(g, (n + kBlock - 1) / kBlock);
+            if (per_cu < 1) t->flags = false;
         }
     }
     *out = t;

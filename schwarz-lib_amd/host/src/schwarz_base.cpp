@@ -1007,6 +1007,11 @@ void SchwarzBase<V, I, M>::run(std::shared_ptr<gko::matrix::Dense<V>> &solution)
                  << (i < ppd.local_converged_iter_count.size() ? ppd.local_converged_iter_count[i] : (V)0) << ","
                  << ppd.local_converged_resnorm[i] << "," << ppd.local_timestamp[i] << "\n";
     }
+    // not in the reference (it reports the time of converged runs only, schwarz_base.cpp:474-498): loop time and
+    // CG launch structure of every run, what bench.py's mirror_bench_ras leg reads
+    if (me == 0)
+        std::cout << " [schwz] outer loop: " << m.iter_count << " iterations in " << elapsed << " s, cg flavour "
+                  << schwz_ras_cg_flavour(im.sd) << std::endl;
     if (!converged) {
         std::cout << "Rank " << me << " did not converge in " << m.iter_count << " iterations." << std::endl;
     } else {
