@@ -101,27 +101,46 @@ def free_port():
 def self_launch(n, argv):
     """`python bench.py --gpus N` with no launcher around it: N rank processes of this same
     script, started as CHILDREN (never exec) before this process has imported torch or touched
-    the GPU.  Rank 0's stdout is the JSON line and is relayed; the exit code is the worst one."""
+    the GPU.  Rank 0's stdout is the JSON line and is relayed; the exit code is the worst one.
+    Every child is watched while the job runs: when one exits with an error the others are ended
+    (they would wait for it in the rendezvous until the process-group timeout), and the whole job
+    has a wall-clock cap (SCHWZ_BENCH_LAUNCH_TIMEOUT seconds, default 1500)."""
+    import tempfile
     port = free_port()
     procs = []
-    for r in range(n):
-        env = dict(os.environ)
-        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    deadline = time.time() + 120.0
-    for p in procs[1:]:
-        try:
-            p.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            p.kill()  # the exact child started above
-            p.wait()
-        rc = rc or p.returncode
-    sys.stdout.write(out.decode())
-    sys.stdout.flush()
+    cap = float(os.environ.get("SCHWZ_BENCH_LAUNCH_TIMEOUT", "1500"))
+    with tempfile.TemporaryFile() as out0:
+        for r in range(n):
+            env = dict(os.environ)
+            env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        deadline = time.time() + cap
+        rc = 0
+        while True:
+            codes = [p.poll() for p in procs]
+            failed = [c for c in codes if c not in (None, 0)]
+            if failed or all(c is not None for c in codes) or time.time() > deadline:
+                if failed:
+                    rc = failed[0]
+                elif any(c is None for c in codes):
+                    rc = 124  # the wall-clock cap
+                break
+            time.sleep(0.2)
+        if rc:
+            # rank 0 has been given a few seconds to finish its line; then the exact children started above go
+            t_end = time.time() + 5.0
+            for p in procs:
+                while p.poll() is None and time.time() < t_end:
+                    time.sleep(0.1)
+                if p.poll() is None:
+                    p.kill()
+                p.wait()
+            sys.stderr.write("bench.py: a rank ended with code %d; the other ranks were stopped\n" % rc)
+        out0.seek(0)
+        sys.stdout.write(out0.read().decode())
+        sys.stdout.flush()
     return rc
 
 
@@ -129,6 +148,8 @@ def launch_probe(a):
     """SCHWZ_BENCH_LAUNCH_PROBE=1 (tests/test_dist_gloo.py): every rank joins a gloo group under the
     environment self_launch (or an outer launcher) gave it, the ranks are all-gathered and rank 0
     prints them -- the rendezvous of bench.py without the GPU work."""
+    if os.environ.get("SCHWZ_BENCH_PROBE_FAIL_RANK") == os.environ.get("RANK"):
+        return 3  # tests: this rank dies before the rendezvous, the others would wait for it
     import torch
     import torch.distributed as dist
     dist.init_process_group("gloo")

@@ -222,6 +222,7 @@ int schwz_problem_extract_rows(const schwz_problem *p, int64_t nrows, const int6
     std::vector<int64_t> c((size_t)p->max_row_nnz + 1);
     std::vector<double> v((size_t)p->max_row_nnz + 1);
     rp_out[0] = 0;
+    p->missing_row = -1;  // a miss recorded by an earlier, failed call must not fail this one
     for (int64_t i = 0; i < nrows; ++i) {
         SCHWZ_REQUIRE(row_ids[i] >= 0 && row_ids[i] < p->N, "schwz_problem_extract_rows: row outside the matrix");
         const int len = p->row(row_ids[i], c.data(), v.data());
@@ -233,7 +234,9 @@ int schwz_problem_extract_rows(const schwz_problem *p, int64_t nrows, const int6
         rp_out[i + 1] = rp_out[i] + len;
     }
     if (p->missing_row >= 0) {
-        set_error("schwz_problem_extract_rows: a requested row is not held by this process");
+        set_error("schwz_problem_extract_rows: a requested row is not held by this process (row " +
+                  std::to_string(p->missing_row) + ")");
+        p->missing_row = -1;
         return SCHWZ_ERR_INVALID;
     }
     return SCHWZ_OK;
@@ -629,6 +632,7 @@ int schwz_subdomain_setup(const schwz_problem *p, int P, int me, int overlap, co
     SCHWZ_REQUIRE(P > 0 && me >= 0 && me < P, "schwz_subdomain_setup: bad rank / subdomain count");
     SCHWZ_REQUIRE(overlap >= 1, "schwz_subdomain_setup: overlap must be >= 1");
     SCHWZ_REQUIRE(first_row[0] == 0 && first_row[P] == p->N, "schwz_subdomain_setup: first_row must cover all rows");
+    p->missing_row = -1;  // see schwz_problem_extract_rows
     auto *sd = new schwz_subdomain();
     sd->P = P;
     sd->me = me;
@@ -773,6 +777,7 @@ int schwz_subdomain_setup(const schwz_problem *p, int P, int me, int overlap, co
         delete sd;
         set_error("schwz_subdomain_setup: the problem does not hold a row this subdomain reads (row " +
                   std::to_string(p->missing_row) + ")");
+        p->missing_row = -1;
         return SCHWZ_ERR_INVALID;
     }
     *out = sd;

@@ -90,6 +90,7 @@ struct CsrView {
     // read with one wave-uniform load instead of one byte per lane; first word 0xffff: more than 8
     // runs, the chunk's ids come from pair_id (nullptr: not built)
     const uint4 *pair_rle = nullptr;
+    int pair_rle_runs = 8;  // runs per chunk record: 8 (16 bytes) or 16 (32 bytes, x lines shorter than ~170 entries)
     const schwz_idx *chunk_ptable = nullptr; // per chunk of 512 rows: pair table id, -1 = not pair coded
     const uint8_t *chunk_dual = nullptr;     // per chunk: the fused dual residual needs its second product
     int pair_shift = 0;                      // log2 of the run length of the XCD deal of the chunks
@@ -226,7 +227,10 @@ int launch_spmv_dict(const CsrView &A, int mode, const SpmvArgs &a, int grid, hi
 int launch_spmv_pattern(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s);
 int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s);
 int launch_spmv_stream(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s, bool *done);
-int launch_spmv_stream_ablate(const CsrView &A, const SpmvArgs &a, int abl, hipStream_t s);
+int launch_spmv_stream_ablate(const CsrView &A, const SpmvArgs &a, int abl, hipStream_t s);  // measurement build only
+// the measurement variants of schwz_csr_spmv (tools/probes/spmv_variants.hip): null in the product library
+typedef int (*SpmvProbeHook)(const CsrView &A, int mode, const SpmvArgs &a, int variant, int grid, hipStream_t s);
+extern SpmvProbeHook g_spmv_probe_hook;
 bool pair_sweep_start_ok(const CsrView &A, int grid);
 bool pair_sweep_dual_ok(const CsrView &A, int grid);
 

@@ -357,29 +357,46 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
     // run-length record of a chunk's pattern ids (first word 0xffff: none, the ids are bytes per pair).
     // chunk is workgroup-uniform and the table is never written by a kernel: read through the constant
     // address space, i.e. with a scalar load that costs no vector-memory slot
-    auto load_rle = [&](int chunk) -> uint4 {
-        uint4 rle = {0xffffu, 0u, 0u, 0u};
+    struct RleRec {
+        uint4 lo, hi;  // hi: runs 8-15 of a 16-run record
+    };
+    const bool rle16 = A.pair_rle_runs == 16;
+    auto load_rle = [&](int chunk) -> RleRec {
+        RleRec rle = {{0xffffu, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
         if (A.pair_rle) {
             typedef const unsigned __attribute__((address_space(4))) *const_words;
-            const const_words q = (const_words)(uintptr_t)(A.pair_rle + chunk);
-            rle.x = q[0];
-            rle.y = q[1];
-            rle.z = q[2];
-            rle.w = q[3];
+            const const_words q = (const_words)(uintptr_t)(A.pair_rle + (rle16 ? 2 * chunk : chunk));
+            rle.lo.x = q[0];
+            rle.lo.y = q[1];
+            rle.lo.z = q[2];
+            rle.lo.w = q[3];
+            if (rle16) {
+                rle.hi.x = q[4];
+                rle.hi.y = q[5];
+                rle.hi.z = q[6];
+                rle.hi.w = q[7];
+            }
         }
         return rle;
     };
     // pattern id of the pair starting at row ra: the id of the last run that starts at or before this
     // lane's pair (runs ascending, unused slots repeat the last run)
-    auto pid_of = [&](const uint4 rle, int ra) -> int {
+    auto pid_of = [&](const RleRec rle, int ra) -> int {
         int pid;
-        if ((rle.x & 0xffffu) != 0xffffu) {
-            const unsigned w[4] = {rle.x, rle.y, rle.z, rle.w};
+        if ((rle.lo.x & 0xffffu) != 0xffffu) {
+            const unsigned w[8] = {rle.lo.x, rle.lo.y, rle.lo.z, rle.lo.w, rle.hi.x, rle.hi.y, rle.hi.z, rle.hi.w};
             pid = (int)((w[0] >> 8) & 0xffu);
 #pragma unroll
             for (int k = 1; k < 8; ++k) {
                 const unsigned e = (w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
                 if ((unsigned)tid >= (e & 0xffu)) pid = (int)(e >> 8);
+            }
+            if (rle16) {  // workgroup-uniform
+#pragma unroll
+                for (int k = 8; k < 16; ++k) {
+                    const unsigned e = (w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+                    if ((unsigned)tid >= (e & 0xffu)) pid = (int)(e >> 8);
+                }
             }
         } else {
             pid = A.pair_id[ra >> 1];
@@ -593,7 +610,10 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
 // DUAL (with INIT): third partial bank = sum of r_i^2 over the chain positions NOT flagged in chain_dual -- the
 // part of the fused check residual ||b - A x2||^2 that coincides with the start residual; the flagged planes
 // are added by a listed kSpmvResidNorm launch on x2 (launch_spmv_pair).
-template <int NHL, int NH, bool DIAGVEC, bool INIT = false, bool DUAL = false>
+// RUNS: runs per chunk record of the pattern ids (8: 16 bytes, 16: 32 bytes; CsrView::pair_rle_runs)
+// H3: the +-NX halo of a position is requested three positions ahead (with the neighbouring bands' own request of
+// the same lines, see SCHWZ_DD below) into a ring of three halo slots instead of one ahead into two.
+template <int NHL, int NH, bool DIAGVEC, bool INIT = false, bool DUAL = false, int RUNS = 8, bool H3 = false>
 __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, SpmvArgs a)
 {
 #pragma clang fp contract(off)
@@ -605,7 +625,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
     const int NX = A.sweep_nx;
     double *const own_ring = reinterpret_cast<double *>(sweep_lds);
     double *const halo_ring = own_ring + 4 * T;
-    PairVal *const cpv = reinterpret_cast<PairVal *>(halo_ring + 4 * NX);
+    PairVal *const cpv = reinterpret_cast<PairVal *>(halo_ring + (H3 ? 6 : 4) * NX);
     int *const cmask = reinterpret_cast<int *>(cpv + A.canon_npat * 9);
     __shared__ double red[4];
     double cg_alpha = 1.0;
@@ -667,8 +687,8 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
                 __builtin_memcpy(&reg[k], a.x + clampg(g), 16);
             }
         };
-        auto store_halo = [&](int z, const pvd2 (&reg)[NHL]) {
-            double *slot_p = halo_ring + (size_t)(z & 1) * 2 * NX;
+        auto store_halo = [&](int hslot, const pvd2 (&reg)[NHL]) {
+            double *slot_p = halo_ring + (size_t)hslot * 2 * NX;
 #pragma unroll
             for (int k = 0; k < NHL; ++k) {
                 const int pc = min(tid + k * kBlock, NX - 1);
@@ -677,17 +697,15 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
         };
         struct Ahead {
             pvd2 r, d;
-            unsigned w0, w1, w2, w3;
+            unsigned w[RUNS / 2];
         };
         auto fetch = [&](int base, int h) -> Ahead {
             Ahead f;
             const int row0 = base + h * kPairRows;
             const int ra = row0 + 2 * tid;
-            const const_words q = (const_words)(uintptr_t)(A.pair_rle + (row0 / kPairRows));
-            f.w0 = q[0];
-            f.w1 = q[1];
-            f.w2 = q[2];
-            f.w3 = q[3];
+            const const_words q = (const_words)(uintptr_t)(A.pair_rle + (row0 / kPairRows) * (RUNS / 8));
+#pragma unroll
+            for (int k = 0; k < RUNS / 2; ++k) f.w[k] = q[k];
             f.r = __builtin_nontemporal_load(reinterpret_cast<const pvd2u *>(r_in + ra));
             if (DIAGVEC) f.d = __builtin_nontemporal_load(reinterpret_cast<const pvd2 *>(a.dinv + ra));
             return f;
@@ -697,19 +715,24 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
         // content -- own(z + 1) -- has just gone to LDS; r(z + 2) at the end of step z, into the set step z
         // has just consumed; the halo of position z + 1 (L2 hits) first thing in step z.  The band's first
         // rows at the positions z - 1 .. z + 3 travel in scalar registers (brow), one new one per step.
-        pvd2 own_a[NH], own_b[NH], hreg[NHL];
+        pvd2 own_a[NH], own_b[NH], hreg[NHL], hreg_b[NHL];
         Ahead r_a[NH], r_b[NH];
         int brow[5];
 #pragma unroll
         for (int k = 0; k < 5; ++k) brow[k] = band_row(z0 - 1 + k);
         {
             // everything the first two positions need is requested before anything is waited for
-            pvd2 first[NH], second[NH];
+            pvd2 first[NH], second[NH], h0[NHL];
             load_own(brow[0], first);
             load_own(brow[1], second);
-            load_halo(brow[1], hreg);
+            load_halo(brow[1], H3 ? h0 : hreg);
             load_own(brow[2], own_b);
             load_own(brow[3], own_a);
+            if (H3) {
+                load_halo(brow[2], hreg);    // position z0 + 1
+                load_halo(brow[3], hreg_b);  // position z0 + 2
+                store_halo(0, h0);
+            }
 #pragma unroll
             for (int h = 0; h < NH; ++h) {
                 r_a[h] = fetch(brow[1], h);
@@ -718,20 +741,29 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
             store_own(z0 - 1, first);
             store_own(z0, second);
         }
-        // one position: `own_next` holds own(z + 1) on entry and own(z + 3) on exit, `rr` r(z) / r(z + 2)
-        auto step = [&](int z, pvd2 (&own_next)[NH], Ahead (&rr)[NH]) {
+        int hs = 0;  // halo slot of the position being computed (three-slot form)
+        // one position: `own_next` holds own(z + 1) on entry and own(z + 3) on exit, `rr` r(z) / r(z + 2); with H3
+        // `hal_next` the halo of position z + 1 on entry and of position z + 3 on exit
+        auto step = [&](int z, pvd2 (&own_next)[NH], Ahead (&rr)[NH], pvd2 (&hal_next)[NHL]) {
             // brow[] = first rows at z - 1, z, z + 1, z + 2, z + 3
             store_own(z + 1, own_next);
-            store_halo(z, hreg);
+            const int hs_next = hs == 2 ? 0 : hs + 1;
+            if (H3)
+                store_halo(hs_next, hal_next);
+            else
+                store_halo(z & 1, hreg);
             lds_barrier();
-            load_halo(brow[2], hreg);
+            if (H3)
+                load_halo(brow[4], hal_next);
+            else
+                load_halo(brow[2], hreg);
             load_own(brow[4], own_next);
             const int far = chain_far[z];
             const bool plain_pos = DUAL ? ((const_ints)(uintptr_t)A.chain_dual)[z] == 0 : true;
             const double *cur = own_ring + (size_t)(z & 3) * T;
             const double *prv = own_ring + (size_t)((z + 3) & 3) * T;
             const double *nxt = own_ring + (size_t)((z + 1) & 3) * T;
-            const double *hlo = halo_ring + (size_t)(z & 1) * 2 * NX, *hup = hlo + NX;
+            const double *hlo = halo_ring + (size_t)(H3 ? hs : (z & 1)) * 2 * NX, *hup = hlo + NX;
             // window each far slot reads (slots of a plane without that coupling read `cur`: masked anyway)
             const double *fb0 = (far & 3) == 1 ? prv : ((far & 3) == 2 ? nxt : cur);
             const double *fb1 = ((far >> 2) & 3) == 1 ? prv : (((far >> 2) & 3) == 2 ? nxt : cur);
@@ -744,11 +776,10 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
                 const int i0 = h * kPairRows + 2 * tid;  // position inside the band
                 const int ra = brow[1] + i0;
                 // the id of the last run that starts at or before this lane's pair
-                const unsigned w[4] = {f.w0, f.w1, f.w2, f.w3};
-                int pid = (int)((w[0] >> 8) & 0xffu);
+                int pid = (int)((f.w[0] >> 8) & 0xffu);
 #pragma unroll
-                for (int k = 1; k < 8; ++k) {
-                    const unsigned e = (w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+                for (int k = 1; k < RUNS; ++k) {
+                    const unsigned e = (f.w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
                     if ((unsigned)tid >= (e & 0xffu)) pid = (int)(e >> 8);
                 }
                 const int mask = cmask[pid];
@@ -798,13 +829,14 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
 #pragma unroll
             for (int k = 0; k < 4; ++k) brow[k] = brow[k + 1];
             brow[4] = band_row(z + 4);
+            hs = hs_next;
         };
         int z = z0;
         for (; z + 1 < z1; z += 2) {
-            step(z, own_b, r_a);
-            step(z + 1, own_a, r_b);
+            step(z, own_b, r_a, hreg);
+            step(z + 1, own_a, r_b, hreg_b);
         }
-        if (z < z1) step(z, own_b, r_a);
+        if (z < z1) step(z, own_b, r_a, hreg);
     }
     const double s0 = block_sum(acc0, red);
     const double s1 = block_sum(acc1, red);
@@ -830,7 +862,19 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
 // FIRST: the first direction of a solve whose start launch was the INIT walk above: p' = z (nothing is
 // read from p, beta does not exist yet), the partial sums of p'.(A p'), CgState untouched.
 // ---------------------------------------------------------------------------------------------------
-template <int NHL, int NH, bool FIRST = false>
+// SCHWZ_DD (build-time switch, tools/dd_ab.sh; round 3): bit 0 p' leaves with non-temporal stores; bit 1 the halo
+// of a position is requested THREE positions ahead, i.e. in the same step in which the neighbouring band
+// requests the same lines as its own window (a third halo slot in LDS); bit 2 the own r lines are plain loads
+// (they are the neighbouring band's halo: a non-temporal load marks them for early eviction).  Before, the halo
+// was asked for two steps after the neighbour had fetched the lines -- longer than a line lives in the 4 MiB L2
+// at this stream rate -- and the PMC traffic of the launch was 1.17 x (256-wide planes) / 1.25 x (512-wide) its
+// bytes: exactly the halo, fetched twice.  All three together, in-box (profiles/r03_dd_ab.txt): launch 0.0789 ->
+// 0.0740 ms on the cube, 0.0861 -> 0.0729 ms on the 512 x 512 x 64 slab (0.585 -> 0.69 of peak; the step
+// 1.95 -> 1.82 ms), the same bits.  0 restores the round-2 schedule.
+#ifndef SCHWZ_DD
+#define SCHWZ_DD 7
+#endif
+template <int NHL, int NH, bool FIRST = false, int RUNS = 8>
 __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView A, SpmvArgs a)
 {
 #pragma clang fp contract(off)
@@ -838,8 +882,9 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
     constexpr int T = NH * kPairRows;
     const int NX = A.sweep_nx;
     double *const own_ring = reinterpret_cast<double *>(sweep_lds);  // p' of four chain positions [4][T]
-    double *const halo_ring = own_ring + 4 * T;                       // p' of the NX rows above the band [2][NX]
-    PairVal *const cpv = reinterpret_cast<PairVal *>(halo_ring + 2 * NX);
+    constexpr int kHaloSlots = (SCHWZ_DD & 2) ? 3 : 2;
+    double *const halo_ring = own_ring + 4 * T;                       // p' of the NX rows above the band [kHaloSlots][NX]
+    PairVal *const cpv = reinterpret_cast<PairVal *>(halo_ring + kHaloSlots * NX);
     int *const cmask = reinterpret_cast<int *>(cpv + A.canon_npat * 5);
     __shared__ double red[4];
     if (a.it >= a.cg_state->stop_iter) return;
@@ -891,7 +936,10 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
 #pragma unroll
             for (int k = 0; k < NH; ++k) {
                 const int g = clampg(base + 2 * (tid + k * kBlock));
-                o.r[k] = __builtin_nontemporal_load(reinterpret_cast<const pvd2 *>(a.cg_r + g));
+                if (SCHWZ_DD & 4)
+                    o.r[k] = *reinterpret_cast<const pvd2 *>(a.cg_r + g);
+                else
+                    o.r[k] = __builtin_nontemporal_load(reinterpret_cast<const pvd2 *>(a.cg_r + g));
                 if (FIRST)
                     o.p[k] = o.r[k];
                 else
@@ -906,7 +954,12 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
             for (int k = 0; k < NH; ++k) {
                 const pvd2 v = newp(o.r[k], o.p[k]);
                 *reinterpret_cast<pvd2 *>(slot_p + 2 * (tid + k * kBlock)) = v;
-                if (out) __builtin_memcpy(a.y + base + 2 * (tid + k * kBlock), &v, 16);
+                if (out) {
+                    if (SCHWZ_DD & 1)
+                        __builtin_nontemporal_store(v, reinterpret_cast<pvd2 *>(a.y + base + 2 * (tid + k * kBlock)));
+                    else
+                        __builtin_memcpy(a.y + base + 2 * (tid + k * kBlock), &v, 16);
+                }
             }
         };
         auto load_halo = [&](int base, Halo &hh) {
@@ -922,8 +975,9 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
                     __builtin_memcpy(&hh.p[k], a.x + g, 16);
             }
         };
-        auto store_halo = [&](int z, const Halo &hh) {
-            double *slot_p = halo_ring + (size_t)(z & 1) * NX;
+        // (with three slots the slot of a position is passed in: position modulo 3, kept incrementally)
+        auto store_halo = [&](int hslot, const Halo &hh) {
+            double *slot_p = halo_ring + (size_t)hslot * NX;
 #pragma unroll
             for (int k = 0; k < NHL; ++k) {
                 const int pc = min(tid + k * kBlock, NX / 2 - 1);
@@ -931,14 +985,17 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
             }
         };
         struct Rle {
-            unsigned w0, w1, w2, w3;
+            unsigned w[RUNS / 2];
         };
         auto fetch_rle = [&](int base, int h) -> Rle {
-            const const_words q = (const_words)(uintptr_t)(A.pair_rle + ((base + h * kPairRows) / kPairRows));
-            return Rle{q[0], q[1], q[2], q[3]};
+            const const_words q = (const_words)(uintptr_t)(A.pair_rle + ((base + h * kPairRows) / kPairRows) * (RUNS / 8));
+            Rle f;
+#pragma unroll
+            for (int k = 0; k < RUNS / 2; ++k) f.w[k] = q[k];
+            return f;
         };
         Own own_a, own_b;
-        Halo hreg;
+        Halo hreg, hreg_b;
         Rle rle_a[NH], rle_b[NH];
         int brow[5];
 #pragma unroll
@@ -946,11 +1003,18 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
         {
             // the previous position is read by rows whose far-after slot points backwards along the chain
             Own before, first;
+            Halo h0;
             load_own(brow[0], before);
             load_own(brow[1], first);
-            load_halo(brow[1], hreg);
+            load_halo(brow[1], (SCHWZ_DD & 2) ? h0 : hreg);
             load_own(brow[2], own_b);
             load_own(brow[3], own_a);
+            if (SCHWZ_DD & 2) {
+                // halo of the first position goes to its slot now; the next two stay in flight like the own windows
+                load_halo(brow[2], hreg);    // position z0 + 1
+                load_halo(brow[3], hreg_b);  // position z0 + 2
+                store_halo(0, h0);
+            }
             store_own(z0 - 1, brow[0], before, false);
             store_own(z0, brow[1], first, true);
         }
@@ -959,18 +1023,27 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
             rle_a[h] = fetch_rle(brow[1], h);
             rle_b[h] = fetch_rle(z0 + 1 < z1 ? brow[2] : brow[1], h);
         }
-        // one position: `own_next` holds r, p of position z + 1 on entry and of position z + 3 on exit
-        auto step = [&](int z, Own &own_next, Rle (&rl)[NH]) {
+        int hs = 0;  // halo slot of the position being computed (three-slot form)
+        // one position: `own_next` holds r, p of position z + 1 on entry and of position z + 3 on exit; in the
+        // three-slot form `hal_next` holds the halo of position z + 1 on entry and of position z + 3 on exit
+        auto step = [&](int z, Own &own_next, Rle (&rl)[NH], Halo &hal_next) {
             store_own(z + 1, brow[2], own_next, z + 1 < z1);
-            store_halo(z, hreg);
+            const int hs_next = hs == 2 ? 0 : hs + 1;
+            if (SCHWZ_DD & 2)
+                store_halo(hs_next, hal_next);
+            else
+                store_halo(z & 1, hreg);
             lds_barrier();
-            load_halo(brow[2], hreg);
+            if (SCHWZ_DD & 2)
+                load_halo(brow[4], hal_next);
+            else
+                load_halo(brow[2], hreg);
             load_own(brow[4], own_next);
             const int far = chain_far[z];
             const double *cur = own_ring + (size_t)(z & 3) * T;
             const double *prv = own_ring + (size_t)((z + 3) & 3) * T;
             const double *nxt = own_ring + (size_t)((z + 1) & 3) * T;
-            const double *hup = halo_ring + (size_t)(z & 1) * NX;
+            const double *hup = halo_ring + (size_t)((SCHWZ_DD & 2) ? hs : (z & 1)) * NX;
             const double *fa0 = ((far >> 4) & 3) == 1 ? prv : (((far >> 4) & 3) == 2 ? nxt : cur);
             const double *fa1 = ((far >> 6) & 3) == 1 ? prv : (((far >> 6) & 3) == 2 ? nxt : cur);
             const int rbase = z + 2 < z1 ? brow[3] : brow[1];
@@ -978,11 +1051,10 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
             for (int h = 0; h < NH; ++h) {
                 const Rle f = rl[h];
                 const int i0 = h * kPairRows + 2 * tid;
-                const unsigned w[4] = {f.w0, f.w1, f.w2, f.w3};
-                int pid = (int)((w[0] >> 8) & 0xffu);
+                int pid = (int)((f.w[0] >> 8) & 0xffu);
 #pragma unroll
-                for (int k = 1; k < 8; ++k) {
-                    const unsigned e = (w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+                for (int k = 1; k < RUNS; ++k) {
+                    const unsigned e = (f.w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
                     if ((unsigned)tid >= (e & 0xffu)) pid = (int)(e >> 8);
                 }
                 const int mask = cmask[pid];
@@ -1009,13 +1081,14 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
 #pragma unroll
             for (int k = 0; k < 4; ++k) brow[k] = brow[k + 1];
             brow[4] = band_row(z + 4);
+            hs = hs_next;
         };
         int z = z0;
         for (; z + 1 < z1; z += 2) {
-            step(z, own_b, rle_a);
-            step(z + 1, own_a, rle_b);
+            step(z, own_b, rle_a, hreg);
+            step(z + 1, own_a, rle_b, hreg_b);
         }
-        if (z < z1) step(z, own_b, rle_a);
+        if (z < z1) step(z, own_b, rle_a, hreg);
     }
     const double s0 = block_sum(acc0, red);
     if (tid == 0) {
@@ -1054,6 +1127,49 @@ bool pair_sweep_dual_ok(const CsrView &A, int grid)
            A.sweep_nslots + A.dual_blocks <= grid;
 }
 
+// One instantiation of the z-sweep update / start walk: raises its dynamic-LDS limit once, launches it.
+// false: the device does not grant 96 KiB of dynamic LDS to the kernel (nothing was launched).
+template <int L_, int H_, bool DV, bool INIT, bool DUAL, int RUNS, bool H3>
+static bool launch_sweep_instance(const CsrView &A, const SpmvArgs &b, size_t lds, hipStream_t s)
+{
+    static const hipError_t e = hipFuncSetAttribute((const void *)spmv_pair_sweep_kernel<L_, H_, DV, INIT, DUAL, RUNS, H3>,
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);
+    if (e != hipSuccess || lds > (size_t)(96 << 10)) return false;
+    hipLaunchKernelGGL((spmv_pair_sweep_kernel<L_, H_, DV, INIT, DUAL, RUNS, H3>), dim3(A.sweep_nslots), dim3(kBlock), lds, s, A, b);
+    return true;
+}
+
+// ... chosen by the run-length record of the matrix (8 / 16 runs per chunk) and the halo schedule
+template <int L_, int H_, bool DV, bool INIT, bool DUAL>
+static bool launch_sweep_variant(const CsrView &A, const SpmvArgs &b, size_t lds, bool h3, hipStream_t s)
+{
+    if (A.pair_rle_runs == 16)
+        return h3 ? launch_sweep_instance<L_, H_, DV, INIT, DUAL, 16, true>(A, b, lds, s)
+                  : launch_sweep_instance<L_, H_, DV, INIT, DUAL, 16, false>(A, b, lds, s);
+    return h3 ? launch_sweep_instance<L_, H_, DV, INIT, DUAL, 8, true>(A, b, lds, s)
+              : launch_sweep_instance<L_, H_, DV, INIT, DUAL, 8, false>(A, b, lds, s);
+}
+
+// Halo schedule of the update / start walk: three positions ahead into three halo slots (H3) where the larger
+// ring leaves the workgroups per CU unchanged (LDS of 3 workgroups within 160 KiB), else one ahead into two.
+// SCHWZ_SWEEP_H3=0 / 1: never / wherever 96 KiB allow.
+static bool sweep_h3(const CsrView &A, size_t *lds)
+{
+    const size_t tables = (size_t)A.canon_npat * (9 * 16 + 4);
+    const size_t lds2 = (size_t)(4 * A.sweep_T + 4 * A.sweep_nx) * sizeof(double) + tables;
+    const size_t lds3 = (size_t)(4 * A.sweep_T + 6 * A.sweep_nx) * sizeof(double) + tables;
+    const char *e = std::getenv("SCHWZ_SWEEP_H3");
+    bool h3;
+    if (e && e[0] == '0')
+        h3 = false;
+    else if (e && e[0] == '1')
+        h3 = lds3 <= (size_t)(96 << 10);
+    else
+        h3 = (160u << 10) / (lds3 + 64) >= std::min<size_t>(3, (160u << 10) / (lds2 + 64));
+    *lds = h3 ? lds3 : lds2;
+    return h3;
+}
+
 int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s)
 {
     const bool wide = A.ncols >= (int64_t(1) << 28);  // byte offsets of x beyond 32 bits
@@ -1065,7 +1181,8 @@ int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hi
             return SCHWZ_ERR_INVALID;
         }
         const int nhl = (A.sweep_nx + kBlock - 1) / kBlock, nh = A.sweep_T / kPairRows;
-        const size_t lds = (size_t)(4 * A.sweep_T + 4 * A.sweep_nx) * sizeof(double) + (size_t)A.canon_npat * (9 * 16 + 4);
+        size_t lds = 0;
+        const bool h3 = sweep_h3(A, &lds);
         SpmvArgs b = a;
         b.part_stride = grid;
         b.part_offset = 0;
@@ -1076,25 +1193,20 @@ int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hi
             set_error("launch_spmv_pair: the z-sweep dual start launch does not apply to this matrix");
             return SCHWZ_ERR_INVALID;
         }
-#define SCHWZ_SWEEP_INIT(L_, H_)                                                                                          \
-    {                                                                                                                    \
-        static const hipError_t e0 = hipFuncSetAttribute((const void *)spmv_pair_sweep_kernel<L_, H_, false, true, false>, \
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);          \
-        static const hipError_t e1 = hipFuncSetAttribute((const void *)spmv_pair_sweep_kernel<L_, H_, false, true, true>, \
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);          \
-        (void)e0;                                                                                                        \
-        (void)e1;                                                                                                        \
-        if (with_dual)                                                                                                   \
-            hipLaunchKernelGGL((spmv_pair_sweep_kernel<L_, H_, false, true, true>), dim3(A.sweep_nslots), dim3(kBlock), lds, s, A, b); \
-        else                                                                                                             \
-            hipLaunchKernelGGL((spmv_pair_sweep_kernel<L_, H_, false, true, false>), dim3(A.sweep_nslots), dim3(kBlock), lds, s, A, b); \
-    }
+#define SCHWZ_SWEEP_INIT(L_, H_)                                                                              \
+    ok = with_dual ? launch_sweep_variant<L_, H_, false, true, true>(A, b, lds, h3, s)                            \
+                   : launch_sweep_variant<L_, H_, false, true, false>(A, b, lds, h3, s);
+        bool ok = false;
         if (nh == 1 && nhl == 1) SCHWZ_SWEEP_INIT(1, 1)
         else if (nh == 1 && nhl == 2) SCHWZ_SWEEP_INIT(2, 1)
         else if (nh == 2 && nhl == 1) SCHWZ_SWEEP_INIT(1, 2)
         else if (nh == 2 && nhl == 2) SCHWZ_SWEEP_INIT(2, 2)
         else if (nh == 1) SCHWZ_SWEEP_INIT(4, 1)
         else SCHWZ_SWEEP_INIT(4, 2)
+        if (!ok) {
+            set_error("launch_spmv_pair: the z-sweep kernels cannot have their dynamic LDS on this device");
+            return SCHWZ_ERR_HIP;
+        }
 #undef SCHWZ_SWEEP_INIT
         SCHWZ_HIP_TRY(hipGetLastError());
         if (with_dual) {
@@ -1121,7 +1233,7 @@ int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hi
             return SCHWZ_ERR_INVALID;
         }
         const int nhl = (A.sweep_nx / 2 + kBlock - 1) / kBlock, nh = A.sweep_T_dir / kPairRows;
-        const size_t lds = (size_t)(4 * A.sweep_T_dir + 2 * A.sweep_nx) * sizeof(double) + (size_t)A.canon_npat * (5 * 16 + 4);
+        const size_t lds = (size_t)(4 * A.sweep_T_dir + ((SCHWZ_DD & 2) ? 3 : 2) * A.sweep_nx) * sizeof(double) + (size_t)A.canon_npat * (5 * 16 + 4);
         SpmvArgs b = a;
         b.part_stride = grid;
         b.part_offset = 0;
@@ -1129,8 +1241,20 @@ int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hi
     {                                                                                                                    \
         static const hipError_t e0 = hipFuncSetAttribute((const void *)spmv_pair_dirdot_sweep_kernel<L_, H_, true>,      \
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);          \
-        (void)e0;                                                                                                        \
-        hipLaunchKernelGGL((spmv_pair_dirdot_sweep_kernel<L_, H_, true>), dim3(A.sweep_nslots_dir), dim3(kBlock), lds, s, A, b); \
+        if (e0 != hipSuccess) {                                                                                          \
+            set_error("launch_spmv_pair: the z-sweep kernels cannot have 96 KiB of dynamic LDS on this device");         \
+            return SCHWZ_ERR_HIP;                                                                                        \
+        }                                                                                                                \
+        if (A.pair_rle_runs == 16) {                                                                                     \
+            static const hipError_t e2 = hipFuncSetAttribute((const void *)spmv_pair_dirdot_sweep_kernel<L_, H_, true, 16>, \
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);      \
+            if (e2 != hipSuccess) {                                                                                      \
+                set_error("launch_spmv_pair: the z-sweep kernels cannot have 96 KiB of dynamic LDS on this device");     \
+                return SCHWZ_ERR_HIP;                                                                                    \
+            }                                                                                                            \
+            hipLaunchKernelGGL((spmv_pair_dirdot_sweep_kernel<L_, H_, true, 16>), dim3(A.sweep_nslots_dir), dim3(kBlock), lds, s, A, b); \
+        } else                                                                                                           \
+            hipLaunchKernelGGL((spmv_pair_dirdot_sweep_kernel<L_, H_, true>), dim3(A.sweep_nslots_dir), dim3(kBlock), lds, s, A, b); \
     }
         if (nh == 1 && nhl == 1) SCHWZ_DIRDOT_FIRST(1, 1)
         else if (nh == 1) SCHWZ_DIRDOT_FIRST(2, 1)
@@ -1149,25 +1273,16 @@ int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hi
             // z-sweep walk + (where boundary planes or overlap rows exist) the listed walk of the chunks it
             // leaves out; the consumer folds `grid` partial sums per bank, as after a chunk-by-chunk launch
             const int nhl = (A.sweep_nx + kBlock - 1) / kBlock, nh = A.sweep_T / kPairRows;  // halo / own pieces per lane
-            const size_t lds = (size_t)(4 * A.sweep_T + 4 * A.sweep_nx) * sizeof(double) + (size_t)A.canon_npat * (9 * 16 + 4);
+            size_t lds = 0;
+            const bool h3 = sweep_h3(A, &lds);
             SpmvArgs b = a;
             b.part_stride = grid;
             b.part_offset = A.sweep_gen_blocks;  // slots of the companion launch follow this one's
             const bool dv = a.diag_mode == 1;
-#define SCHWZ_SWEEP_LAUNCH(L_, H_)                                                                                        \
-    {                                                                                                                    \
-        static const hipError_t e0 = hipFuncSetAttribute((const void *)spmv_pair_sweep_kernel<L_, H_, false>,            \
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);          \
-        static const hipError_t e1 = hipFuncSetAttribute((const void *)spmv_pair_sweep_kernel<L_, H_, true>,             \
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);          \
-        (void)e0;                                                                                                        \
-        (void)e1;                                                                                                        \
-        if (dv)                                                                                                          \
-            hipLaunchKernelGGL((spmv_pair_sweep_kernel<L_, H_, true>), dim3(A.sweep_nslots), dim3(kBlock), lds, s, A, b); \
-        else                                                                                                             \
-            hipLaunchKernelGGL((spmv_pair_sweep_kernel<L_, H_, false>), dim3(A.sweep_nslots), dim3(kBlock), lds, s, A, b); \
-    }
-            bool launched = true;
+#define SCHWZ_SWEEP_LAUNCH(L_, H_)                                                                   \
+    launched = dv ? launch_sweep_variant<L_, H_, true, false, false>(A, b, lds, h3, s)                 \
+                  : launch_sweep_variant<L_, H_, false, false, false>(A, b, lds, h3, s);
+            bool launched = true;  // false: no such instantiation, or no LDS for it -- chunk by chunk then
             if (nh == 1 && nhl == 1) SCHWZ_SWEEP_LAUNCH(1, 1)
             else if (nh == 1 && nhl == 2) SCHWZ_SWEEP_LAUNCH(2, 1)
             else if (nh == 2 && nhl == 1) SCHWZ_SWEEP_LAUNCH(1, 2)
@@ -1196,7 +1311,7 @@ int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hi
         const char *sweep_env = std::getenv("SCHWZ_CG_SWEEP");
         if (!(sweep_env && sweep_env[0] == '0')) {
             const int nhl = (A.sweep_nx / 2 + kBlock - 1) / kBlock, nh = A.sweep_T_dir / kPairRows;
-            const size_t lds = (size_t)(4 * A.sweep_T_dir + 2 * A.sweep_nx) * sizeof(double) + (size_t)A.canon_npat * (5 * 16 + 4);
+            const size_t lds = (size_t)(4 * A.sweep_T_dir + ((SCHWZ_DD & 2) ? 3 : 2) * A.sweep_nx) * sizeof(double) + (size_t)A.canon_npat * (5 * 16 + 4);
             if (nhl <= 2) {
                 // the companion first: the z-sweep kernel's workgroup 0 advances CgState for both
                 if (A.sweep_gen_blocks > 0) {
@@ -1215,8 +1330,20 @@ int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hi
     {                                                                                                                    \
         static const hipError_t e0 = hipFuncSetAttribute((const void *)spmv_pair_dirdot_sweep_kernel<L_, H_>,            \
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);          \
-        (void)e0;                                                                                                        \
-        hipLaunchKernelGGL((spmv_pair_dirdot_sweep_kernel<L_, H_>), dim3(A.sweep_nslots_dir), dim3(kBlock), lds, s, A, b); \
+        if (e0 != hipSuccess) {                                                                                          \
+            set_error("launch_spmv_pair: the z-sweep kernels cannot have 96 KiB of dynamic LDS on this device");         \
+            return SCHWZ_ERR_HIP;                                                                                        \
+        }                                                                                                                \
+        if (A.pair_rle_runs == 16) {                                                                                     \
+            static const hipError_t e2 = hipFuncSetAttribute((const void *)spmv_pair_dirdot_sweep_kernel<L_, H_, false, 16>, \
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);      \
+            if (e2 != hipSuccess) {                                                                                      \
+                set_error("launch_spmv_pair: the z-sweep kernels cannot have 96 KiB of dynamic LDS on this device");     \
+                return SCHWZ_ERR_HIP;                                                                                    \
+            }                                                                                                            \
+            hipLaunchKernelGGL((spmv_pair_dirdot_sweep_kernel<L_, H_, false, 16>), dim3(A.sweep_nslots_dir), dim3(kBlock), lds, s, A, b); \
+        } else                                                                                                           \
+            hipLaunchKernelGGL((spmv_pair_dirdot_sweep_kernel<L_, H_>), dim3(A.sweep_nslots_dir), dim3(kBlock), lds, s, A, b); \
     }
                 if (nh == 1 && nhl == 1) SCHWZ_DIRDOT_LAUNCH(1, 1)
                 else if (nh == 1) SCHWZ_DIRDOT_LAUNCH(2, 1)
@@ -1330,12 +1457,13 @@ static int build_sweep(schwz_csr *A, int64_t nrows, const PairTable &tb, const P
     for (int k = 0; k < nplanes; ++k) {
         std::vector<uint8_t> used((size_t)tb.npat, 0);
         for (int c = k * cpp; c < (k + 1) * cpp && plane_ok[(size_t)k]; ++c) {
-            if (rle[(size_t)c * 8] == 0xffffu) {  // ids must run-length code (scalar loads only)
+            const int R = A->v.pair_rle_runs;
+            if (rle[(size_t)c * R] == 0xffffu) {  // ids must run-length code (scalar loads only)
                 plane_ok[(size_t)k] = 0;
                 break;
             }
             // the patterns of a chunk are the ids of its runs
-            for (int r = 0; r < 8; ++r) used[(size_t)(rle[(size_t)c * 8 + r] >> 8)] = 1;
+            for (int r = 0; r < R; ++r) used[(size_t)(rle[(size_t)c * R + r] >> 8)] = 1;
         }
         if (!plane_ok[(size_t)k]) continue;
         std::vector<schwz_idx> far;
@@ -1484,6 +1612,12 @@ static int build_sweep(schwz_csr *A, int64_t nrows, const PairTable &tb, const P
     int T = t_env ? std::atoi(t_env) : (NX >= 512 ? 1024 : 512);
     if (T != 512 && T != 1024) T = 512;
     if (PL % T) T = 512;
+    // dynamic LDS of the update / start walk: the ring (4 T own + 4 NX halo doubles) and the nine-slot tables of
+    // every pattern; the launches raise the kernels' limit to 96 KiB.  Too many patterns for the tall band: the
+    // short one; still too much: no walk (the chunk-by-chunk launches take the matrix).
+    auto walk_lds = [&](int t) { return (size_t)(4 * t + 4 * NX) * sizeof(double) + (size_t)tb.npat * (9 * 16 + 4); };
+    if (walk_lds(T) > (size_t)(96 << 10) && T == 1024 && PL % 512 == 0) T = 512;
+    if (walk_lds(T) > (size_t)(96 << 10)) return SCHWZ_OK;
     const int bands = (int)(PL / T);
     const int grid = (int)((std::min<int64_t>(ntiles, kMaxGrid) + kXcds - 1) / kXcds) * kXcds;
     struct Run { int p0, p1; };
@@ -1586,7 +1720,7 @@ static int build_sweep(schwz_csr *A, int64_t nrows, const PairTable &tb, const P
     const char *td_env = std::getenv("SCHWZ_SWEEP_TDIR");
     int T_dir = td_env ? std::atoi(td_env) : (T == 512 ? 1024 : (NX >= 1024 ? 2048 : T));
     if ((T_dir != 512 && T_dir != 1024 && T_dir != 2048) || PL % T_dir ||
-        (size_t)(4 * T_dir + 2 * NX) * sizeof(double) + (size_t)tb.npat * 84 > (size_t)(96 << 10))
+        (size_t)(4 * T_dir + ((SCHWZ_DD & 2) ? 3 : 2) * NX) * sizeof(double) + (size_t)tb.npat * 84 > (size_t)(96 << 10))
         T_dir = T;
     std::vector<int4> slots_dir;
     if (T_dir != T) {
@@ -1884,32 +2018,52 @@ int build_spmv_pair(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, con
         return rc;
     A->v.pair_id = (const uint8_t *)A->d_pair_id;
     // run-length form of the ids, chunk by chunk (SCHWZ_SPMV_RLE=0: byte ids only)
+    // Records of 8 runs (16 bytes per chunk) serve x lines of ~170 entries and more; a matrix some of whose
+    // chunks need up to 16 runs (a 512-row chunk of a 192 x 192 plane crosses three line ends: ten runs) gets
+    // records of 16 runs (32 bytes per chunk) throughout -- SCHWZ_SPMV_RLE=8 keeps the short records.
     const char *rle_env = std::getenv("SCHWZ_SPMV_RLE");
     std::vector<uint16_t> rle;
+    int rle_runs = 8;
     if (!(rle_env && rle_env[0] == '0')) {
-        rle.assign((size_t)nchunks * 8, 0xffffu);
-        for (int c = 0; c < nchunks; ++c) {
-            if (chunk_ptable[(size_t)c] < 0) continue;
-            const int64_t p0 = (int64_t)c * (kPairRows / 2), p1 = std::min<int64_t>(p0 + kPairRows / 2, (nrows + 1) / 2);
-            uint16_t runs[8];
-            int nr = 0;
-            bool fits = true;
-            for (int64_t p = p0; p < p1 && fits; ++p) {
-                if (nr == 0 || pair_id[(size_t)p] != (uint8_t)(runs[nr - 1] >> 8)) {
-                    if (nr == 8) {
-                        fits = false;
-                        break;
+        auto build_rle = [&](int R, int64_t *coded_out) {
+            std::vector<uint16_t> out((size_t)nchunks * R, 0xffffu);
+            int64_t coded = 0;
+            for (int c = 0; c < nchunks; ++c) {
+                if (chunk_ptable[(size_t)c] < 0) continue;
+                const int64_t p0 = (int64_t)c * (kPairRows / 2), p1 = std::min<int64_t>(p0 + kPairRows / 2, (nrows + 1) / 2);
+                uint16_t runs[16];
+                int nr = 0;
+                bool fits = true;
+                for (int64_t p = p0; p < p1 && fits; ++p) {
+                    if (nr == 0 || pair_id[(size_t)p] != (uint8_t)(runs[nr - 1] >> 8)) {
+                        if (nr == R) {
+                            fits = false;
+                            break;
+                        }
+                        runs[nr++] = (uint16_t)((p - p0) | ((int)pair_id[(size_t)p] << 8));
                     }
-                    runs[nr++] = (uint16_t)((p - p0) | ((int)pair_id[(size_t)p] << 8));
                 }
+                if (!fits || nr == 0) continue;
+                for (int k = nr; k < R; ++k) runs[k] = runs[nr - 1];
+                if (runs[0] == 0xffffu) continue;  // would read as the "not coded" marker
+                std::copy(runs, runs + R, out.begin() + (size_t)c * R);
+                ++coded;
             }
-            if (!fits || nr == 0) continue;
-            for (int k = nr; k < 8; ++k) runs[k] = runs[nr - 1];
-            if (runs[0] == 0xffffu) continue;  // would read as the "not coded" marker
-            std::copy(runs, runs + 8, rle.begin() + (size_t)c * 8);
+            *coded_out = coded;
+            return out;
+        };
+        int64_t coded8 = 0, coded16 = 0;
+        rle = build_rle(8, &coded8);
+        if (!(rle_env && rle_env[0] == '8')) {
+            std::vector<uint16_t> wide = build_rle(16, &coded16);
+            if (coded16 > coded8) {
+                rle.swap(wide);
+                rle_runs = 16;
+            }
         }
         if ((rc = upv(rle, &A->d_pair_rle))) return rc;
         A->v.pair_rle = (const uint4 *)A->d_pair_rle;
+        A->v.pair_rle_runs = rle_runs;
     }
     A->v.chunk_ptable = (const schwz_idx *)A->d_tile_ptable;
     A->v.ptbl_desc = (const schwz_idx *)A->d_ptbl_desc;
@@ -1965,8 +2119,8 @@ int build_spmv_pair(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, con
         const uint16_t *rle_h = rle.empty() ? nullptr : rle.data();
         for (int c = 0; c < nchunks; ++c) {
             if (chunk_ptable[(size_t)c] < 0) continue;
-            const bool runs = rle_h && rle_h[(size_t)c * 8] != 0xffffu;
-            bytes += runs ? 16 : (rle_h ? 16 : 0) + kPairRows / 2;
+            const bool runs = rle_h && rle_h[(size_t)c * rle_runs] != 0xffffu;
+            bytes += runs ? 2 * rle_runs : (rle_h ? 2 * rle_runs : 0) + kPairRows / 2;
             if (!single) bytes += 4;
         }
         const size_t ntab = sym_base ? (size_t)sym_base : tables.size();

@@ -247,7 +247,9 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(CsrView A, SpmvArgs
     }
 }
 
-// measurement builds of the plain mode (tools/stream_check.py)
+#ifdef SCHWZ_WITH_PROBES
+// measurement builds of the plain mode (tools/stream_ablate.py, tools/r03_stream_probe.py): compiled into
+// libschwz_hip_probes.so only
 int launch_spmv_stream_ablate(const CsrView &A, const SpmvArgs &a, int abl, hipStream_t s)
 {
     if (A.stream_cap == 0 || A.stream_cap > 8 || !A.tile_nz || A.tile_order) {
@@ -277,6 +279,8 @@ int launch_spmv_stream_ablate(const CsrView &A, const SpmvArgs &a, int abl, hipS
     SCHWZ_HIP_TRY(hipGetLastError());
     return SCHWZ_OK;
 }
+
+#endif  // SCHWZ_WITH_PROBES
 
 // Folds the per-workgroup partial sums of a launch of `nin` workgroups (two banks, `nin` apart) into the `nout`
 // slots per bank the consumers read: slot i = the sum of the workgroups i, i + nout, ... in that order.

@@ -112,6 +112,58 @@ private:
     std::vector<T> data_;
 };
 
+// host-resident CSR matrix: the arrays and the accessors of gko::matrix::Csr a caller of the solver class reads
+// (the public matrix members of SchwarzBase, include/schwarz_base.hpp:137-167); no arithmetic
+template <typename T = default_precision, typename I = int32>
+class Csr {
+public:
+    using value_type = T;
+    using index_type = I;
+    static std::unique_ptr<Csr> create(std::shared_ptr<Executor> exec, dim<2> size = dim<2>(0, 0), size_type nnz = 0)
+    {
+        return std::unique_ptr<Csr>(new Csr(std::move(exec), size, nnz));
+    }
+    dim<2> get_size() const { return size_; }
+    size_type get_num_stored_elements() const { return vals_.size(); }
+    T *get_values() { return vals_.data(); }
+    const T *get_const_values() const { return vals_.data(); }
+    I *get_col_idxs() { return cols_.data(); }
+    const I *get_const_col_idxs() const { return cols_.data(); }
+    I *get_row_ptrs() { return rows_.data(); }
+    const I *get_const_row_ptrs() const { return rows_.data(); }
+    std::shared_ptr<Executor> get_executor() const { return exec_; }
+
+private:
+    Csr(std::shared_ptr<Executor> exec, dim<2> size, size_type nnz)
+        : exec_(std::move(exec)), size_(size), rows_(size[0] + 1, I{}), cols_(nnz, I{}), vals_(nnz, T{})
+    {}
+    std::shared_ptr<Executor> exec_;
+    dim<2> size_;
+    std::vector<I> rows_, cols_;
+    std::vector<T> vals_;
+};
+
+// row permutation as an index array (gko::matrix::Permutation)
+template <typename I = int32>
+class Permutation {
+public:
+    using index_type = I;
+    static std::unique_ptr<Permutation> create(std::shared_ptr<Executor> exec, size_type n = 0)
+    {
+        return std::unique_ptr<Permutation>(new Permutation(std::move(exec), n));
+    }
+    dim<2> get_size() const { return dim<2>(perm_.size(), perm_.size()); }
+    size_type get_permutation_size() const { return perm_.size(); }
+    I *get_permutation() { return perm_.data(); }
+    const I *get_const_permutation() const { return perm_.data(); }
+    std::shared_ptr<Executor> get_executor() const { return exec_; }
+
+private:
+    Permutation(std::shared_ptr<Executor> exec, size_type n) : exec_(std::move(exec)), perm_(n, I{}) {}
+    std::shared_ptr<Executor> exec_;
+    std::vector<I> perm_;
+};
+
 }  // namespace matrix
 
 template <typename T>

@@ -42,9 +42,33 @@ public:
     // on rank 0
     void run(std::shared_ptr<gko::matrix::Dense<ValueType>> &solution);
 
-    // host copies of this rank's vectors (public members of the reference class)
+    // ---- the public data members of the reference class (include/schwarz_base.hpp:137-197), as HOST copies:
+    // the working data lives in HBM behind the C ABI and is never read through these.
+    // local_matrix / interface_matrix (interface columns are GLOBAL ids, like the reference stores them),
+    // and for the direct local solver triangular_factor_l / _u (A(perm, perm) = L L^T, U = L^T) with
+    // local_perm / local_inv_perm: filled by initialize() for subdomains of up to 2^24 nonzeros
+    // (SCHWZ_PUBLIC_MEMBERS=1: any size, =0: never), or on demand by materialize_public_members().
+    std::shared_ptr<gko::matrix::Csr<ValueType, IndexType>> local_matrix;
+    std::shared_ptr<gko::matrix::Permutation<IndexType>> local_perm;
+    std::shared_ptr<gko::matrix::Permutation<IndexType>> local_inv_perm;
+    std::shared_ptr<gko::matrix::Csr<ValueType, IndexType>> triangular_factor_l;
+    std::shared_ptr<gko::matrix::Csr<ValueType, IndexType>> triangular_factor_u;
+    std::shared_ptr<gko::matrix::Csr<ValueType, IndexType>> interface_matrix;
+    // Deliberately ABSENT (always null): nothing of global length exists per rank in this build (the reference
+    // replicates the N x N matrix and the rhs on every rank, schwarz_base.cpp:142-147,169).
+    std::shared_ptr<gko::matrix::Csr<ValueType, IndexType>> global_matrix;
+    std::shared_ptr<gko::matrix::Dense<ValueType>> global_rhs;
+    // host copies of this rank's vectors: rhs after initialize(), the last local solution after run()
     std::shared_ptr<gko::matrix::Dense<ValueType>> local_rhs;
     std::shared_ptr<gko::matrix::Dense<ValueType>> local_solution;
+    // the assembled solution on rank 0 after run() (the object run() hands back), null elsewhere
+    std::shared_ptr<gko::matrix::Dense<ValueType>> global_solution;
+    // residual histories of the last run (also in metadata.post_process_data)
+    std::vector<ValueType> local_residual_vector_out;
+    std::vector<std::vector<ValueType>> global_residual_vector_out;
+
+    // Extension: fills the matrix members above from the library's host-side subdomain (after initialize()).
+    void materialize_public_members();
 
 protected:
     Settings &settings;

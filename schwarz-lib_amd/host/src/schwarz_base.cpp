@@ -511,6 +511,87 @@ void SchwarzBase<V, I, M>::initialize()
             std::cout << " Local direct solve with HIP TRS" << std::endl;
         }
     }
+    // host copies behind the reference's public matrix members: by default only where they are cheap
+    local_matrix.reset();
+    interface_matrix.reset();
+    triangular_factor_l.reset();
+    triangular_factor_u.reset();
+    local_perm.reset();
+    local_inv_perm.reset();
+    {
+        const char *pm = std::getenv("SCHWZ_PUBLIC_MEMBERS");
+        const bool never = pm && pm[0] == '0', always = pm && pm[0] == '1';
+        if (!never && (always || im.sizes[4] <= (int64_t(1) << 24))) materialize_public_members();
+    }
+}
+
+// The public matrix members of the reference class (include/schwarz_base.hpp:137-167) as host objects: the local
+// and interface matrices as the library's host-side subdomain holds them (restricted_schwarz.cpp:245-298) and,
+// for the direct local solver, the factors of A(perm, perm) = L L^T with the fill-reducing permutation
+// (solve.cpp:92-143: the same host factorisation the device solve was built from).
+template <typename V, typename I, typename M>
+void SchwarzBase<V, I, M>::materialize_public_members()
+{
+    auto &im = *impl_;
+    auto &s = settings;
+    if (!im.sd) throw ::BadDimension(__FILE__, __LINE__, __func__, "initialize() has not run");
+    auto host = s.executor->get_master();
+    const int64_t n = im.sizes[1], nnz = im.sizes[4], nnz_i = im.sizes[5];
+    std::vector<schwz_idx> rp((size_t)n + 1), col((size_t)std::max<int64_t>(nnz, 1));
+    std::vector<double> val((size_t)std::max<int64_t>(nnz, 1));
+    SCHWZ_CALL(schwz_subdomain_local_matrix(im.sd, rp.data(), col.data(), val.data()));
+    local_matrix = gko::share(gko::matrix::Csr<V, I>::create(host, gko::dim<2>((gko::size_type)n, (gko::size_type)n),
+                                                              (gko::size_type)nnz));
+    for (int64_t i = 0; i <= n; ++i) local_matrix->get_row_ptrs()[i] = (I)rp[(size_t)i];
+    for (int64_t j = 0; j < nnz; ++j) {
+        local_matrix->get_col_idxs()[j] = (I)col[(size_t)j];
+        local_matrix->get_values()[j] = (V)val[(size_t)j];
+    }
+    {
+        std::vector<schwz_idx> irp((size_t)n + 1);
+        std::vector<int64_t> icol((size_t)std::max<int64_t>(nnz_i, 1));
+        std::vector<double> ival((size_t)std::max<int64_t>(nnz_i, 1));
+        SCHWZ_CALL(schwz_subdomain_interface_matrix(im.sd, irp.data(), icol.data(), ival.data()));
+        interface_matrix = gko::share(gko::matrix::Csr<V, I>::create(
+            host, gko::dim<2>((gko::size_type)n, (gko::size_type)n), (gko::size_type)nnz_i));
+        for (int64_t i = 0; i <= n; ++i) interface_matrix->get_row_ptrs()[i] = (I)irp[(size_t)i];
+        for (int64_t j = 0; j < nnz_i; ++j) {
+            interface_matrix->get_col_idxs()[j] = (I)icol[(size_t)j];  // global ids (int32 instantiations: N < 2^31)
+            interface_matrix->get_values()[j] = (V)ival[(size_t)j];
+        }
+    }
+    if (s.local_solver == Settings::local_solver_settings::direct_solver_ginkgo ||
+        s.local_solver == Settings::local_solver_settings::direct_solver_cholmod) {
+        schwz_idx *l_rp = nullptr, *l_col = nullptr, *u_rp = nullptr, *u_col = nullptr, *perm = nullptr;
+        double *l_val = nullptr, *u_val = nullptr;
+        SCHWZ_CALL(schwz_cholesky(n, rp.data(), col.data(), val.data(), s.naturally_ordered_factor ? 1 : 0, &l_rp, &l_col,
+                                  &l_val, &u_rp, &u_col, &u_val, &perm));
+        auto fill = [&](std::shared_ptr<gko::matrix::Csr<V, I>> &dst, const schwz_idx *frp, const schwz_idx *fcol,
+                        const double *fval) {
+            dst = gko::share(gko::matrix::Csr<V, I>::create(host, gko::dim<2>((gko::size_type)n, (gko::size_type)n),
+                                                             (gko::size_type)frp[n]));
+            for (int64_t i = 0; i <= n; ++i) dst->get_row_ptrs()[i] = (I)frp[i];
+            for (int64_t j = 0; j < frp[n]; ++j) {
+                dst->get_col_idxs()[j] = (I)fcol[j];
+                dst->get_values()[j] = (V)fval[j];
+            }
+        };
+        fill(triangular_factor_l, l_rp, l_col, l_val);
+        fill(triangular_factor_u, u_rp, u_col, u_val);
+        local_perm = gko::share(gko::matrix::Permutation<I>::create(host, (gko::size_type)n));
+        local_inv_perm = gko::share(gko::matrix::Permutation<I>::create(host, (gko::size_type)n));
+        for (int64_t i = 0; i < n; ++i) {
+            local_perm->get_permutation()[i] = (I)perm[i];
+            local_inv_perm->get_permutation()[perm[i]] = (I)i;
+        }
+        schwz_free(l_rp);
+        schwz_free(l_col);
+        schwz_free(l_val);
+        schwz_free(u_rp);
+        schwz_free(u_col);
+        schwz_free(u_val);
+        schwz_free(perm);
+    }
 }
 
 template <typename V, typename I, typename M>
@@ -1042,7 +1123,27 @@ void SchwarzBase<V, I, M>::run(std::shared_ptr<gko::matrix::Dense<V>> &solution)
         if (solution->get_size()[0] != m.global_size)
             solution = gko::share(gko::matrix::Dense<V>::create(s.executor->get_master(), gko::dim<2>(m.global_size, 1)));
         for (gko::size_type i = 0; i < m.global_size; ++i) solution->at(i) = (V)gathered[i];
+        global_solution = solution;
     }
+    // public members of the reference class: the local solution and the histories.  Interior rows from x~ (what
+    // the last COMPLETED local solve restricted; the solve enqueued beside the final convergence check is
+    // discarded, schwarz_base.cpp:420-452), overlap rows from the solver's vector y
+    {
+        double *d_x = nullptr, *d_y = nullptr;
+        int64_t len_x = 0, len = 0;
+        SCHWZ_CALL(schwz_ras_vector(im.sd, 0, &d_x, &len_x));
+        SCHWZ_CALL(schwz_ras_vector(im.sd, 2, &d_y, &len));
+        std::vector<double> y((size_t)std::max<int64_t>(len, 1));
+        const int64_t nint = std::min<int64_t>((int64_t)m.local_size, len);
+        HIP_CALL(hipDeviceSynchronize());
+        if (nint > 0) HIP_CALL(hipMemcpy(y.data(), d_x, (size_t)nint * sizeof(double), hipMemcpyDeviceToHost));
+        if (len > nint)
+            HIP_CALL(hipMemcpy(y.data() + nint, d_y + nint, (size_t)(len - nint) * sizeof(double), hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < len && (gko::size_type)i < local_solution->get_size()[0]; ++i)
+            local_solution->at((gko::size_type)i) = (V)y[(size_t)i];
+    }
+    local_residual_vector_out = ppd.local_residual_vector_out;
+    global_residual_vector_out = ppd.global_residual_vector_out;
 }
 
 #define SCHWZ_INSTANTIATE(V, I, M)          \

@@ -418,6 +418,7 @@ class SolverRAS:
             (me, [(q, len(ids)) for q, ids in sd.put_lists()],
              [(p, len(ids)) for p, ids in sd.get_lists()], sd.num_send, sd.num_recv)
             for me, sd in self.subdomains.items()]
+        self.close()  # windows of an earlier initialize()
         self._win = None
         if s.comm_settings.enable_onesided and getattr(comm, "node_windows", False) \
                 and not s.comm_settings.enable_overlap:
@@ -597,6 +598,14 @@ class SolverRAS:
         which offset of a neighbour's window its own values live (put_displacements /
         get_displacements, restricted_schwarz.cpp:624-658)."""
         s, be, comm = self.settings, self.backend, self.comm
+        # HIP IPC handles and the POSIX shared-memory segment only mean something on ONE node
+        import socket
+        hosts = set(comm.share(socket.gethostname()))
+        if len(hosts) > 1:
+            raise capi.SchwzError(capi.ERR_INVALID,
+                                  "the free-running one-sided mode maps the neighbours' device windows through HIP "
+                                  "IPC and needs all ranks on one node; this job spans %d hosts (%s)" %
+                                  (len(hosts), ", ".join(sorted(hosts))))
         me = comm.rank
         sd = self.subdomains[me]
         single = s.use_mixed_precision
@@ -617,6 +626,27 @@ class SolverRAS:
                          puts=[(q, len(ids)) for q, ids in sd.put_lists()],
                          gets=[(p, len(ids)) for p, ids in sd.get_lists()], roff=roff, soff=soff)
         comm.barrier()
+
+    def close(self):
+        """Releases the windows of the free-running one-sided mode in an order every rank can rely on:
+        nobody iterates any more (barrier), the mappings of the neighbours' windows go, everybody has
+        unmapped (barrier), the own exported buffers are freed, then the host windows (the creator unlinks
+        the shared-memory segment).  Collective; called by a re-initialize and by the owner when done."""
+        win = getattr(self, "_win", None)
+        if win is None:
+            return
+        self._win = None
+        comm = self.comm
+        self.backend.synchronize()
+        comm.barrier()
+        for w, _ in list(win["peers_recv"].values()) + list(win["peers_send"].values()):
+            w.close()
+        comm.barrier()
+        win["recv"].close()
+        win["send"].close()
+        win["host"] = None
+        if hasattr(comm, "close_windows"):
+            comm.close_windows()
 
     def _exchange_free_running(self, sd, stream):
         """exchange_boundary_onesided (restricted_schwarz.cpp:715-852): put = pack into the neighbours'

@@ -39,6 +39,18 @@ def test_self_launch_reports_a_failing_rank():
     assert p.returncode != 0
 
 
+def test_self_launch_ends_the_other_ranks_when_one_dies_at_start_up():
+    """Rank 1 exits before the rendezvous: rank 0 would wait for it until the process-group timeout.  The
+    launcher watches every child, ends the survivors and reports the failing rank's code within seconds."""
+    import time
+    t0 = time.time()
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2"], capture_output=True, text=True, timeout=240,
+                       env=_clean_env(SCHWZ_BENCH_LAUNCH_PROBE="1", SCHWZ_BENCH_PROBE_FAIL_RANK="1"))
+    assert p.returncode == 3, p.stdout + p.stderr
+    assert time.time() - t0 < 120
+    assert "other ranks were stopped" in p.stderr
+
+
 @pytest.mark.gpu
 def test_bench_gpus_2_starts_itself_and_prints_one_line():
     """`python bench.py --gpus 2` exactly as the driver calls it.  On a box with fewer GPUs than

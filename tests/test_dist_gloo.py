@@ -187,6 +187,12 @@ def _free_worker(rank, world, port, case, out_dir):
         m = S.Metadata(**case["metadata"])
         solver = S.SolverRAS(s, m, comm=comm, backend=OracleBackend(), quiet=True)
         solver.initialize()
+        if case.get("reinit"):
+            # a second initialize() closes the windows of the first one (peers unmapped before the owners
+            # free, the shared-memory segment unlinked) and sets up new ones
+            first = comm._shm.name
+            solver.initialize()
+            assert comm._shm.name != first and not os.path.exists("/dev/shm/" + first.lstrip("/"))
         if case.get("slow_rank") == rank:
             # one rank runs at a third of the others' pace: nobody may wait for it inside the loop
             step = solver.step
@@ -201,13 +207,15 @@ def _free_worker(rank, world, port, case, out_dir):
                  converged=out["converged"], residual_norm=out["residual_norm"], rhs_norm=out["rhs_norm"],
                  solution=out["solution"] if rank == 0 else np.zeros(0), hist=hist,
                  local=np.array(m.post_process_data["local_residual_vector_out"]))
+        solver.close()
+        assert solver._win is None and comm._shm is None
     finally:
         comm.close_windows()
         dist.destroy_process_group()
 
 
 FREE_CASES = {
-    "put_tree": dict(world=3, put=True, protocol="tree"),
+    "put_tree": dict(world=3, put=True, protocol="tree", reinit=True),
     "get_tree": dict(world=4, put=False, protocol="tree"),
     "put_decentralized": dict(world=3, put=True, protocol="decentralized"),
     "get_decentralized_propagated_norms": dict(world=4, put=False, protocol="decentralized", put_all=False),

@@ -349,3 +349,47 @@ def test_bench_ras_early_exchange_is_bit_identical(tmp_path, flags):
             rows.append([ln.split(",")[:2] for ln in lines])  # iteration, local residual norm (not the timestamp)
         hist[early] = (iters, rows, re.search(r"relative residual norm of solution ([0-9.eE+-]+)", out).group(1))
     assert hist["1"] == hist["0"]
+
+
+@pytest.mark.parametrize("types", ["d32d", "d64d"])
+def test_mirror_public_data_members(types):
+    """The public data members of the reference's solver class (include/schwarz_base.hpp:137-197) on the
+    mirror, checked by every rank of a direct-solver run (tests/drivers/ras_types_driver.cpp "members"):
+    local_matrix / interface_matrix as host CSR, the factors with A(perm, perm) = L L^T and U = L^T,
+    local_perm / local_inv_perm inverse to each other, local_solution = the rank's piece of the solution,
+    the residual histories, global_matrix / global_rhs deliberately null."""
+    n, P = 20, 3
+    it, norm, out = _run_types(P, types, n, False, False, 1e-8, 300, extra=("members",))
+    rows = re.findall(r"MEMBERS rank=(\d+) local_n=(\d+) local_size_x=(\d+) local_nnz=(\d+) iface_nnz=(\d+) iface_ok=(\d) "
+                      r"factor_err=([0-9.eE+-]+) perm_ok=(\d) ut_ok=(\d) sol_err=([0-9.eE+-]+) global_null=(\d) "
+                      r"global_solution=(\d) hist=(\d+)/(\d+) rhs0=([0-9.eE+-]+)", out)
+    assert len(rows) == P, out
+    for r in rows:
+        rank, local_n, lsx, nnz, inz = (int(t) for t in r[:5])
+        assert local_n == lsx and nnz > 4 * local_n and inz > 0 and r[5] == "1"
+        assert float(r[6]) < 1e-12 and r[7] == "1" and r[8] == "1"
+        assert float(r[9]) < 1e-12 * max(norm, 1.0)
+        assert r[10] == "1" and int(r[11]) == (1 if rank == 0 else 0)
+        assert int(r[12]) >= it and int(r[13]) == P and float(r[14]) == 1.0
+
+
+def test_mirror_and_python_host_run_the_same_cg_launch_structure(schwz, torch_cuda):
+    """The two hosts over the one C ABI must drive the same kernels: schwz_ras_cg_flavour (stored q / q-free,
+    fused direction launch, deferred x, which launches walk) reported by the unchanged bench_ras on libschwz.so
+    and by the Python host for the same problem and settings -- at a size where the walk applies."""
+    import json
+    sys_path = os.path.join(ROOT, "schwarz-lib_amd")
+    flags = ["--matrix_filename=poisson3d:128", "--enable_global_check", "--set_tol=1e-30", "--num_iters=6",
+             "--local_precond=block-jacobi", "--precond_max_block_size=1", "--local_max_iters=10", "--local_tol=0"]
+    out = _run(1, *flags)
+    m = re.search(r"outer loop: (\d+) iterations in ([0-9.eE+-]+) s, cg flavour (\d+)", out)
+    assert m and int(m.group(1)) == 6, out
+    s = schwz.Settings(laplacian_dim=3, laplacian_shape=(128, 128, 128))
+    s.convergence_settings.enable_global_check = True
+    md = schwz.Metadata(tolerance=1e-30, max_iters=6, local_precond="block-jacobi", precond_max_block_size=1,
+                        local_solver_tolerance=0.0, local_max_iters=10, num_subdomains=1)
+    solver = schwz.SolverRAS(s, md, comm=schwz.InProcessComm(1), quiet=True)
+    solver.initialize()
+    solver.run(gather_solution=False)
+    flav = solver.subdomains[0].cg_flavour()
+    assert flav == int(m.group(3)) and flav != 0, (flav, m.group(3))

@@ -59,9 +59,12 @@ def _ragged_matrix(rng, n, max_len, long_row=None):
     return rp, col, val
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [0, 6, 7, 8, 9])
 @pytest.mark.parametrize("case", ["lap2d", "lap3d", "ragged", "longrow", "tiny"])
 def test_spmv_matches_oracle(schwz, oracle, torch_cuda, case, variant):
+    """Every SpMV variant of the product library (0 best coding, 6 plain CSR stream kernel, 7 dictionaries,
+    8 row patterns, 9 tiled kernel).  The measurement variants (1-5, 10-73, 80+) are not in libschwz_hip.so:
+    test_measurement_variants_are_not_in_the_product_library."""
     torch = torch_cuda
     rng = np.random.default_rng(7)
     if case == "lap2d":
@@ -86,6 +89,23 @@ def test_spmv_matches_oracle(schwz, oracle, torch_cuda, case, variant):
         got = d_y.cpu().numpy()
         scale = np.abs(exp).max() + 1e-300
         assert np.abs(got - exp).max() <= RTOL_SPMV * max(scale, 1.0) * 50
+
+
+@pytest.mark.gpu
+def test_measurement_variants_are_not_in_the_product_library(schwz, oracle, torch_cuda):
+    """tools/probes/spmv_variants.hip and the ablation builds of spmv_stream.hip are linked into
+    libschwz_hip_probes.so only; the product library refuses their variant ids and says where they live."""
+    torch = torch_cuda
+    if "probes" in os.path.basename(schwz.capi.LIB_PATH):
+        pytest.skip("running on the measurement build")
+    rp, col, val = oracle.laplacian2d(20)
+    A = schwz.Csr(rp, col, val)
+    x = _dev(torch, np.ones(400))
+    y = _dev(torch, np.zeros(400))
+    for variant in (1, 2, 3, 4, 5, 10, 80, 208):
+        with pytest.raises(schwz.SchwzError) as exc:
+            A.spmv(x.data_ptr(), y.data_ptr(), 1.0, 0.0, variant=variant)
+        assert "libschwz_hip_probes.so" in str(exc.value)
 
 
 @pytest.mark.gpu

@@ -316,3 +316,24 @@ def test_csr_upload_refuses_malformed_matrices(schwz):
     with pytest.raises(schwz.SchwzError) as e:
         schwz.Csr(np.array([0, 3, 2], dtype=np.int32), np.array([0, 1, 0], dtype=np.int32), np.ones(3))
     assert e.value.code == schwz.capi.ERR_INVALID
+
+
+def test_partial_problem_recovers_after_a_missing_row(schwz, oracle):
+    """A row source that holds part of the matrix (schwz_problem_from_rows): asking for a row it does not
+    hold fails with the row id, and the handle is usable afterwards -- the miss is not remembered."""
+    rp, col, val = oracle.laplacian2d(12)
+    full = schwz.Problem.from_csr(rp, col, val)
+    held = np.arange(30, 90, dtype=np.int64)
+    part = schwz.Problem.from_rows(full.N, held, *full.extract_rows(held))
+    with pytest.raises(schwz.SchwzError) as exc:
+        part.extract_rows(np.array([40, 5], dtype=np.int64))
+    assert "row 5" in str(exc.value)
+    got = part.extract_rows(np.array([40, 41], dtype=np.int64))
+    exp = full.extract_rows(np.array([40, 41], dtype=np.int64))
+    for a, b in zip(got, exp):
+        assert np.array_equal(a, b)
+    # a subdomain that reads rows outside the part fails, one inside it still builds afterwards
+    with pytest.raises(schwz.SchwzError):
+        schwz.Subdomain(part, 2, 0, 2, schwz.partition_regular(full.N, 2))
+    got = part.extract_rows(held[:3])
+    assert np.array_equal(got[0], full.extract_rows(held[:3])[0])

@@ -3,6 +3,8 @@
 ablation builds (variants 80 + bits, spmv_stream.hip) on the shapes a GPU holds in the BASELINE configurations."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the measurement variants live in the measurement build of the library (make -C schwarz-lib_amd probes)
+os.environ.setdefault("SCHWZ_HIP_LIB", os.path.join(ROOT, "schwarz-lib_amd", "lib", "libschwz_hip_probes.so"))
 sys.path.insert(0, os.path.join(ROOT, "schwarz-lib_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch

@@ -11,6 +11,8 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the measurement variants live in the measurement build of the library (make -C schwarz-lib_amd probes)
+os.environ.setdefault("SCHWZ_HIP_LIB", os.path.join(ROOT, "schwarz-lib_amd", "lib", "libschwz_hip_probes.so"))
 sys.path.insert(0, os.path.join(ROOT, "schwarz-lib_amd"))
 
 
