@@ -264,8 +264,12 @@ int schwz_partition_regular(int64_t N, int P, int64_t *h_first_row);
 /* PartitionTools::PartitionRegular2D (include/partition_tools.hpp:70-106) */
 int schwz_partition_regular2d(int64_t n1d, int P, uint32_t *h_part);
 /* graph partition standing in for PartitionTools::PartitionMetis
- * (include/partition_tools.hpp:110-202; METIS itself is absent): recursive
- * BFS-level bisection of the matrix graph. */
+ * (include/partition_tools.hpp:110-202; METIS itself is absent): multilevel
+ * recursive bisection of the (symmetrised) matrix graph -- heavy-edge
+ * coarsening, greedy growing on the coarsest graph, Fiduccia-Mattheyses
+ * refinement on every level -- to part sizes that differ by at most one row.
+ * Deterministic.  SCHWZ_PART_MULTILEVEL=0: the single-level bisection of
+ * rounds 1-2. */
 int schwz_partition_graph(const schwz_problem *p, int P, uint32_t *h_part);
 
 /* Subdomain: index sets, local/interface matrices, comm lists, device state.

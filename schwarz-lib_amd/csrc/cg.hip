@@ -708,6 +708,7 @@ static int pcg_build(schwz_pcg *s, const schwz_csr *A, int precond)
 
 int schwz_pcg_create_ex(const schwz_csr *A, int precond, int block_size, schwz_pcg **out)
 {
+    StageTimer timer_all("pcg_create (diagonal, preconditioner data, vectors)");
     SCHWZ_REQUIRE(A && out, "schwz_pcg_create: null argument");
     SCHWZ_REQUIRE(A->v.nrows == A->v.ncols, "schwz_pcg_create: matrix not square");
     SCHWZ_REQUIRE(precond >= SCHWZ_PRECOND_NONE && precond <= SCHWZ_PRECOND_ISAI,

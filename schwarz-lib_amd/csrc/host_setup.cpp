@@ -6,7 +6,10 @@
 // (SURVEY F7): the global matrix is a row source (explicit CSR or an analytic
 // stencil), interior ids are an arithmetic range and only overlap / halo ids
 // go through a hash map.
+#include <omp.h>
+
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -91,7 +94,9 @@ int schwz_problem::row(int64_t g, int64_t *cols, double *vals) const
     } else if (kind == 1) {
         const auto it = std::lower_bound(present.begin(), present.end(), g);
         if (it == present.end() || *it != g) {
-            if (missing_row < 0) missing_row = g;
+            // (rows are read by several threads during setup: the first miss wins, without a race)
+            int64_t none = -1;
+            __atomic_compare_exchange_n(&missing_row, &none, g, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
             return 0;
         }
         const int64_t k = it - present.begin();
@@ -610,9 +615,360 @@ static void bisect(const schwz_problem *p, std::vector<int64_t> &nodes, int part
     bisect(p, right, parts - left_parts, base + (uint32_t)left_parts, part, mark, stamp);
 }
 
+
+// ---------------------------------------------------------------------------
+// Multilevel recursive bisection (the scheme of METIS_PartGraphRecursive, which PartitionTools::PartitionMetis
+// would call through METIS, include/partition_tools.hpp:110-202; METIS itself is absent):
+//   coarsening by heavy-edge matching until ~100 vertices are left, greedy graph growing from several seeds on
+//   the coarsest graph, and Fiduccia-Mattheyses boundary refinement at every level on the way back up --
+//   weighted while vertices stand for several rows (balance within the heaviest vertex), then on the rows
+//   themselves to EXACT part sizes (single moves towards the target, then moves in pairs).
+// Deterministic: no random numbers, ties broken by vertex number.  SCHWZ_PART_MULTILEVEL=0 keeps the
+// single-level bisection above.
+// ---------------------------------------------------------------------------
+namespace {
+
+struct MlGraph {
+    int n = 0;
+    std::vector<int64_t> xadj;   // n + 1
+    std::vector<int> adj, ew;    // neighbours and edge weights (symmetric)
+    std::vector<int> vw;         // vertex weights
+    int64_t total_vw() const
+    {
+        int64_t t = 0;
+        for (int w : vw) t += w;
+        return t;
+    }
+};
+
+// side[v] in {0, 1}.  Fiduccia-Mattheyses passes: every vertex moves at most once per pass, always the best-gain
+// move that keeps |w0 - target0| within `slack` (from the heavy side while it is outside), and the pass keeps the
+// best prefix of its move sequence -- first by how far the balance is outside the slack, then by the cut.
+// slack 0 with unit weights: exact sizes.
+static void ml_refine(const MlGraph &g, std::vector<char> &side, int64_t target0, int64_t slack, int passes)
+{
+    const int n = g.n;
+    std::vector<int> gain((size_t)n);
+    std::vector<char> locked((size_t)n);
+    auto excess = [&](int64_t w0) { return std::max<int64_t>(0, (int64_t)std::llabs(w0 - target0) - slack); };
+    for (int pass = 0; pass < passes; ++pass) {
+        int64_t w0 = 0;
+        std::set<std::pair<int, int>> q[2];  // (-gain, vertex) per side
+        for (int v = 0; v < n; ++v) {
+            int gsum = 0;
+            for (int64_t j = g.xadj[(size_t)v]; j < g.xadj[(size_t)v + 1]; ++j)
+                gsum += side[(size_t)g.adj[(size_t)j]] != side[(size_t)v] ? g.ew[(size_t)j] : -g.ew[(size_t)j];
+            gain[(size_t)v] = gsum;
+            locked[(size_t)v] = 0;
+            q[(int)side[(size_t)v]].insert({-gsum, v});
+            if (!side[(size_t)v]) w0 += g.vw[(size_t)v];
+        }
+        std::vector<int> moved;
+        int64_t delta = 0, best_delta = 0, best_excess = excess(w0);
+        size_t best_len = 0;
+        int stale = 0;
+        const int patience = std::max(50, std::min(n / 20, 5000));
+        while (stale < patience) {
+            int from = -1;
+            const int64_t imb = w0 - target0;
+            auto stays_inside = [&](int f) {
+                if (q[f].empty()) return false;
+                const int v = q[f].begin()->second;
+                const int64_t nw0 = w0 + (f == 0 ? -(int64_t)g.vw[(size_t)v] : (int64_t)g.vw[(size_t)v]);
+                return (int64_t)std::llabs(nw0 - target0) <= slack;
+            };
+            if (imb > slack) {
+                from = q[0].empty() ? -1 : 0;
+            } else if (imb < -slack) {
+                from = q[1].empty() ? -1 : 1;
+            } else {
+                const bool f0 = stays_inside(0), f1 = stays_inside(1);
+                if (f0 && f1)
+                    from = q[0].begin()->first <= q[1].begin()->first ? 0 : 1;
+                else if (f0)
+                    from = 0;
+                else if (f1)
+                    from = 1;
+                else if (slack == 0 && !q[0].empty() && !q[1].empty())
+                    from = imb >= 0 ? 0 : 1;  // exact balance: a move out and, next, the best move back (a pair)
+            }
+            if (from < 0) break;
+            const auto it = q[from].begin();
+            const int v = it->second;
+            q[from].erase(it);
+            locked[(size_t)v] = 1;
+            delta -= gain[(size_t)v];
+            side[(size_t)v] = (char)(1 - from);
+            w0 += from == 0 ? -(int64_t)g.vw[(size_t)v] : (int64_t)g.vw[(size_t)v];
+            moved.push_back(v);
+            for (int64_t j = g.xadj[(size_t)v]; j < g.xadj[(size_t)v + 1]; ++j) {
+                const int w = g.adj[(size_t)j];
+                if (locked[(size_t)w]) continue;
+                const int sw = side[(size_t)w];
+                q[sw].erase({-gain[(size_t)w], w});
+                gain[(size_t)w] += (sw == from ? 2 : -2) * g.ew[(size_t)j];
+                q[sw].insert({-gain[(size_t)w], w});
+            }
+            const int64_t ex = excess(w0);
+            if (ex < best_excess || (ex == best_excess && delta < best_delta)) {
+                best_excess = ex;
+                best_delta = delta;
+                best_len = moved.size();
+                stale = 0;
+            } else {
+                ++stale;
+            }
+        }
+        for (size_t i = moved.size(); i > best_len; --i) {
+            const int v = moved[i - 1];
+            side[(size_t)v] = (char)(1 - side[(size_t)v]);
+        }
+        if (best_len == 0) break;
+    }
+}
+
+// heavy-edge matching: cmap[v] = coarse vertex; returns the coarse graph
+static MlGraph ml_coarsen(const MlGraph &g, std::vector<int> &cmap)
+{
+    const int n = g.n;
+    cmap.assign((size_t)n, -1);
+    // light vertices first (keeps the coarse vertex weights even), ties by number
+    std::vector<int> order((size_t)n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return g.vw[(size_t)a] < g.vw[(size_t)b]; });
+    int nc = 0;
+    for (int v : order) {
+        if (cmap[(size_t)v] >= 0) continue;
+        int best = -1, best_w = -1;
+        for (int64_t j = g.xadj[(size_t)v]; j < g.xadj[(size_t)v + 1]; ++j) {
+            const int w = g.adj[(size_t)j];
+            if (cmap[(size_t)w] < 0 && w != v && g.ew[(size_t)j] > best_w) {
+                best_w = g.ew[(size_t)j];
+                best = w;
+            }
+        }
+        cmap[(size_t)v] = nc;
+        if (best >= 0) cmap[(size_t)best] = nc;
+        ++nc;
+    }
+    MlGraph c;
+    c.n = nc;
+    c.vw.assign((size_t)nc, 0);
+    for (int v = 0; v < n; ++v) c.vw[(size_t)cmap[(size_t)v]] += g.vw[(size_t)v];
+    // members of every coarse vertex, then its merged adjacency
+    std::vector<int> first((size_t)nc, -1), second((size_t)nc, -1);
+    for (int v = 0; v < n; ++v) {
+        const int cv = cmap[(size_t)v];
+        if (first[(size_t)cv] < 0)
+            first[(size_t)cv] = v;
+        else
+            second[(size_t)cv] = v;
+    }
+    c.xadj.assign((size_t)nc + 1, 0);
+    std::vector<int> slot((size_t)nc, -1);
+    for (int cv = 0; cv < nc; ++cv) {
+        const int64_t start = (int64_t)c.adj.size();
+        for (int v : {first[(size_t)cv], second[(size_t)cv]}) {
+            if (v < 0) continue;
+            for (int64_t j = g.xadj[(size_t)v]; j < g.xadj[(size_t)v + 1]; ++j) {
+                const int cw = cmap[(size_t)g.adj[(size_t)j]];
+                if (cw == cv) continue;
+                if (slot[(size_t)cw] < start) {
+                    slot[(size_t)cw] = (int)c.adj.size();
+                    c.adj.push_back(cw);
+                    c.ew.push_back(g.ew[(size_t)j]);
+                } else {
+                    c.ew[(size_t)slot[(size_t)cw]] += g.ew[(size_t)j];
+                }
+            }
+        }
+        c.xadj[(size_t)cv + 1] = (int64_t)c.adj.size();
+    }
+    return c;
+}
+
+// greedy graph growing on the coarsest graph: side 0 grows from a seed by the vertex with the largest gain until
+// it holds target0; several seeds, the smallest cut wins
+static void ml_initial(const MlGraph &g, std::vector<char> &side, int64_t target0)
+{
+    const int n = g.n;
+    int64_t best_cut = -1;
+    std::vector<char> best;
+    const int tries = std::min(n, 12);
+    for (int t = 0; t < tries; ++t) {
+        const int seed = (int)((int64_t)t * n / tries);
+        std::vector<char> s((size_t)n, 1);
+        std::vector<int> conn((size_t)n, 0);  // edge weight towards side 0
+        std::vector<char> in0((size_t)n, 0);
+        int64_t w0 = 0;
+        int next = seed;
+        while (next >= 0 && w0 < target0) {
+            s[(size_t)next] = 0;
+            in0[(size_t)next] = 1;
+            w0 += g.vw[(size_t)next];
+            for (int64_t j = g.xadj[(size_t)next]; j < g.xadj[(size_t)next + 1]; ++j) conn[(size_t)g.adj[(size_t)j]] += g.ew[(size_t)j];
+            // the frontier vertex most tied to side 0 (ties: fewest ties to side 1, then number); none: any vertex left
+            int pick = -1;
+            int64_t pick_score = INT64_MIN;
+            for (int v = 0; v < n; ++v) {
+                if (in0[(size_t)v]) continue;
+                if (conn[(size_t)v] == 0 && pick >= 0) continue;
+                int64_t deg = 0;
+                for (int64_t j = g.xadj[(size_t)v]; j < g.xadj[(size_t)v + 1]; ++j) deg += g.ew[(size_t)j];
+                const int64_t score = conn[(size_t)v] > 0 ? (int64_t)2 * conn[(size_t)v] - deg + ((int64_t)1 << 40) : -deg;
+                if (score > pick_score) {
+                    pick_score = score;
+                    pick = v;
+                }
+            }
+            next = pick;
+        }
+        ml_refine(g, s, target0, *std::max_element(g.vw.begin(), g.vw.end()), 4);
+        int64_t cut = 0;
+        for (int v = 0; v < n; ++v)
+            for (int64_t j = g.xadj[(size_t)v]; j < g.xadj[(size_t)v + 1]; ++j)
+                if (s[(size_t)v] != s[(size_t)g.adj[(size_t)j]]) cut += g.ew[(size_t)j];
+        if (best_cut < 0 || cut < best_cut) {
+            best_cut = cut;
+            best = s;
+        }
+    }
+    side = best;
+}
+
+// bisection of g into weights (target0, rest): multilevel V-cycle
+static void ml_bisect(const MlGraph &g, std::vector<char> &side, int64_t target0)
+{
+    std::vector<MlGraph> levels;
+    std::vector<std::vector<int>> maps;
+    const MlGraph *cur = &g;
+    while (cur->n > 120) {
+        std::vector<int> cmap;
+        MlGraph c = ml_coarsen(*cur, cmap);
+        if (c.n > cur->n * 0.93) break;  // matching no longer shrinks the graph
+        maps.push_back(std::move(cmap));
+        levels.push_back(std::move(c));
+        cur = &levels.back();
+    }
+    std::vector<char> s;
+    ml_initial(*cur, s, target0);
+    for (int l = (int)levels.size() - 1; l >= 0; --l) {
+        const MlGraph &fine = l == 0 ? g : levels[(size_t)l - 1];
+        std::vector<char> sf((size_t)fine.n);
+        for (int v = 0; v < fine.n; ++v) sf[(size_t)v] = s[(size_t)maps[(size_t)l][(size_t)v]];
+        const int64_t slack = l == 0 ? 0 : *std::max_element(fine.vw.begin(), fine.vw.end());
+        ml_refine(fine, sf, target0, slack, l == 0 ? 10 : 6);
+        s.swap(sf);
+    }
+    if (levels.empty()) ml_refine(g, s, target0, 0, 10);
+    side = s;
+}
+
+static void ml_recurse(const MlGraph &g, const std::vector<int64_t> &ids, int parts, uint32_t base, uint32_t *part)
+{
+    if (g.n == 0) return;
+    if (parts == 1) {
+        for (int64_t id : ids) part[id] = base;
+        return;
+    }
+    const int left_parts = parts / 2;
+    const int64_t target0 = (int64_t)((double)g.n * left_parts / parts + 0.5);
+    std::vector<char> side;
+    ml_bisect(g, side, target0);
+    // exact sizes: whatever the refinement left over is moved by gain order (unit weights on this level)
+    {
+        int64_t w0 = 0;
+        for (int v = 0; v < g.n; ++v) w0 += !side[(size_t)v];
+        while (w0 != target0) {
+            const int from = w0 > target0 ? 0 : 1;
+            int pick = -1, pick_gain = INT_MIN;
+            for (int v = 0; v < g.n; ++v) {
+                if (side[(size_t)v] != from) continue;
+                int gsum = 0;
+                for (int64_t j = g.xadj[(size_t)v]; j < g.xadj[(size_t)v + 1]; ++j)
+                    gsum += side[(size_t)g.adj[(size_t)j]] != from ? g.ew[(size_t)j] : -g.ew[(size_t)j];
+                if (gsum > pick_gain) {
+                    pick_gain = gsum;
+                    pick = v;
+                }
+            }
+            if (pick < 0) break;
+            side[(size_t)pick] = (char)(1 - from);
+            w0 += from == 0 ? -1 : 1;
+        }
+    }
+    // the two induced subgraphs
+    for (int sd = 0; sd < 2; ++sd) {
+        std::vector<int> loc((size_t)g.n, -1);
+        MlGraph sub;
+        std::vector<int64_t> sub_ids;
+        for (int v = 0; v < g.n; ++v)
+            if (side[(size_t)v] == sd) {
+                loc[(size_t)v] = sub.n++;
+                sub_ids.push_back(ids[(size_t)v]);
+            }
+        sub.vw.assign((size_t)sub.n, 1);
+        sub.xadj.assign((size_t)sub.n + 1, 0);
+        for (int v = 0; v < g.n; ++v) {
+            if (side[(size_t)v] != sd) continue;
+            for (int64_t j = g.xadj[(size_t)v]; j < g.xadj[(size_t)v + 1]; ++j) {
+                const int w = loc[(size_t)g.adj[(size_t)j]];
+                if (w >= 0) {
+                    sub.adj.push_back(w);
+                    sub.ew.push_back(g.ew[(size_t)j]);
+                }
+            }
+            sub.xadj[(size_t)loc[(size_t)v] + 1] = (int64_t)sub.adj.size();
+        }
+        ml_recurse(sub, sub_ids, sd == 0 ? left_parts : parts - left_parts, sd == 0 ? base : base + (uint32_t)left_parts, part);
+    }
+}
+
+}  // namespace
+
 int schwz_partition_graph(const schwz_problem *p, int P, uint32_t *part)
 {
     SCHWZ_REQUIRE(p && part && P > 0, "schwz_partition_graph: bad arguments");
+    static const bool multilevel = [] {
+        const char *e = std::getenv("SCHWZ_PART_MULTILEVEL");
+        return !(e && e[0] == '0');
+    }();
+    if (multilevel && p->N > 0 && p->N < INT32_MAX / 2) {
+        // the matrix graph, symmetrised (an entry in either triangle is an edge), without the diagonal
+        const int64_t N = p->N;
+        std::vector<std::pair<int, int>> edges;
+        {
+            std::vector<int64_t> c((size_t)p->max_row_nnz + 1);
+            std::vector<double> v((size_t)p->max_row_nnz + 1);
+            for (int64_t u = 0; u < N; ++u) {
+                const int len = p->row(u, c.data(), v.data());
+                for (int k = 0; k < len; ++k)
+                    if (c[k] != u) {
+                        edges.push_back({(int)u, (int)c[k]});
+                        edges.push_back({(int)c[k], (int)u});
+                    }
+            }
+        }
+        std::sort(edges.begin(), edges.end());
+        edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
+        MlGraph g;
+        g.n = (int)N;
+        g.vw.assign((size_t)N, 1);
+        g.xadj.assign((size_t)N + 1, 0);
+        g.adj.resize(edges.size());
+        g.ew.assign(edges.size(), 1);
+        for (size_t e = 0; e < edges.size(); ++e) {
+            g.adj[e] = edges[e].second;
+            ++g.xadj[(size_t)edges[e].first + 1];
+        }
+        for (int64_t u = 0; u < N; ++u) g.xadj[(size_t)u + 1] += g.xadj[(size_t)u];
+        edges.clear();
+        edges.shrink_to_fit();
+        std::vector<int64_t> ids((size_t)N);
+        std::iota(ids.begin(), ids.end(), 0);
+        ml_recurse(g, ids, P, 0, part);
+        return SCHWZ_OK;
+    }
     std::vector<int64_t> nodes((size_t)p->N);
     std::iota(nodes.begin(), nodes.end(), 0);
     std::vector<int32_t> mark((size_t)p->N, 0);
@@ -632,6 +988,7 @@ int schwz_subdomain_setup(const schwz_problem *p, int P, int me, int overlap, co
     SCHWZ_REQUIRE(P > 0 && me >= 0 && me < P, "schwz_subdomain_setup: bad rank / subdomain count");
     SCHWZ_REQUIRE(overlap >= 1, "schwz_subdomain_setup: overlap must be >= 1");
     SCHWZ_REQUIRE(first_row[0] == 0 && first_row[P] == p->N, "schwz_subdomain_setup: first_row must cover all rows");
+    StageTimer timer_all("subdomain_setup (index sets, local / interface matrices, get lists)");
     p->missing_row = -1;  // see schwz_problem_extract_rows
     auto *sd = new schwz_subdomain();
     sd->P = P;
@@ -653,22 +1010,47 @@ int schwz_subdomain_setup(const schwz_problem *p, int P, int me, int overlap, co
     // interior ids are implicit; l2g stores them anyway for the callers
     l2g.resize((size_t)sd->local_size);
     std::iota(l2g.begin(), l2g.end(), lo);
-    auto mapped = [&](int64_t g) { return (g >= lo && g < hi) || sd->g2l_x.count(g) != 0; };
-    // overlap-1 BFS layers in discovery order (:166-180)
+    // overlap-1 BFS layers in discovery order (:166-180).  The candidates of a layer -- columns outside the
+    // interior range -- are collected by all threads over contiguous blocks of the layer's rows and visited block
+    // after block, i.e. in row order then column order like the sequential loop: the same discovery order.
+    StageTimer t_bfs("  setup: overlap layers");
     int64_t old = 0;
-    for (int k = 1; k < overlap; ++k) {
-        const int64_t now = (int64_t)l2g.size();
-        for (int64_t i = old; i < now; ++i) {
-            const int len = p->row(l2g[(size_t)i], c.data(), v.data());
-            for (int j = 0; j < len; ++j) {
-                if (!mapped(c[j])) {
-                    sd->g2l_x.emplace(c[j], (schwz_idx)l2g.size());
-                    l2g.push_back(c[j]);
-                }
+    auto grow_layer = [&](int64_t from, int64_t to) {
+        int nthreads = 1;
+#pragma omp parallel
+        {
+#pragma omp single
+            nthreads = omp_get_num_threads();
+        }
+        if (to - from < 4096) nthreads = 1;
+        std::vector<std::vector<int64_t>> cand((size_t)nthreads);
+#pragma omp parallel num_threads(nthreads)
+        {
+            const int t = omp_get_thread_num();
+            const int64_t a = from + (to - from) * t / nthreads, b = from + (to - from) * (t + 1) / nthreads;
+            std::vector<int64_t> cc((size_t)mr);
+            std::vector<double> vv((size_t)mr);
+            auto &mine = cand[(size_t)t];
+            for (int64_t i = a; i < b; ++i) {
+                const int len = p->row(l2g[(size_t)i], cc.data(), vv.data());
+                for (int j = 0; j < len; ++j)
+                    if (cc[j] < lo || cc[j] >= hi) mine.push_back(cc[j]);
             }
         }
+        for (const auto &lst : cand)
+            for (int64_t g : lst)
+                if (sd->g2l_x.count(g) == 0) {
+                    sd->g2l_x.emplace(g, (schwz_idx)l2g.size());
+                    l2g.push_back(g);
+                }
+    };
+    for (int k = 1; k < overlap; ++k) {
+        const int64_t now = (int64_t)l2g.size();
+        grow_layer(old, now);
         old = now;
     }
+    t_bfs.stop();
+    StageTimer t_cnt("  setup: row counts");
     sd->local_size_x = (int64_t)l2g.size();
     sd->overlap_size = sd->local_size_x - sd->local_size;
     const int64_t n = sd->local_size_x;
@@ -681,20 +1063,28 @@ int schwz_subdomain_setup(const schwz_problem *p, int P, int me, int overlap, co
     std::vector<schwz_idx> lc((size_t)mr);
     std::vector<double> lv((size_t)mr);
     int64_t nnz_l = 0;
-    for (int64_t r = 0; r < n; ++r) {
-        const int len = p->row(l2g[(size_t)r], c.data(), v.data());
-        for (int j = 0; j < len; ++j) {
-            const schwz_idx loc = sd->to_local(c[j]);
-            if (loc >= 0)
-                ++nnz_l;
+    {
+        // entries per row (all threads), then the running sum
+        std::vector<int> cnt((size_t)n, 0);
+#pragma omp parallel for schedule(static) firstprivate(c, v)
+        for (int64_t r = 0; r < n; ++r) {
+            const int len = p->row(l2g[(size_t)r], c.data(), v.data());
+            int k = 0;
+            for (int j = 0; j < len; ++j) k += sd->to_local(c[j]) >= 0;
+            cnt[(size_t)r] = k;
         }
-        if (nnz_l >= INT32_MAX) {
-            delete sd;
-            set_error("schwz_subdomain_setup: local matrix exceeds 2^31-1 nonzeros");
-            return SCHWZ_ERR_INVALID;
+        for (int64_t r = 0; r < n; ++r) {
+            nnz_l += cnt[(size_t)r];
+            if (nnz_l >= INT32_MAX) {
+                delete sd;
+                set_error("schwz_subdomain_setup: local matrix exceeds 2^31-1 nonzeros");
+                return SCHWZ_ERR_INVALID;
+            }
+            sd->l_rp[(size_t)r + 1] = (schwz_idx)nnz_l;
         }
-        sd->l_rp[(size_t)r + 1] = (schwz_idx)nnz_l;
     }
+    t_cnt.stop();
+    StageTimer t_fill("  setup: local matrix fill");
     sd->l_col.resize((size_t)nnz_l);
     sd->l_val.resize((size_t)nnz_l);
 #pragma omp parallel for schedule(static) firstprivate(c, v)
@@ -724,6 +1114,8 @@ int schwz_subdomain_setup(const schwz_problem *p, int P, int me, int overlap, co
             sd->l_val[(size_t)b] = vv;
         }
     }
+    t_fill.stop();
+    StageTimer t_rest("  setup: interface rows, halo, get lists");
     // interface entries: overlap rows only, GLOBAL columns, ascending (:262-284,298)
     for (int64_t r = sd->local_size; r < n; ++r) {
         const int len = p->row(l2g[(size_t)r], c.data(), v.data());
@@ -741,18 +1133,7 @@ int schwz_subdomain_setup(const schwz_problem *p, int P, int me, int overlap, co
     }
     for (int64_t r = 0; r < sd->local_size; ++r) sd->i_rp[(size_t)r + 1] = 0;
     // halo marking: one more BFS step from the last layer (:285-295)
-    {
-        const int64_t now = (int64_t)l2g.size();
-        for (int64_t i = old; i < now; ++i) {
-            const int len = p->row(l2g[(size_t)i], c.data(), v.data());
-            for (int j = 0; j < len; ++j) {
-                if (!mapped(c[j])) {
-                    sd->g2l_x.emplace(c[j], (schwz_idx)l2g.size());
-                    l2g.push_back(c[j]);
-                }
-            }
-        }
-    }
+    grow_layer(old, (int64_t)l2g.size());
     sd->halo_size = (int64_t)l2g.size() - sd->local_size_x;
 
     // get lists (:336-371): every mapped id owned by p, ascending.  Only the

@@ -344,10 +344,14 @@ int schwz_csr_create(int64_t nrows, int64_t ncols, const schwz_idx *h_rp, const 
     SCHWZ_REQUIRE(h_rp[0] == 0 && nnz >= 0, "schwz_csr_create: malformed row_ptr");
     SCHWZ_REQUIRE(nnz == 0 || (h_col && h_val), "schwz_csr_create: null column / value array");
     // the kernels index x with these columns without a bounds test: refuse a malformed matrix here
+    StageTimer timer_all("csr_create total");
+    StageTimer timer_chk("csr_create: well-formed check");
     SCHWZ_REQUIRE(csr_is_well_formed(nrows, ncols, h_rp, h_col),
                   "schwz_csr_create: row_ptr not monotone or column index out of range");
     // row tiles: consecutive rows, <= kTileRows rows and <= kTileNnz nonzeros; a
     // row longer than kTileNnz forms a tile of its own.
+    timer_chk.stop();
+    StageTimer timer_tiles("csr_create: tiles, orders, column check");
     std::vector<schwz_idx> tiles;
     tiles.reserve((size_t)(nrows / 128 + 2));
     tiles.push_back(0);
@@ -520,6 +524,8 @@ int schwz_csr_create(int64_t nrows, int64_t ncols, const schwz_idx *h_rp, const 
         else if (stream_cap && longest > 16) stream_cap = 32;
         else if (stream_cap && longest > 8) stream_cap = 16;
     }
+    timer_tiles.stop();
+    StageTimer timer_up("csr_create: upload of rp / col / val");
     schwz_csr *A = new schwz_csr();
     int rc;
     if ((rc = upload(tile_nz.data(), tile_nz.size(), &A->d_tile_nz)) ||
@@ -530,6 +536,7 @@ int schwz_csr_create(int64_t nrows, int64_t ncols, const schwz_idx *h_rp, const 
         schwz_csr_destroy(A);
         return rc;
     }
+    timer_up.stop();
     A->v.nrows = nrows;
     A->v.ncols = ncols;
     A->v.nnz = nnz;
@@ -582,6 +589,7 @@ int schwz_csr_create(int64_t nrows, int64_t ncols, const schwz_idx *h_rp, const 
     }
     A->v.nwtiles = (int)wtiles.size() - 1;
     A->v.wtile_row = (const schwz_idx *)A->d_wtile;
+    StageTimer timer_code("csr_create: matrix codings (patterns, pairs, walk tables)");
     if ((rc = build_spmv_dict(A, h_rp, h_col, h_val, tiles))) {
         schwz_csr_destroy(A);
         return rc;

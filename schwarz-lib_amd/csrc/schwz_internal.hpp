@@ -4,15 +4,94 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <sched.h>
+
+#include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <memory>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
 #include "schwz_hip.h"
 
 namespace schwz {
+
+// std::allocator whose construct() default-initialises: resize() of a vector of arithmetic type leaves the new
+// elements unwritten instead of zero-filling them on one thread.
+template <typename T>
+struct NoInitAlloc : std::allocator<T> {
+    template <typename U>
+    struct rebind {
+        using other = NoInitAlloc<U>;
+    };
+    NoInitAlloc() = default;
+    template <typename U>
+    NoInitAlloc(const NoInitAlloc<U> &) {}
+    template <typename U>
+    void construct(U *p) { ::new ((void *)p) U; }
+    template <typename U, typename... Args>
+    void construct(U *p, Args &&...args) { ::new ((void *)p) U(std::forward<Args>(args)...); }
+};
+
+// Host-side setup loops of the .hip translation units (hipcc builds them without an OpenMP runtime): fn(t, nt,
+// begin, end) on nt threads over contiguous blocks of [0, n), thread t taking the t-th block.  nt = the
+// hardware threads available to the process, at most 32 (SCHWZ_SETUP_THREADS overrides), 1 below min_per_thread
+// items per thread.  Returns nt.
+template <typename F>
+inline int parallel_blocks(int64_t n, int64_t min_per_thread, F fn)
+{
+    static const int cap = [] {
+        const char *e = std::getenv("SCHWZ_SETUP_THREADS");
+        int v = e ? std::atoi(e) : 0;
+        if (v <= 0) {
+            cpu_set_t set;
+            v = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
+        }
+        return v < 1 ? 1 : (v > 32 ? 32 : v);
+    }();
+    int nt = (int)std::min<int64_t>(cap, n / std::max<int64_t>(min_per_thread, 1));
+    if (nt < 1) nt = 1;
+    if (nt == 1) {
+        fn(0, 1, (int64_t)0, n);
+        return 1;
+    }
+    std::vector<std::thread> th;
+    th.reserve((size_t)nt - 1);
+    for (int t = 1; t < nt; ++t) th.emplace_back([=, &fn] { fn(t, nt, n * t / nt, n * (t + 1) / nt); });
+    fn(0, nt, (int64_t)0, n / nt);
+    for (auto &x : th) x.join();
+    return nt;
+}
+
+// SCHWZ_SETUP_TIMING=1: wall time of the setup stages on stderr ("[schwz setup] <stage>: <ms> ms"), what
+// tools/setup_probe.py reads.  Zero cost when off.
+struct StageTimer {
+    const char *name;
+    std::chrono::steady_clock::time_point t0;
+    bool on;
+    explicit StageTimer(const char *n) : name(n), on(false)
+    {
+        static const bool enabled = [] {
+            const char *e = std::getenv("SCHWZ_SETUP_TIMING");
+            return e && e[0] == '1';
+        }();
+        on = enabled;
+        if (on) t0 = std::chrono::steady_clock::now();
+    }
+    void stop()
+    {
+        if (!on) return;
+        on = false;
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        std::fprintf(stderr, "[schwz setup] %s: %.1f ms\n", name, ms);
+    }
+    ~StageTimer() { stop(); }
+};
 
 void set_error(const std::string &msg);
 
@@ -429,8 +508,11 @@ struct schwz_subdomain {
     int64_t local_size = 0, local_size_x = 0, overlap_size = 0, halo_size = 0;
     std::vector<int64_t> l2g;                      // local_size_x + halo
     std::unordered_map<int64_t, schwz_idx> g2l_x;  // non-interior global -> local
-    std::vector<schwz_idx> l_rp, l_col;
-    std::vector<double> l_val;
+    // (col / val: no value-initialisation on resize -- every entry is written by the threads that fill the matrix,
+    // which also places the pages near them)
+    std::vector<schwz_idx> l_rp;
+    std::vector<schwz_idx, schwz::NoInitAlloc<schwz_idx>> l_col;
+    std::vector<double, schwz::NoInitAlloc<double>> l_val;
     std::vector<schwz_idx> i_rp;       // interface rows (local_size_x+1)
     std::vector<int64_t> i_col_global;
     std::vector<double> i_val;

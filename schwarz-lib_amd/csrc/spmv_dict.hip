@@ -546,65 +546,76 @@ static int build_spmv_pattern(schwz_csr *A, const schwz_idx *rp, const schwz_idx
     std::vector<schwz_idx> tile_table((size_t)ntiles, -1);
     std::vector<Table> tables;
     std::unordered_multimap<uint64_t, int> by_hash;
-    std::vector<RowPat> pats;
     int64_t coded = 0;
-    for (int t = 0; t < ntiles; ++t) {
-        const schwz_idx r0 = tiles[(size_t)t], r1 = tiles[(size_t)t + 1];
-        if (rp[r1] == rp[r0] || (r1 - r0 == 1 && rp[r1] - rp[r0] > kTileNnz - 2)) continue;
-        pats.clear();
-        int lmax = 0;
-        bool ok = true;
-        for (schwz_idx r = r0; r < r1 && ok; ++r) {
+    // every tile's table by all threads (a tile's rows, ids and table depend on that tile alone), then the tables
+    // are de-duplicated in tile order -- the ids a sequential pass would give
+    std::vector<Table> tile_tb((size_t)ntiles);
+    std::vector<char> tile_ok((size_t)ntiles, 0);
+    parallel_blocks(ntiles, 256, [&](int, int, int64_t t_begin, int64_t t_end) {
+        std::vector<RowPat> pats;
+        for (int t = (int)t_begin; t < (int)t_end; ++t) {
+            const schwz_idx r0 = tiles[(size_t)t], r1 = tiles[(size_t)t + 1];
+            if (rp[r1] == rp[r0] || (r1 - r0 == 1 && rp[r1] - rp[r0] > kTileNnz - 2)) continue;
+            pats.clear();
+            int lmax = 0;
+            bool ok = true;
             RowPat p;
-            const int len = rp[r + 1] - rp[r];
-            if (len > 255) {
-                ok = false;
-                break;
-            }
-            p.bits.resize((size_t)len);
-            p.delta.resize((size_t)len);
-            for (int k = 0; k < len; ++k) {
-                std::memcpy(&p.bits[(size_t)k], &val[rp[r] + k], 8);
-                p.delta[(size_t)k] = col[rp[r] + k] - r;
-            }
-            int id = -1;
-            for (size_t q = 0; q < pats.size(); ++q)
-                if (pats[q] == p) {
-                    id = (int)q;
-                    break;
-                }
-            if (id < 0) {
-                if ((int)pats.size() == kPatMax) {
+            for (schwz_idx r = r0; r < r1 && ok; ++r) {
+                const int len = rp[r + 1] - rp[r];
+                if (len > 255) {
                     ok = false;
                     break;
                 }
-                id = (int)pats.size();
-                lmax = std::max(lmax, len);
-                pats.push_back(std::move(p));
+                p.bits.resize((size_t)len);
+                p.delta.resize((size_t)len);
+                for (int k = 0; k < len; ++k) {
+                    std::memcpy(&p.bits[(size_t)k], &val[rp[r] + k], 8);
+                    p.delta[(size_t)k] = col[rp[r] + k] - r;
+                }
+                int id = -1;
+                for (size_t q = 0; q < pats.size(); ++q)
+                    if (pats[q] == p) {
+                        id = (int)q;
+                        break;
+                    }
+                if (id < 0) {
+                    if ((int)pats.size() == kPatMax) {
+                        ok = false;
+                        break;
+                    }
+                    id = (int)pats.size();
+                    lmax = std::max(lmax, len);
+                    pats.push_back(p);
+                }
+                pat_id[(size_t)r] = (uint8_t)id;
             }
-            pat_id[(size_t)r] = (uint8_t)id;
-        }
-        if (!ok || (int64_t)pats.size() * pat_stride(std::max(lmax, 1)) > kPatEntries) continue;
-        Table tb;
-        tb.npat = (int)pats.size();
-        tb.lmax = std::max(lmax, 1);
-        tb.len.resize((size_t)tb.npat);
-        tb.val.assign((size_t)tb.npat * tb.lmax, 0.0);
-        tb.delta.assign((size_t)tb.npat * tb.lmax, 0);
-        uint64_t h = 1469598103934665603ull;
-        for (int q = 0; q < tb.npat; ++q) {
-            tb.len[(size_t)q] = (uint8_t)pats[(size_t)q].bits.size();
-            for (size_t k = 0; k < pats[(size_t)q].bits.size(); ++k) {
-                std::memcpy(&tb.val[(size_t)q * tb.lmax + k], &pats[(size_t)q].bits[k], 8);
-                tb.delta[(size_t)q * tb.lmax + k] = pats[(size_t)q].delta[k];
-                h = (h ^ pats[(size_t)q].bits[k]) * 1099511628211ull;
-                h = (h ^ (uint64_t)(int64_t)pats[(size_t)q].delta[k]) * 1099511628211ull;
+            if (!ok || (int64_t)pats.size() * pat_stride(std::max(lmax, 1)) > kPatEntries) continue;
+            Table &tb = tile_tb[(size_t)t];
+            tb.npat = (int)pats.size();
+            tb.lmax = std::max(lmax, 1);
+            tb.len.resize((size_t)tb.npat);
+            tb.val.assign((size_t)tb.npat * tb.lmax, 0.0);
+            tb.delta.assign((size_t)tb.npat * tb.lmax, 0);
+            uint64_t h = 1469598103934665603ull;
+            for (int q = 0; q < tb.npat; ++q) {
+                tb.len[(size_t)q] = (uint8_t)pats[(size_t)q].bits.size();
+                for (size_t k = 0; k < pats[(size_t)q].bits.size(); ++k) {
+                    std::memcpy(&tb.val[(size_t)q * tb.lmax + k], &pats[(size_t)q].bits[k], 8);
+                    tb.delta[(size_t)q * tb.lmax + k] = pats[(size_t)q].delta[k];
+                    h = (h ^ pats[(size_t)q].bits[k]) * 1099511628211ull;
+                    h = (h ^ (uint64_t)(int64_t)pats[(size_t)q].delta[k]) * 1099511628211ull;
+                }
+                h = (h ^ 0xffull ^ (uint64_t)tb.len[(size_t)q]) * 1099511628211ull;
             }
-            h = (h ^ 0xffull ^ (uint64_t)tb.len[(size_t)q]) * 1099511628211ull;
+            tb.hash = h;
+            tile_ok[(size_t)t] = 1;
         }
-        tb.hash = h;
+    });
+    for (int t = 0; t < ntiles; ++t) {
+        if (!tile_ok[(size_t)t]) continue;
+        Table &tb = tile_tb[(size_t)t];
         int id = -1;
-        auto range = by_hash.equal_range(h);
+        auto range = by_hash.equal_range(tb.hash);
         for (auto it = range.first; it != range.second; ++it)
             if (tables[(size_t)it->second].same(tb)) {
                 id = it->second;
@@ -612,12 +623,14 @@ static int build_spmv_pattern(schwz_csr *A, const schwz_idx *rp, const schwz_idx
             }
         if (id < 0) {
             id = (int)tables.size();
-            by_hash.emplace(h, id);
+            by_hash.emplace(tb.hash, id);
             tables.push_back(std::move(tb));
         }
         tile_table[(size_t)t] = id;
-        coded += rp[r1] - rp[r0];
+        coded += rp[tiles[(size_t)t + 1]] - rp[tiles[(size_t)t]];
     }
+    tile_tb.clear();
+    tile_tb.shrink_to_fit();
     A->pattern_fraction = (double)coded / (double)nnz;
     if (A->pattern_fraction < 0.9 && !(env && env[0] == '2')) return SCHWZ_OK;
     // a table pays off only when it is shared: with one table per tile the "coding" is just the
@@ -653,8 +666,15 @@ int build_spmv_dict(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, con
                     const std::vector<schwz_idx> &tiles)
 {
     {
-        int rc = build_spmv_pattern(A, rp, col, val, tiles);
-        if (!rc && A->v.pat_id) rc = build_spmv_pair(A, rp, col, val, tiles);  // stencil-like: pairs too
+        int rc;
+        {
+            StageTimer t("codings: row patterns");
+            rc = build_spmv_pattern(A, rp, col, val, tiles);
+        }
+        if (!rc && A->v.pat_id) {
+            StageTimer t("codings: row pairs + walk tables");
+            rc = build_spmv_pair(A, rp, col, val, tiles);  // stencil-like: pairs too
+        }
         if (rc) {
             free_spmv_dict(A);
             return rc;

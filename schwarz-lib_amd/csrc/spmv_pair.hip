@@ -611,9 +611,11 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
 // part of the fused check residual ||b - A x2||^2 that coincides with the start residual; the flagged planes
 // are added by a listed kSpmvResidNorm launch on x2 (launch_spmv_pair).
 // RUNS: runs per chunk record of the pattern ids (8: 16 bytes, 16: 32 bytes; CsrView::pair_rle_runs)
-// H3: the +-NX halo of a position is requested three positions ahead (with the neighbouring bands' own request of
-// the same lines, see SCHWZ_DD below) into a ring of three halo slots instead of one ahead into two.
-template <int NHL, int NH, bool DIAGVEC, bool INIT = false, bool DUAL = false, int RUNS = 8, bool H3 = false>
+// (The three-positions-ahead halo schedule that pays in the fused direction launch below was measured here too,
+// with a third halo slot: no gain on 256- and 512-wide planes, where the p halo already hits L2 -- r is a
+// non-temporal stream in this launch and does not evict it --, and a loss wherever the larger ring costs a
+// workgroup per CU: profiles/r03_h3_rle16_ab.txt.  Not kept.)
+template <int NHL, int NH, bool DIAGVEC, bool INIT = false, bool DUAL = false, int RUNS = 8>
 __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, SpmvArgs a)
 {
 #pragma clang fp contract(off)
@@ -625,7 +627,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
     const int NX = A.sweep_nx;
     double *const own_ring = reinterpret_cast<double *>(sweep_lds);
     double *const halo_ring = own_ring + 4 * T;
-    PairVal *const cpv = reinterpret_cast<PairVal *>(halo_ring + (H3 ? 6 : 4) * NX);
+    PairVal *const cpv = reinterpret_cast<PairVal *>(halo_ring + 4 * NX);
     int *const cmask = reinterpret_cast<int *>(cpv + A.canon_npat * 9);
     __shared__ double red[4];
     double cg_alpha = 1.0;
@@ -687,8 +689,8 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
                 __builtin_memcpy(&reg[k], a.x + clampg(g), 16);
             }
         };
-        auto store_halo = [&](int hslot, const pvd2 (&reg)[NHL]) {
-            double *slot_p = halo_ring + (size_t)hslot * 2 * NX;
+        auto store_halo = [&](int z, const pvd2 (&reg)[NHL]) {
+            double *slot_p = halo_ring + (size_t)(z & 1) * 2 * NX;
 #pragma unroll
             for (int k = 0; k < NHL; ++k) {
                 const int pc = min(tid + k * kBlock, NX - 1);
@@ -715,24 +717,19 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
         // content -- own(z + 1) -- has just gone to LDS; r(z + 2) at the end of step z, into the set step z
         // has just consumed; the halo of position z + 1 (L2 hits) first thing in step z.  The band's first
         // rows at the positions z - 1 .. z + 3 travel in scalar registers (brow), one new one per step.
-        pvd2 own_a[NH], own_b[NH], hreg[NHL], hreg_b[NHL];
+        pvd2 own_a[NH], own_b[NH], hreg[NHL];
         Ahead r_a[NH], r_b[NH];
         int brow[5];
 #pragma unroll
         for (int k = 0; k < 5; ++k) brow[k] = band_row(z0 - 1 + k);
         {
             // everything the first two positions need is requested before anything is waited for
-            pvd2 first[NH], second[NH], h0[NHL];
+            pvd2 first[NH], second[NH];
             load_own(brow[0], first);
             load_own(brow[1], second);
-            load_halo(brow[1], H3 ? h0 : hreg);
+            load_halo(brow[1], hreg);
             load_own(brow[2], own_b);
             load_own(brow[3], own_a);
-            if (H3) {
-                load_halo(brow[2], hreg);    // position z0 + 1
-                load_halo(brow[3], hreg_b);  // position z0 + 2
-                store_halo(0, h0);
-            }
 #pragma unroll
             for (int h = 0; h < NH; ++h) {
                 r_a[h] = fetch(brow[1], h);
@@ -741,29 +738,20 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
             store_own(z0 - 1, first);
             store_own(z0, second);
         }
-        int hs = 0;  // halo slot of the position being computed (three-slot form)
-        // one position: `own_next` holds own(z + 1) on entry and own(z + 3) on exit, `rr` r(z) / r(z + 2); with H3
-        // `hal_next` the halo of position z + 1 on entry and of position z + 3 on exit
-        auto step = [&](int z, pvd2 (&own_next)[NH], Ahead (&rr)[NH], pvd2 (&hal_next)[NHL]) {
+        // one position: `own_next` holds own(z + 1) on entry and own(z + 3) on exit, `rr` r(z) / r(z + 2)
+        auto step = [&](int z, pvd2 (&own_next)[NH], Ahead (&rr)[NH]) {
             // brow[] = first rows at z - 1, z, z + 1, z + 2, z + 3
             store_own(z + 1, own_next);
-            const int hs_next = hs == 2 ? 0 : hs + 1;
-            if (H3)
-                store_halo(hs_next, hal_next);
-            else
-                store_halo(z & 1, hreg);
+            store_halo(z, hreg);
             lds_barrier();
-            if (H3)
-                load_halo(brow[4], hal_next);
-            else
-                load_halo(brow[2], hreg);
+            load_halo(brow[2], hreg);
             load_own(brow[4], own_next);
             const int far = chain_far[z];
             const bool plain_pos = DUAL ? ((const_ints)(uintptr_t)A.chain_dual)[z] == 0 : true;
             const double *cur = own_ring + (size_t)(z & 3) * T;
             const double *prv = own_ring + (size_t)((z + 3) & 3) * T;
             const double *nxt = own_ring + (size_t)((z + 1) & 3) * T;
-            const double *hlo = halo_ring + (size_t)(H3 ? hs : (z & 1)) * 2 * NX, *hup = hlo + NX;
+            const double *hlo = halo_ring + (size_t)(z & 1) * 2 * NX, *hup = hlo + NX;
             // window each far slot reads (slots of a plane without that coupling read `cur`: masked anyway)
             const double *fb0 = (far & 3) == 1 ? prv : ((far & 3) == 2 ? nxt : cur);
             const double *fb1 = ((far >> 2) & 3) == 1 ? prv : (((far >> 2) & 3) == 2 ? nxt : cur);
@@ -829,14 +817,13 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
 #pragma unroll
             for (int k = 0; k < 4; ++k) brow[k] = brow[k + 1];
             brow[4] = band_row(z + 4);
-            hs = hs_next;
         };
         int z = z0;
         for (; z + 1 < z1; z += 2) {
-            step(z, own_b, r_a, hreg);
-            step(z + 1, own_a, r_b, hreg_b);
+            step(z, own_b, r_a);
+            step(z + 1, own_a, r_b);
         }
-        if (z < z1) step(z, own_b, r_a, hreg);
+        if (z < z1) step(z, own_b, r_a);
     }
     const double s0 = block_sum(acc0, red);
     const double s1 = block_sum(acc1, red);
@@ -1129,45 +1116,22 @@ bool pair_sweep_dual_ok(const CsrView &A, int grid)
 
 // One instantiation of the z-sweep update / start walk: raises its dynamic-LDS limit once, launches it.
 // false: the device does not grant 96 KiB of dynamic LDS to the kernel (nothing was launched).
-template <int L_, int H_, bool DV, bool INIT, bool DUAL, int RUNS, bool H3>
+template <int L_, int H_, bool DV, bool INIT, bool DUAL, int RUNS>
 static bool launch_sweep_instance(const CsrView &A, const SpmvArgs &b, size_t lds, hipStream_t s)
 {
-    static const hipError_t e = hipFuncSetAttribute((const void *)spmv_pair_sweep_kernel<L_, H_, DV, INIT, DUAL, RUNS, H3>,
+    static const hipError_t e = hipFuncSetAttribute((const void *)spmv_pair_sweep_kernel<L_, H_, DV, INIT, DUAL, RUNS>,
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);
     if (e != hipSuccess || lds > (size_t)(96 << 10)) return false;
-    hipLaunchKernelGGL((spmv_pair_sweep_kernel<L_, H_, DV, INIT, DUAL, RUNS, H3>), dim3(A.sweep_nslots), dim3(kBlock), lds, s, A, b);
+    hipLaunchKernelGGL((spmv_pair_sweep_kernel<L_, H_, DV, INIT, DUAL, RUNS>), dim3(A.sweep_nslots), dim3(kBlock), lds, s, A, b);
     return true;
 }
 
-// ... chosen by the run-length record of the matrix (8 / 16 runs per chunk) and the halo schedule
+// ... chosen by the run-length record of the matrix (8 / 16 runs per chunk)
 template <int L_, int H_, bool DV, bool INIT, bool DUAL>
-static bool launch_sweep_variant(const CsrView &A, const SpmvArgs &b, size_t lds, bool h3, hipStream_t s)
+static bool launch_sweep_variant(const CsrView &A, const SpmvArgs &b, size_t lds, hipStream_t s)
 {
-    if (A.pair_rle_runs == 16)
-        return h3 ? launch_sweep_instance<L_, H_, DV, INIT, DUAL, 16, true>(A, b, lds, s)
-                  : launch_sweep_instance<L_, H_, DV, INIT, DUAL, 16, false>(A, b, lds, s);
-    return h3 ? launch_sweep_instance<L_, H_, DV, INIT, DUAL, 8, true>(A, b, lds, s)
-              : launch_sweep_instance<L_, H_, DV, INIT, DUAL, 8, false>(A, b, lds, s);
-}
-
-// Halo schedule of the update / start walk: three positions ahead into three halo slots (H3) where the larger
-// ring leaves the workgroups per CU unchanged (LDS of 3 workgroups within 160 KiB), else one ahead into two.
-// SCHWZ_SWEEP_H3=0 / 1: never / wherever 96 KiB allow.
-static bool sweep_h3(const CsrView &A, size_t *lds)
-{
-    const size_t tables = (size_t)A.canon_npat * (9 * 16 + 4);
-    const size_t lds2 = (size_t)(4 * A.sweep_T + 4 * A.sweep_nx) * sizeof(double) + tables;
-    const size_t lds3 = (size_t)(4 * A.sweep_T + 6 * A.sweep_nx) * sizeof(double) + tables;
-    const char *e = std::getenv("SCHWZ_SWEEP_H3");
-    bool h3;
-    if (e && e[0] == '0')
-        h3 = false;
-    else if (e && e[0] == '1')
-        h3 = lds3 <= (size_t)(96 << 10);
-    else
-        h3 = (160u << 10) / (lds3 + 64) >= std::min<size_t>(3, (160u << 10) / (lds2 + 64));
-    *lds = h3 ? lds3 : lds2;
-    return h3;
+    return A.pair_rle_runs == 16 ? launch_sweep_instance<L_, H_, DV, INIT, DUAL, 16>(A, b, lds, s)
+                                 : launch_sweep_instance<L_, H_, DV, INIT, DUAL, 8>(A, b, lds, s);
 }
 
 int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hipStream_t s)
@@ -1181,8 +1145,7 @@ int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hi
             return SCHWZ_ERR_INVALID;
         }
         const int nhl = (A.sweep_nx + kBlock - 1) / kBlock, nh = A.sweep_T / kPairRows;
-        size_t lds = 0;
-        const bool h3 = sweep_h3(A, &lds);
+        const size_t lds = (size_t)(4 * A.sweep_T + 4 * A.sweep_nx) * sizeof(double) + (size_t)A.canon_npat * (9 * 16 + 4);
         SpmvArgs b = a;
         b.part_stride = grid;
         b.part_offset = 0;
@@ -1194,8 +1157,8 @@ int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hi
             return SCHWZ_ERR_INVALID;
         }
 #define SCHWZ_SWEEP_INIT(L_, H_)                                                                              \
-    ok = with_dual ? launch_sweep_variant<L_, H_, false, true, true>(A, b, lds, h3, s)                            \
-                   : launch_sweep_variant<L_, H_, false, true, false>(A, b, lds, h3, s);
+    ok = with_dual ? launch_sweep_variant<L_, H_, false, true, true>(A, b, lds, s)                            \
+                   : launch_sweep_variant<L_, H_, false, true, false>(A, b, lds, s);
         bool ok = false;
         if (nh == 1 && nhl == 1) SCHWZ_SWEEP_INIT(1, 1)
         else if (nh == 1 && nhl == 2) SCHWZ_SWEEP_INIT(2, 1)
@@ -1273,15 +1236,14 @@ int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hi
             // z-sweep walk + (where boundary planes or overlap rows exist) the listed walk of the chunks it
             // leaves out; the consumer folds `grid` partial sums per bank, as after a chunk-by-chunk launch
             const int nhl = (A.sweep_nx + kBlock - 1) / kBlock, nh = A.sweep_T / kPairRows;  // halo / own pieces per lane
-            size_t lds = 0;
-            const bool h3 = sweep_h3(A, &lds);
+            const size_t lds = (size_t)(4 * A.sweep_T + 4 * A.sweep_nx) * sizeof(double) + (size_t)A.canon_npat * (9 * 16 + 4);
             SpmvArgs b = a;
             b.part_stride = grid;
             b.part_offset = A.sweep_gen_blocks;  // slots of the companion launch follow this one's
             const bool dv = a.diag_mode == 1;
 #define SCHWZ_SWEEP_LAUNCH(L_, H_)                                                                   \
-    launched = dv ? launch_sweep_variant<L_, H_, true, false, false>(A, b, lds, h3, s)                 \
-                  : launch_sweep_variant<L_, H_, false, false, false>(A, b, lds, h3, s);
+    launched = dv ? launch_sweep_variant<L_, H_, true, false, false>(A, b, lds, s)                 \
+                  : launch_sweep_variant<L_, H_, false, false, false>(A, b, lds, s);
             bool launched = true;  // false: no such instantiation, or no LDS for it -- chunk by chunk then
             if (nh == 1 && nhl == 1) SCHWZ_SWEEP_LAUNCH(1, 1)
             else if (nh == 1 && nhl == 2) SCHWZ_SWEEP_LAUNCH(2, 1)
@@ -1826,42 +1788,117 @@ int build_spmv_pair(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, con
     // distinct pairs in total); the kernel then stages it once and looks nothing up per chunk.
     bool single = !(env && env[0] == '3');  // SCHWZ_SPMV_PAIR=3: per-chunk tables even if one would do
     {
+        StageTimer t_single("  pairs: one table for the whole matrix");
+        std::vector<char> unsorted(64, 0);
+        parallel_blocks(nrows, 1 << 16, [&](int t, int, int64_t a, int64_t b) {
+            bool bad = false;
+            for (int64_t r = a; r < b && !bad; ++r) {
+                if (rp[r + 1] - rp[r] > 127) bad = true;
+                for (schwz_idx j = rp[r] + 1; j < rp[r + 1] && !bad; ++j)
+                    if (col[j] <= col[j - 1]) bad = true;
+            }
+            unsorted[(size_t)t] = bad;
+        });
         bool sorted = true;
-        for (int64_t r = 0; r < nrows && sorted; ++r) {
-            if (rp[r + 1] - rp[r] > 127) sorted = false;
-            for (schwz_idx j = rp[r] + 1; j < rp[r + 1] && sorted; ++j)
-                if (col[j] <= col[j - 1]) sorted = false;
-        }
+        for (char u : unsorted) sorted = sorted && !u;
         single = single && sorted;
         int lmax = 1;
-        std::unordered_multimap<uint64_t, int> seen;
-        for (int64_t ra = 0; ra < nrows && single; ra += 2) {
-            merge_pair(ra, ra + 1 < nrows);
-            uint64_t h = 1469598103934665603ull;
-            for (const PairEntryH &e : cur) {
-                h = (h ^ e.va) * 1099511628211ull;
-                h = (h ^ e.vb) * 1099511628211ull;
-                h = (h ^ (uint64_t)(int64_t)e.off) * 1099511628211ull;
-                h = (h ^ (uint64_t)e.flags) * 1099511628211ull;
-            }
-            int id = -1;
-            auto range = seen.equal_range(h);
-            for (auto it = range.first; it != range.second; ++it)
-                if (pats[(size_t)it->second] == cur) {
-                    id = it->second;
-                    break;
+        if (single) {
+            // Every thread codes a contiguous block of pairs against a dictionary of its own (ids in ITS order of
+            // first appearance); the dictionaries are then merged in block order, which numbers the patterns in
+            // the order a sequential pass meets them, and the ids are renumbered.
+            const int64_t npairs = (nrows + 1) / 2;
+            std::vector<std::vector<std::vector<PairEntryH>>> tpats(64);
+            std::vector<char> tfail(64, 0);
+            const int nthreads = parallel_blocks(npairs, 1 << 15, [&](int t, int, int64_t a, int64_t b) {
+                auto &mine = tpats[(size_t)t];
+                std::unordered_multimap<uint64_t, int> seen;
+                std::vector<PairEntryH> cur_t;
+                for (int64_t pi = a; pi < b && !tfail[(size_t)t]; ++pi) {
+                    const int64_t ra = 2 * pi;
+                    // (merge_pair on a thread-private sequence)
+                    cur_t.clear();
+                    {
+                        const bool has_b = ra + 1 < nrows;
+                        schwz_idx ja = rp[ra], ea = rp[ra + 1];
+                        schwz_idx jb = has_b ? rp[ra + 1] : 0, eb = has_b ? rp[ra + 2] : 0;
+                        while (ja < ea || jb < eb) {
+                            const int64_t da = ja < ea ? (int64_t)col[ja] - ra : INT64_MAX;
+                            const int64_t db = jb < eb ? (int64_t)col[jb] - (ra + 1) : INT64_MAX;
+                            PairEntryH e = {0, 0, 0, 0};
+                            const int64_t d = std::min(da, db);
+                            e.off = (schwz_idx)d;
+                            if (da == d) {
+                                e.flags |= 1;
+                                std::memcpy(&e.va, &val[ja], 8);
+                                ++ja;
+                            }
+                            if (db == d) {
+                                e.flags |= 2;
+                                std::memcpy(&e.vb, &val[jb], 8);
+                                ++jb;
+                            }
+                            cur_t.push_back(e);
+                        }
+                    }
+                    uint64_t h = 1469598103934665603ull;
+                    for (const PairEntryH &e : cur_t) {
+                        h = (h ^ e.va) * 1099511628211ull;
+                        h = (h ^ e.vb) * 1099511628211ull;
+                        h = (h ^ (uint64_t)(int64_t)e.off) * 1099511628211ull;
+                        h = (h ^ (uint64_t)e.flags) * 1099511628211ull;
+                    }
+                    int id = -1;
+                    auto range = seen.equal_range(h);
+                    for (auto it = range.first; it != range.second; ++it)
+                        if (mine[(size_t)it->second] == cur_t) {
+                            id = it->second;
+                            break;
+                        }
+                    if (id < 0) {
+                        id = (int)mine.size();
+                        if (id == kPairPats) {
+                            tfail[(size_t)t] = 1;
+                            break;
+                        }
+                        seen.emplace(h, id);
+                        mine.push_back(cur_t);
+                    }
+                    pair_id[(size_t)pi] = (uint8_t)id;
                 }
-            if (id < 0) {
-                id = (int)pats.size();
-                lmax = std::max(lmax, (int)cur.size());
-                if (id == kPairPats || (int64_t)(id + 1) * pair_stride(lmax) > kPairEntries) {
-                    single = false;
-                    break;
+            });
+            std::vector<std::vector<int>> remap((size_t)nthreads);
+            for (int t = 0; t < nthreads && single; ++t) {
+                if (tfail[(size_t)t]) single = false;
+                for (const auto &pt : tpats[(size_t)t]) {
+                    if (!single) break;
+                    int id = -1;
+                    for (size_t q = 0; q < pats.size(); ++q)
+                        if (pats[q] == pt) {
+                            id = (int)q;
+                            break;
+                        }
+                    if (id < 0) {
+                        id = (int)pats.size();
+                        lmax = std::max(lmax, (int)pt.size());
+                        if (id == kPairPats || (int64_t)(id + 1) * pair_stride(lmax) > kPairEntries) {
+                            single = false;
+                            break;
+                        }
+                        pats.push_back(pt);
+                    }
+                    remap[(size_t)t].push_back(id);
                 }
-                seen.emplace(h, id);
-                pats.push_back(cur);
             }
-            pair_id[(size_t)(ra >> 1)] = (uint8_t)id;
+            if (single) {
+                // the same blocks again (parallel_blocks cuts [0, npairs) the same way for the same n and grain)
+                parallel_blocks(npairs, 1 << 15, [&](int t, int, int64_t a, int64_t b) {
+                    const auto &mp = remap[(size_t)t];
+                    for (int64_t pi = a; pi < b; ++pi) pair_id[(size_t)pi] = (uint8_t)mp[(size_t)pair_id[(size_t)pi]];
+                });
+            } else {
+                pats.clear();
+            }
         }
         if (single) {
             PairTable tb;
@@ -1951,6 +1988,7 @@ int build_spmv_pair(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, con
     if (!single && tables.size() * 4 > (size_t)nchunks && !force) return SCHWZ_OK;  // tables must be shared to pay off
     // Symmetric matrix (checked bit for bit): a second set of tables with the entries on and above the
     // diagonal only, the strictly upper ones doubled (exact), for kSpmvDotSym.  SCHWZ_SPMV_SYM=0 skips it.
+    StageTimer t_sym("  pairs: symmetry check, upper-triangle twins");
     int sym_base = 0;
     const char *sym_env = std::getenv("SCHWZ_SPMV_SYM");
     if (!(sym_env && sym_env[0] == '0') && csr_is_symmetric(nrows, A->v.ncols, rp, col, val)) {
@@ -1989,6 +2027,8 @@ int build_spmv_pair(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, con
         }
         for (PairTable &u : upper) tables.push_back(std::move(u));
     }
+    t_sym.stop();
+    StageTimer t_rest("  pairs: tables, records, canonical layout, walk tables, uploads");
     std::vector<schwz_idx> desc, meta;
     std::vector<uint8_t> lens;
     std::vector<double> vals;
@@ -2027,28 +2067,34 @@ int build_spmv_pair(schwz_csr *A, const schwz_idx *rp, const schwz_idx *col, con
     if (!(rle_env && rle_env[0] == '0')) {
         auto build_rle = [&](int R, int64_t *coded_out) {
             std::vector<uint16_t> out((size_t)nchunks * R, 0xffffu);
-            int64_t coded = 0;
-            for (int c = 0; c < nchunks; ++c) {
-                if (chunk_ptable[(size_t)c] < 0) continue;
-                const int64_t p0 = (int64_t)c * (kPairRows / 2), p1 = std::min<int64_t>(p0 + kPairRows / 2, (nrows + 1) / 2);
-                uint16_t runs[16];
-                int nr = 0;
-                bool fits = true;
-                for (int64_t p = p0; p < p1 && fits; ++p) {
-                    if (nr == 0 || pair_id[(size_t)p] != (uint8_t)(runs[nr - 1] >> 8)) {
-                        if (nr == R) {
-                            fits = false;
-                            break;
+            std::vector<int64_t> coded_t(64, 0);
+            parallel_blocks(nchunks, 2048, [&](int t, int, int64_t c_begin, int64_t c_end) {
+                int64_t mine = 0;
+                for (int64_t c = c_begin; c < c_end; ++c) {
+                    if (chunk_ptable[(size_t)c] < 0) continue;
+                    const int64_t p0 = c * (kPairRows / 2), p1 = std::min<int64_t>(p0 + kPairRows / 2, (nrows + 1) / 2);
+                    uint16_t runs[16];
+                    int nr = 0;
+                    bool fits = true;
+                    for (int64_t p = p0; p < p1 && fits; ++p) {
+                        if (nr == 0 || pair_id[(size_t)p] != (uint8_t)(runs[nr - 1] >> 8)) {
+                            if (nr == R) {
+                                fits = false;
+                                break;
+                            }
+                            runs[nr++] = (uint16_t)((p - p0) | ((int)pair_id[(size_t)p] << 8));
                         }
-                        runs[nr++] = (uint16_t)((p - p0) | ((int)pair_id[(size_t)p] << 8));
                     }
+                    if (!fits || nr == 0) continue;
+                    for (int k = nr; k < R; ++k) runs[k] = runs[nr - 1];
+                    if (runs[0] == 0xffffu) continue;  // would read as the "not coded" marker
+                    std::copy(runs, runs + R, out.begin() + (size_t)c * R);
+                    ++mine;
                 }
-                if (!fits || nr == 0) continue;
-                for (int k = nr; k < R; ++k) runs[k] = runs[nr - 1];
-                if (runs[0] == 0xffffu) continue;  // would read as the "not coded" marker
-                std::copy(runs, runs + R, out.begin() + (size_t)c * R);
-                ++coded;
-            }
+                coded_t[(size_t)t] = mine;
+            });
+            int64_t coded = 0;
+            for (int64_t v : coded_t) coded += v;
             *coded_out = coded;
             return out;
         };

@@ -56,6 +56,7 @@ void schwz_subdomain_destroy(schwz_subdomain *sd)
 
 int schwz_subdomain_to_device(schwz_subdomain *sd, const double *h_local_rhs, const schwz_solver_options *opt)
 {
+    StageTimer timer_all("subdomain_to_device total");
     SCHWZ_REQUIRE(sd && h_local_rhs && opt, "schwz_subdomain_to_device: null argument");
     SCHWZ_REQUIRE(!sd->on_device, "schwz_subdomain_to_device: already on the device");
     SCHWZ_REQUIRE(opt->local_solver == SCHWZ_SOLVER_ITERATIVE || opt->local_solver == SCHWZ_SOLVER_DIRECT,
