@@ -183,8 +183,12 @@ int schwz_gmres_last_stats(schwz_gmres *s, int *h_iters, double *h_resnorm);
  * times host calls without a device sync). */
 int schwz_profile_begin(int capacity);
 /* STREAM-style probe for the measured HBM ceiling quoted beside the 8 TB/s spec
- * (SURVEY 8d): mode 0 copies n doubles src->dst, mode 1 reads n doubles and
- * writes one partial sum per workgroup (dst needs 2048 doubles). */
+ * (SURVEY 8d): mode 0 copies n doubles src->dst in a grid-stride loop of 2048
+ * persistent workgroups, mode 1 reads n doubles and writes one partial sum per
+ * workgroup (dst needs 2048 doubles), mode 2 copies with one 16-byte element
+ * per thread and a grid that covers the buffer once (the form that reaches the
+ * ~6.2 TB/s copy ceiling), mode 3 / 4 four elements per thread, plain /
+ * non-temporal. */
 int schwz_stream_probe(int64_t n, int mode, const double *d_src, double *d_dst,
                        schwz_stream stream);
 int schwz_profile_end(double *h_total_ms, int64_t *h_launches);

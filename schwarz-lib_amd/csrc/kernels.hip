@@ -504,12 +504,7 @@ int schwz_csr_create(int64_t nrows, int64_t ncols, const schwz_idx *h_rp, const 
         wtiles.push_back((schwz_idx)e);
         r = e;
     }
-    for (int64_t i = 0; i < nnz; ++i) {
-        if (h_col[i] < 0 || h_col[i] >= ncols) {
-            set_error("schwz_csr_create: column index out of range");
-            return SCHWZ_ERR_INVALID;
-        }
-    }
+    // (column indices were range-checked by csr_is_well_formed above)
     // spmv_stream.hip: nonzero offset of every tile, and whether the straight-line kernel applies (every tile
     // fits the 16-byte aligned window, no row longer than 32 entries)
     std::vector<schwz_idx> tile_nz(tiles.size());

@@ -1678,9 +1678,12 @@ static int build_sweep(schwz_csr *A, int64_t nrows, const PairTable &tb, const P
     // own; equal to the update launch's when the band heights coincide.
     // Measured in-box (tools/tdir_ab.sh): 256-wide planes, update bands of 512 rows: 1024-row bands for the fused
     // launch -3 % per step (2048: +5 %); 512-wide planes, 1024 / 2048: +3 % (two workgroups per CU); 1024-wide
-    // planes, where a 1024-row band is a single x line, 2048: fused launch 0.773 -> 0.696 ms, -4 % per step.
+    // planes, where a 1024-row band is a single x line, 2048: fused launch 0.773 -> 0.696 ms, -4 % per step -- in
+    // round 2.  With the halo schedule of round 3 (SCHWZ_DD) the halo lines hit L2 and what counts on 1024-wide
+    // planes is the second workgroup per CU a 1024-row band leaves room for: 1024 x 1024 x 128 slab, fused launch
+    // 0.681 ms with 2048-row bands, 0.640 ms with 1024 (step 16.5 -> 16.0 ms; profiles/r03_c5slab_ab.txt).
     const char *td_env = std::getenv("SCHWZ_SWEEP_TDIR");
-    int T_dir = td_env ? std::atoi(td_env) : (T == 512 ? 1024 : (NX >= 1024 ? 2048 : T));
+    int T_dir = td_env ? std::atoi(td_env) : (T == 512 ? 1024 : T);
     if ((T_dir != 512 && T_dir != 1024 && T_dir != 2048) || PL % T_dir ||
         (size_t)(4 * T_dir + ((SCHWZ_DD & 2) ? 3 : 2) * NX) * sizeof(double) + (size_t)tb.npat * 84 > (size_t)(96 << 10))
         T_dir = T;

@@ -22,7 +22,7 @@ import shutil
 import sys
 from collections import defaultdict
 
-TRACKED = ("spmv_pair_sweep_kernel<", "spmv_pair_dirdot_sweep_kernel<", "spmv_pair_kernel<8,", "spmv_pair_kernel<6,", "spmv_pair_kernel<7,", "spmv_pair_kernel<5,", "spmv_pair_kernel<1,", "spmv_pattern_kernel<1,",
+TRACKED = ("spmv_stream_kernel<0,", "spmv_pair_sweep_kernel<", "spmv_pair_dirdot_sweep_kernel<", "spmv_pair_kernel<8,", "spmv_pair_kernel<6,", "spmv_pair_kernel<7,", "spmv_pair_kernel<5,", "spmv_pair_kernel<1,", "spmv_pattern_kernel<1,",
            "spmv_dict_kernel<1>", "spmv_tiled2_kernel<1>", "spmv_stream_kernel<1,", "cg_update_kernel", "cg_direction_kernel")
 
 
@@ -50,7 +50,41 @@ def read_counter(dirname, counter):
     return {k: v[0] / v[1] for k, v in acc.items() if v[1]}
 
 
+def plain(prefix, tag):
+    """--plain <gpurun_out/prof_<tag>_plain> <tag>: the per-shape passes of tools/profile_plain.sh -> one
+    profiles/<tag>_plain_<shape>_kernel_stats.csv per shape and the spmv_stream_kernel<0, entry of that shape
+    in profiles/traffic.json (the other entries of the shape are kept)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, "profiles")
+    tpath = os.path.join(out, "traffic.json")
+    allent = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    for d in sorted(glob.glob(prefix + "_*")):
+        key = os.path.basename(d).split("_plain_")[-1]
+        stats = glob.glob(os.path.join(d, "stats", "**", "*_kernel_stats.csv"), recursive=True)
+        if not stats:
+            continue
+        shutil.copy(stats[0], os.path.join(out, "%s_plain_%s_kernel_stats.csv" % (tag, key)))
+        fetch = read_counter(os.path.join(d, "fetch"), "FETCH_SIZE")
+        write = read_counter(os.path.join(d, "write"), "WRITE_SIZE")
+        for row in csv.DictReader(open(stats[0])):
+            name = row["Name"]
+            if "spmv_stream_kernel<0," not in name or name not in fetch or name not in write:
+                continue
+            ent = allent.setdefault(key, {})
+            ent["spmv_stream_kernel<0,"] = dict(
+                hbm_bytes_per_launch=(2.0 * fetch[name] + write[name]) * 1024.0, avg_ns=float(row["AverageNs"]),
+                fetch_size_kib_raw=fetch[name], write_size_kib=write[name], calls=int(row["Calls"]),
+                source="%s_plain_%s_kernel_stats.csv" % (tag, key),
+                note="(2*FETCH_SIZE + WRITE_SIZE) KiB per launch, separate --pmc passes (tools/profile_plain.sh)")
+            ent["kernel_source_hash"] = kernel_source_hash(root)
+            print("%-16s %-50s avg %8.1f us  hbm %.3f GB" % (key, name[:50], float(row["AverageNs"]) / 1e3,
+                                                          ent["spmv_stream_kernel<0,"]["hbm_bytes_per_launch"] / 1e9))
+    json.dump(allent, open(tpath, "w"), indent=1, sort_keys=True)
+
+
 def main():
+    if sys.argv[1] == "--plain":
+        return plain(sys.argv[2], sys.argv[3])
     src, tag = sys.argv[1], sys.argv[2]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = os.path.join(root, "profiles")
