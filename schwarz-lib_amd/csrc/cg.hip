@@ -264,23 +264,39 @@ struct PRing {
 
 // The launch covers the pairs [pair0, pair1) (and the odd last row when `tail` is set): the last update of a
 // solve is cut into the caller's priority rows and the rest (schwz_pcg::prio_*).
+// lazy_it >= 0: the update launch of iteration lazy_it was not run (schwz_pcg::LazyLast); its direction counts
+// as carried out and its alpha = rho / (p.Ap) is formed here from the partial sums that launch would have folded
+// (the same expression, the same bits).  x2: rows [0, x2_rows) of the result are stored there as well (the
+// restricted write-back of the RAS step) and the rows [x2_rows, x2_total) are copied from x2_src -- the overlap and
+// halo entries of the current x~ --, so that x2 is the complete x~ after the restriction; with nothing to add the
+// launch only copies.
 __global__ __launch_bounds__(kBlock) void cg_flush_x_kernel(int64_t n, double *__restrict__ x, const PRing ring,
                                                             const double *__restrict__ alpha_hist,
                                                             const CgState *st, int b0, int count, int pending,
-                                                            int64_t pair0, int64_t pair1, int tail, int fused)
+                                                            int64_t pair0, int64_t pair1, int tail, int fused,
+                                                            int lazy_it, const double *pq_partials, int pq_nparts,
+                                                            double *__restrict__ x2, int64_t x2_rows,
+                                                            const double *__restrict__ x2_src, int64_t x2_total)
 {
 #pragma clang fp contract(off)
     __shared__ double alpha[kDeferDepth];
-    const int done = st->iters + ((pending >= 0 && pending < st->stop_iter) ? 1 : 0);
+    __shared__ double red[4];
+    const int stop = st->stop_iter;
+    int done = st->iters + ((pending >= 0 && pending < stop) ? 1 : 0);
+    if (lazy_it >= 0 && lazy_it < stop && done <= lazy_it) done = lazy_it + 1;
     const int kmax = min(count, done - b0);
-    if (kmax <= 0) return;
-    if ((int)threadIdx.x < kmax) alpha[threadIdx.x] = alpha_hist[(b0 + threadIdx.x) % kDeferDepth];
+    if (kmax <= 0 && !x2) return;
+    double lazy_alpha = 0.0;
+    if (kmax > 0 && lazy_it >= b0 && lazy_it < b0 + kmax)  // workgroup-uniform
+        lazy_alpha = st->rho[lazy_it & 1] / fold_partials(pq_partials, pq_nparts, red);
+    if ((int)threadIdx.x < kmax)
+        alpha[threadIdx.x] = (b0 + (int)threadIdx.x == lazy_it) ? lazy_alpha : alpha_hist[(b0 + threadIdx.x) % kDeferDepth];
     __syncthreads();
     const int64_t n2 = pair1;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    vd2 *x2 = reinterpret_cast<vd2 *>(x);
+    vd2 *x2v = reinterpret_cast<vd2 *>(x);
     for (int64_t i = pair0 + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
-        vd2 xv = __builtin_nontemporal_load(x2 + i);
+        vd2 xv = __builtin_nontemporal_load(x2v + i);
         for (int k0 = 0; k0 < kmax; k0 += 4) {
             vd2 pv[4];
 #pragma unroll
@@ -299,8 +315,23 @@ __global__ __launch_bounds__(kBlock) void cg_flush_x_kernel(int64_t n, double *_
                     }
                 }
         }
-        __builtin_nontemporal_store(xv, x2 + i);
+        if (kmax > 0) __builtin_nontemporal_store(xv, x2v + i);
+        if (x2) {
+            if (2 * i + 1 < x2_rows) {
+                __builtin_nontemporal_store(xv, reinterpret_cast<vd2 *>(x2) + i);
+            } else {
+                if (2 * i < x2_rows)
+                    x2[2 * i] = xv.x;
+                else if (2 * i < x2_total)
+                    x2[2 * i] = x2_src[2 * i];
+                if (2 * i + 1 < x2_total) x2[2 * i + 1] = x2_src[2 * i + 1];
+            }
+        }
     }
+    // entries of x2 beyond the solve's vector (the halo of x~): copied by the launch that takes the tail
+    if (x2 && tail)
+        for (int64_t j = 2 * pair1 + (int64_t)blockIdx.x * kBlock + threadIdx.x; j < x2_total; j += stride)
+            if (!((n & 1) && j == n - 1)) x2[j] = x2_src[j];
     if (tail && (n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         double xv = x[n - 1];
         for (int k = 0; k < kmax; ++k) {
@@ -312,7 +343,8 @@ __global__ __launch_bounds__(kBlock) void cg_flush_x_kernel(int64_t n, double *_
                 xv = xv + inc;
             }
         }
-        x[n - 1] = xv;
+        if (kmax > 0) x[n - 1] = xv;
+        if (x2) x2[n - 1] = n - 1 < x2_rows ? xv : x2_src[n - 1];
     }
 }
 
@@ -807,8 +839,19 @@ static int pcg_apply_general(schwz_pcg *s, hipStream_t st) { return precond_appl
 
 int pcg_take_trs_error(schwz_pcg *s) { return s && s->ilu ? trs_take_error(s->ilu) : SCHWZ_OK; }
 
+// The residual update and state advance a solve postponed (schwz_pcg::LazyLast): launched now, on the solve's
+// stream, for a caller that wants the iteration count or the final residual norm.
+int pcg_finish_lazy(schwz_pcg *s)
+{
+    if (!s || !s->lazy.pending) return SCHWZ_OK;
+    s->lazy.pending = false;
+    return s->lazy_run ? s->lazy_run(s->lazy.stream) : SCHWZ_OK;
+}
+
 int pcg_last_stats(schwz_pcg *s, int *h_iters, double *h_resnorm)
 {
+    const int rc_lazy = pcg_finish_lazy(s);
+    if (rc_lazy) return rc_lazy;
     SCHWZ_HIP_TRY(hipDeviceSynchronize());
     SCHWZ_HIP_TRY(hipMemcpy(&s->h_state[0], s->state, sizeof(CgState), hipMemcpyDeviceToHost));
     *h_iters = s->h_state[0].iters;
@@ -919,6 +962,7 @@ int pcg_begin(schwz_pcg *s, const double *d_b, double *d_x, double rtol, bool fu
 {
     const CsrView &A = s->A->v;
     const int gs = spmv_grid(A, s->variant);
+    s->lazy.pending = false;  // nobody asked for the last solve's final residual: it is recomputed from b - A x now
     SpmvArgs a;
     a.x = d_x;
     a.x2 = d_x2;
@@ -1000,25 +1044,44 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
     auto slot = [&](int it) -> double * { return const_cast<double *>(ring.slot[it % kDeferDepth]); };
     bool prio_recorded = false;
     const int fused_x = qfree ? 0 : 1;  // how the in-launch update of this iteration forms x + alpha p
+    // The last iteration of a solve of exactly max_iters iterations (rtol == 0: no stopping test can fire), x
+    // deferred: what its result needs is alpha = rho / (p.Ap) and x += alpha p, and both happen inside the last x
+    // update.  The residual update r -= alpha A p with rho' and ||r||^2, and the state advance, produce nothing
+    // anybody reads -- the next solve starts from b - A y -- unless the caller asks for the iteration count or
+    // the residual norm: they are postponed (schwz_pcg::lazy, pcg_finish_lazy) instead of launched.  Same x bit
+    // for bit.  SCHWZ_CG_LAZYLAST=0: every iteration is launched in full.
+    const char *lazy_env = std::getenv("SCHWZ_CG_LAZYLAST");  // read per solve: tests switch it
+    const bool lazy_on = !(lazy_env && lazy_env[0] == '0');
+    const char *ld_env0 = std::getenv("SCHWZ_CG_LASTDIR");
+    const bool lazy_last = lazy_on && rtol == 0.0 && deferx && !general && max_iters > 0 && !(ld_env0 && ld_env0[0] == '1');
+    const int lazy_it = lazy_last ? max_iters - 1 : -1;
+    const double *const lazy_pq = part_spmv;  // p.(A p) of the last iteration: SpMV bank 0, gs slots
+    s->x2_written = false;
     auto flush_x = [&](int b0, int count, int pending, hipStream_t q, bool last = false) {
         const int64_t n2 = n >> 1;
+        // the second output only from the launches that finish x (`last`)
+        double *const x2 = last ? s->x2_out : nullptr;
+        const int64_t x2_rows = last ? s->x2_rows : 0;
+        const int lz = last ? lazy_it : -1;
         if (last && s->prio_on && s->prio_event && q == st && !prio_recorded) {
             // the caller's priority rows first, the event, then the rest (the same bits: every element is
             // updated by exactly one lane of exactly one of the launches)
             const int64_t lo = std::min(s->prio_lo >> 1, n2), hi = std::max(std::min(s->prio_hi >> 1, n2), lo);
             if (lo > 0)
                 hipLaunchKernelGGL(cg_flush_x_kernel, dim3(grid_for(lo)), dim3(kBlock), 0, q, n, d_x, ring, s->alpha_hist,
-                                   s->state, b0, count, pending, (int64_t)0, lo, 0, fused_x);
+                                   s->state, b0, count, pending, (int64_t)0, lo, 0, fused_x, lz, lazy_pq, gs, x2, x2_rows, s->x2_src, s->x2_total);
             hipLaunchKernelGGL(cg_flush_x_kernel, dim3(grid_for(n2 - hi + 1)), dim3(kBlock), 0, q, n, d_x, ring,
-                               s->alpha_hist, s->state, b0, count, pending, hi, n2, 1, fused_x);
+                               s->alpha_hist, s->state, b0, count, pending, hi, n2, 1, fused_x, lz, lazy_pq, gs, x2, x2_rows, s->x2_src, s->x2_total);
             if (hipEventRecord(s->prio_event, q) == hipSuccess) prio_recorded = true;
             if (hi > lo)
                 hipLaunchKernelGGL(cg_flush_x_kernel, dim3(grid_for(hi - lo)), dim3(kBlock), 0, q, n, d_x, ring,
-                                   s->alpha_hist, s->state, b0, count, pending, lo, hi, 0, fused_x);
+                                   s->alpha_hist, s->state, b0, count, pending, lo, hi, 0, fused_x, lz, lazy_pq, gs, x2, x2_rows, s->x2_src, s->x2_total);
+            if (x2) s->x2_written = true;
             return;
         }
         hipLaunchKernelGGL(cg_flush_x_kernel, dim3(gv), dim3(kBlock), 0, q, n, d_x, ring, s->alpha_hist, s->state, b0,
-                           count, pending, (int64_t)0, n2, 1, fused_x);
+                           count, pending, (int64_t)0, n2, 1, fused_x, lz, lazy_pq, gs, x2, x2_rows, s->x2_src, s->x2_total);
+        if (x2) s->x2_written = true;
     };
     double *const pbuf[2] = {s->p, fusedir ? s->q : s->p};
     // SCHWZ_CG_LASTDIR=1: the last iteration of a solve updates the search direction like every other one
@@ -1062,9 +1125,10 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
             u.dinv = s->dinv;
             u.partials = part_vec;
             u.it = it;
-            const bool prof2 = instrument && g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
+            const bool lazy_now = instrument && it == lazy_it;
+            const bool prof2 = !lazy_now && instrument && g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
             if (prof2) SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used], q));
-            if ((rc = launch_spmv(A, kSpmvCgUpdate, u, s->variant, q))) return rc;
+            if (!lazy_now && (rc = launch_spmv(A, kSpmvCgUpdate, u, s->variant, q))) return rc;
             if (prof2) {
                 SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used + 1], q));
                 g_prof.kind[g_prof.used / 2] = 1;
@@ -1101,7 +1165,23 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
                 // the ring is full: apply its kDeferDepth increments before slot (it + 1) % depth,
                 // the oldest direction, is overwritten
                 if ((it + 1) % kDeferDepth == 0) flush_x(it + 1 - kDeferDepth, kDeferDepth, it, q, instrument && it == max_iters - 1);
-                if (instrument && it == max_iters - 1 && last_state_only)  // nobody reads the direction after the last iteration
+                if (lazy_now) {
+                    // the residual update and the state advance of this iteration wait until somebody asks
+                    const CsrView Av = A;
+                    const int variant = s->variant;
+                    double *const pv = part_vec;
+                    s->lazy_run = [Av, u, variant, pv, gs, s, it, rtol](hipStream_t qq) -> int {
+                        const int rc2 = launch_spmv(Av, kSpmvCgUpdate, u, variant, qq);
+                        if (rc2) return rc2;
+                        hipLaunchKernelGGL(cg_state_advance_kernel, dim3(1), dim3(kBlock), 0, qq, pv, gs, s->state, it, rtol);
+                        SCHWZ_HIP_TRY(hipGetLastError());
+                        return SCHWZ_OK;
+                    };
+                    s->lazy.pending = true;
+                    s->lazy.it = it;
+                    s->lazy.rtol = rtol;
+                    s->lazy.stream = q;
+                } else if (instrument && it == max_iters - 1 && last_state_only)  // nobody reads the direction after the last iteration
                     hipLaunchKernelGGL(cg_state_advance_kernel, dim3(1), dim3(kBlock), 0, q, part_vec, gs, s->state, it, rtol);
                 else
                     hipLaunchKernelGGL((cg_direction_kernel<1, false>), dim3(gv), dim3(kBlock), 0, q, n, slot(it), s->r,
@@ -1113,11 +1193,27 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
         } else if (!general && deferx) {
             // stored q, x deferred: r -= alpha q (24 n bytes instead of 48-56 n), alpha to the history, the new
             // direction into the next ring slot; the last iteration of a solve only advances the state
-            hipLaunchKernelGGL((cg_update_kernel<1, false, true>), dim3(gv), dim3(kBlock), 0, q, n, (double *)nullptr, s->r,
-                               (const double *)nullptr, s->q, s->diag, part_spmv, gs, s->state, it, part_vec,
-                               s->alpha_hist + it % kDeferDepth);
+            const bool lazy_now = instrument && it == lazy_it;
+            if (!lazy_now)
+                hipLaunchKernelGGL((cg_update_kernel<1, false, true>), dim3(gv), dim3(kBlock), 0, q, n, (double *)nullptr, s->r,
+                                   (const double *)nullptr, s->q, s->diag, part_spmv, gs, s->state, it, part_vec,
+                                   s->alpha_hist + it % kDeferDepth);
             if ((it + 1) % kDeferDepth == 0) flush_x(it + 1 - kDeferDepth, kDeferDepth, it, q, instrument && it == max_iters - 1);
-            if (instrument && it == max_iters - 1 && last_state_only)
+            if (lazy_now) {
+                double *const ps = part_spmv, *const pv = part_vec;
+                s->lazy_run = [s, n, gv, gs, ps, pv, it, rtol](hipStream_t qq) -> int {
+                    hipLaunchKernelGGL((cg_update_kernel<1, false, true>), dim3(gv), dim3(kBlock), 0, qq, n, (double *)nullptr,
+                                       s->r, (const double *)nullptr, s->q, s->diag, ps, gs, s->state, it, pv,
+                                       s->alpha_hist + it % kDeferDepth);
+                    hipLaunchKernelGGL(cg_state_advance_kernel, dim3(1), dim3(kBlock), 0, qq, pv, gv, s->state, it, rtol);
+                    SCHWZ_HIP_TRY(hipGetLastError());
+                    return SCHWZ_OK;
+                };
+                s->lazy.pending = true;
+                s->lazy.it = it;
+                s->lazy.rtol = rtol;
+                s->lazy.stream = q;
+            } else if (instrument && it == max_iters - 1 && last_state_only)
                 hipLaunchKernelGGL(cg_state_advance_kernel, dim3(1), dim3(kBlock), 0, q, part_vec, gv, s->state, it, rtol);
             else
                 hipLaunchKernelGGL((cg_direction_kernel<1, false>), dim3(gv), dim3(kBlock), 0, q, n, slot(it), s->r,
@@ -1235,6 +1331,12 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
         flush_x(it - it % kDeferDepth, it % kDeferDepth, -1, st, true);
         SCHWZ_HIP_TRY(hipGetLastError());
     }
+    // second output asked for, but no launch above was the last x update (ring just emptied, a stop between two
+    // rings, no iteration at all): a launch that adds nothing and copies
+    if (deferx && s->x2_out && !s->x2_written) {
+        flush_x(it, 0, -1, st, true);
+        SCHWZ_HIP_TRY(hipGetLastError());
+    }
     // priority rows without a split update (x updated inside the iteration, or no iteration at all): final
     // behind the last launch
     if (s->prio_on && s->prio_event && !prio_recorded) SCHWZ_HIP_TRY(hipEventRecord(s->prio_event, st));
@@ -1261,6 +1363,7 @@ int schwz_pcg_solve(schwz_pcg *s, const double *d_b, double *d_x, double rtol, i
     if (rc) return rc;
     if ((rc = pcg_iterate(s, d_x, rtol, max_iters, st))) return rc;
     if (h_iters || h_resnorm) {
+        if ((rc = pcg_finish_lazy(s))) return rc;
         SCHWZ_HIP_TRY(hipMemcpyAsync(&s->h_state[0], s->state, sizeof(CgState), hipMemcpyDeviceToHost, st));
         SCHWZ_HIP_TRY(hipStreamSynchronize(st));
         if (h_iters) *h_iters = s->h_state[0].iters;

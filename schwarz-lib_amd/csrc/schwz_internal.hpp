@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <memory>
 #include <string>
 #include <thread>
@@ -361,7 +362,8 @@ int pcg_begin(schwz_pcg *s, const double *d_b, double *d_x, double rtol, bool fu
 int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream_t st);
 int precond_apply(schwz_pcg *s, const double *in, double *out, hipStream_t st);
 int pcg_last_stats(schwz_pcg *s, int *h_iters, double *h_resnorm);  // device sync + state copy
-int pcg_take_trs_error(schwz_pcg *s);  // ILU(0) sweeps: trs_take_error of the factor solves
+int pcg_take_trs_error(schwz_pcg *s);
+int pcg_finish_lazy(schwz_pcg *s);  // the postponed residual update / state advance of the last solve, if any  // ILU(0) sweeps: trs_take_error of the factor solves
 }  // namespace schwz
 
 // ---- opaque ABI types -------------------------------------------------------
@@ -435,6 +437,26 @@ struct schwz_pcg {
     // in between, so that the halo pack + send can run beside the remaining update (schwz_ras_pack_early).
     // Without a deferred x update the event is recorded behind the last launch of the solve.
     bool prio_on = false;
+    // Second output of the LAST x update of a solve (cg_flush_x_kernel): rows [0, x2_rows) of the result also go
+    // to x2_out -- the restriction x~[interior] = y[interior] without a launch of its own.  x2_written: the last
+    // solve did write it (deferred x update; otherwise the caller copies).
+    double *x2_out = nullptr;
+    int64_t x2_rows = 0;
+    const double *x2_src = nullptr;  // rows [x2_rows, x2_total) of x2_out are copied from here (overlap / halo of x~)
+    int64_t x2_total = 0;
+    bool x2_written = false;
+    // A solve of exactly max_iters iterations (rtol == 0) whose last iteration was cut down to what its result
+    // needs: alpha of that iteration is formed inside the x update, and the residual update + state advance --
+    // whose results nothing reads unless the caller asks for the iteration count / residual norm -- wait in
+    // `lazy` until pcg_finish_lazy runs them (pcg_last_stats, schwz_pcg_solve with outputs) or the next solve
+    // drops them.
+    struct LazyLast {
+        bool pending = false;
+        int it = 0;
+        double rtol = 0.0;
+        hipStream_t stream = nullptr;
+    } lazy;
+    std::function<int(hipStream_t)> lazy_run;
     int64_t prio_lo = 0, prio_hi = 0;  // even
     hipEvent_t prio_event = nullptr;
     // how the last solve iterated: bits 0-1: 0 stored q, 1 q-free (three launches), 2 q-free with the fused
@@ -538,6 +560,7 @@ struct schwz_subdomain {
     int64_t nnz_interface = 0;
     schwz_idx *d_put_idx = nullptr, *d_get_idx = nullptr;  // local ids, packed
     double *d_x = nullptr;       // x~ [interior|overlap|halo]
+    double *d_x_alt = nullptr;   // the other x~ buffer: the last x update of a CG solve writes its interior, the restriction swaps the two
     double *d_rhs = nullptr;     // b_loc
     double *d_btilde = nullptr;  // b~ = local_solution on entry of the solve
     double *d_y = nullptr;       // init_guess / solve result

@@ -45,7 +45,7 @@ void schwz_subdomain_destroy(schwz_subdomain *sd)
         schwz_gmres_destroy(sd->gmres);
         schwz_trs_destroy(sd->trs);
         schwz_csr_destroy(sd->A);
-        void *ptrs[] = {sd->d_i_rp, sd->d_i_col, sd->d_i_val, sd->d_put_idx, sd->d_get_idx, sd->d_x,
+        void *ptrs[] = {sd->d_i_rp, sd->d_i_col, sd->d_i_val, sd->d_put_idx, sd->d_get_idx, sd->d_x, sd->d_x_alt,
                         sd->d_rhs, sd->d_btilde, sd->d_y, sd->d_partials};
         for (void *p : ptrs) (void)hipFree(p);
         if (sd->h_scalar) (void)hipHostFree(sd->h_scalar);
@@ -397,6 +397,33 @@ int schwz_ras_last_inner_stats(schwz_subdomain *sd, int *h_iters, double *h_resn
     return SCHWZ_OK;
 }
 
+// Step 4 inside step 3: the last x update of a CG solve also writes the interior rows into the OTHER x~ buffer
+// (schwz_pcg::x2_out) and copies the overlap / halo entries of the current one behind them, and schwz_ras_restrict
+// then only swaps the two buffers: the state after the restriction is the reference's.  A solve that is discarded (the verdict was "converged": no restriction) leaves
+// the current buffer untouched, like the reference, which breaks before the solve.  The second buffer is allocated
+// on first use; SCHWZ_RESTRICT_FUSE=0 keeps the copy launch.
+static void restrict_by_solver(schwz_subdomain *sd)
+{
+    const char *e = std::getenv("SCHWZ_RESTRICT_FUSE");  // read per solve: tests switch it
+    const bool on = !(e && e[0] == '0');
+    if (sd->cg) sd->cg->x2_out = nullptr;
+    if (!on || !sd->cg || sd->local_size == 0) return;
+    if (!sd->d_x_alt) {
+        const size_t nx = (size_t)std::max<int64_t>(sd->local_size_x + sd->halo_size, 1);
+        if (hipMalloc((void **)&sd->d_x_alt, nx * sizeof(double)) != hipSuccess ||
+            hipMemset(sd->d_x_alt, 0, nx * sizeof(double)) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(sd->d_x_alt);
+            sd->d_x_alt = nullptr;
+            return;
+        }
+    }
+    sd->cg->x2_out = sd->d_x_alt;
+    sd->cg->x2_rows = sd->local_size;
+    sd->cg->x2_src = sd->d_x;
+    sd->cg->x2_total = sd->local_size_x + sd->halo_size;
+}
+
 int schwz_ras_local_solve(schwz_subdomain *sd, int *h_inner_iters, schwz_stream stream)
 {
     REQUIRE_DEVICE(sd, "schwz_ras_local_solve");
@@ -409,6 +436,7 @@ int schwz_ras_local_solve(schwz_subdomain *sd, int *h_inner_iters, schwz_stream 
     if (sd->gmres)
         return schwz_gmres_solve(sd->gmres, sd->d_btilde, sd->d_y, sd->opt.local_tol, maxit, h_inner_iters, nullptr,
                                  stream);
+    restrict_by_solver(sd);
     return schwz_pcg_solve(sd->cg, sd->d_btilde, sd->d_y, sd->opt.local_tol, maxit, h_inner_iters, nullptr,
                            stream);
 }
@@ -429,6 +457,7 @@ int schwz_ras_check_and_solve_launch(schwz_subdomain *sd, schwz_stream stream)
     // (single subdomain): the check residual is then the CG start residual.
     const double *x2 = (sd->overlap_size == 0) ? nullptr : sd->d_x;
     const int maxit = sd->opt.local_max_iters == -1 ? (int)n : sd->opt.local_max_iters;
+    restrict_by_solver(sd);
     double *keep = sd->cg->d_norm_sq;
     sd->cg->d_norm_sq = sd->d_h_scalar;  // mapped pinned host memory, written by the kernel
     int rc = pcg_begin(sd->cg, sd->d_btilde, sd->d_y, sd->opt.local_tol, true, x2, n, st);
@@ -442,6 +471,13 @@ int schwz_ras_restrict(schwz_subdomain *sd, schwz_stream stream)
 {
     REQUIRE_DEVICE(sd, "schwz_ras_restrict");
     if (sd->local_size == 0) return SCHWZ_OK;
+    if (sd->cg && sd->cg->x2_written && sd->d_x_alt && sd->cg->x2_out == sd->d_x_alt) {
+        // the solve's last x update wrote y[interior] into the other buffer: it becomes x~
+        std::swap(sd->d_x, sd->d_x_alt);
+        sd->cg->x2_written = false;
+        sd->cg->x2_out = sd->d_x_alt;
+        return SCHWZ_OK;
+    }
     return launch_copy(sd->local_size, sd->d_y, sd->d_x, (hipStream_t)stream);
 }
 

@@ -941,3 +941,44 @@ def test_ras_from_a_matrix_file_with_distributed_ingest(schwz, oracle, torch_cud
     assert out["converged"] and out["iter_count"] == outs[0]["iters"]
     got = np.load(sol)
     assert np.abs(got - out["solution"]).max() <= 1e-12 * np.abs(out["solution"]).max()
+
+
+@pytest.mark.parametrize("case", ["walk_K6", "walk_K10", "walk_K16", "walk_K32", "plain_csr_K10", "walk_K10_P1"])
+def test_lazy_last_iteration_and_restriction_by_the_solver_are_bit_identical(schwz, oracle, torch_cuda, monkeypatch, case):
+    """Round 3, per-solve fixed costs of the fixed-work operating point (rtol = 0, exactly K iterations):
+      * the last iteration's residual update and state advance are not launched (nothing reads their results; alpha of
+        that iteration is formed inside the last x update) unless the caller asks for the iteration count / residual
+        norm -- then they run late, with the same results (schwz_pcg::LazyLast);
+      * the last x update writes y[interior] into the second x~ buffer and schwz_ras_restrict swaps the buffers
+        instead of copying.
+    Whole RAS runs with both switched off (SCHWZ_CG_LAZYLAST=0, SCHWZ_RESTRICT_FUSE=0) and on: residual histories and
+    solutions are the same bits; the inner statistics asked for after a lazy solve are those of the eager solve."""
+    torch = torch_cuda
+    K = int(case.split("_K")[1].split("_")[0])
+    P = 1 if case.endswith("_P1") else 3
+    if case.startswith("walk"):
+        for k, v in (("SCHWZ_SPMV_PATTERN", "2"), ("SCHWZ_SPMV_PAIR", "2"), ("SCHWZ_SPMV_SWEEP", "2"),
+                     ("SCHWZ_SWEEP_T", "512"), ("SCHWZ_CG_DEFERX", "2")):
+            monkeypatch.setenv(k, v)
+        shape, variant = (256, 4, 30), 0
+    else:
+        monkeypatch.setenv("SCHWZ_CG_DEFERX", "2")
+        shape, variant = (40, 33, 36), 6
+    runs = {}
+    for mode in ("eager", "lazy"):
+        monkeypatch.setenv("SCHWZ_CG_LAZYLAST", "0" if mode == "eager" else "1")
+        monkeypatch.setenv("SCHWZ_RESTRICT_FUSE", "0" if mode == "eager" else "1")
+        solver, m, out = _run_gpu(
+            schwz, P, dict(laplacian_dim=3, laplacian_shape=shape, spmv_variant=variant),
+            dict(tolerance=1e-6, max_iters=40, local_precond="block-jacobi", precond_max_block_size=1,
+                 local_solver_tolerance=0.0, local_max_iters=K))
+        stats = [sd.last_inner_stats() for sd in solver.subdomains.values()]
+        runs[mode] = (out["iter_count"], np.array(m.post_process_data["global_residual_vector_out"]),
+                      out["solution"].copy(), stats, [sd.cg_flavour() for sd in solver.subdomains.values()])
+        del solver
+    assert runs["eager"][0] == runs["lazy"][0]
+    assert np.array_equal(runs["eager"][1], runs["lazy"][1])
+    assert np.array_equal(runs["eager"][2], runs["lazy"][2])
+    assert runs["eager"][4] == runs["lazy"][4] and all(f & 4 for f in runs["lazy"][4])   # deferred x: the path in question
+    for (it_e, rn_e), (it_l, rn_l) in zip(runs["eager"][3], runs["lazy"][3]):
+        assert it_e == it_l == K and rn_e == rn_l
