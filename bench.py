@@ -372,7 +372,7 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
     mirror = None
-    if a.gpus == 1 and not a.no_mirror and "WORLD_SIZE" not in os.environ:
+    if a.gpus == 1 and not a.no_mirror and os.environ.get("WORLD_SIZE", "1") == "1":
         # a child process, finished before this process touches the GPU
         mirror = mirror_bench_ras(a.size, a.inner, a.mirror_iters)
     import torch

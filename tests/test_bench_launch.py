@@ -58,7 +58,7 @@ def test_bench_gpus_2_starts_itself_and_prints_one_line():
     with two GPUs the same command runs on RCCL.  Small slabs: this checks the launch path, the
     distributed branch and the shape of the line, not performance."""
     p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--slab", "48,40,16",
-                        "--no-cpu-baseline", "--ttr-budget-s", "20"],
+                        "--no-cpu-baseline", "--ttr-budget-s", "20", "--strong-grid", "48,40,32", "--strong-steps", "3"],
                        capture_output=True, text=True, timeout=900, env=_clean_env())
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
@@ -71,4 +71,7 @@ def test_bench_gpus_2_starts_itself_and_prints_one_line():
     backend = got["config"]["exchange_backend"]
     assert backend.startswith("nccl" if torch.cuda.device_count() >= 2 else "gloo")
     assert 0.0 < got["roofline"]["frac"] <= 1.0
+    # the strong-scaling leg of the same job: the fixed grid cut into N z-slabs
+    assert got["strong"]["grid"] == "48x40x32" and got["strong"]["subdomains"] == 2 and got["strong"]["outer_iter_per_s"] > 0
+    assert "mirror_bench_ras" not in got   # the C++ mirror's line belongs to the N = 1 run
     assert got["time_to_residual_converged"] and got["true_relative_residual"] < 1e-4
