@@ -170,6 +170,7 @@ struct CsrView {
     // read with one wave-uniform load instead of one byte per lane; first word 0xffff: more than 8
     // runs, the chunk's ids come from pair_id (nullptr: not built)
     const uint4 *pair_rle = nullptr;
+    int sweep_gen_mode = 0;  // z-sweep walk over planes that are not whole 512-row chunks: byte ids, partial last band
     int pair_rle_runs = 8;  // runs per chunk record: 8 (16 bytes) or 16 (32 bytes, x lines shorter than ~170 entries)
     const schwz_idx *chunk_ptable = nullptr; // per chunk of 512 rows: pair table id, -1 = not pair coded
     const uint8_t *chunk_dual = nullptr;     // per chunk: the fused dual residual needs its second product

@@ -610,7 +610,11 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
 // DUAL (with INIT): third partial bank = sum of r_i^2 over the chain positions NOT flagged in chain_dual -- the
 // part of the fused check residual ||b - A x2||^2 that coincides with the start residual; the flagged planes
 // are added by a listed kSpmvResidNorm launch on x2 (launch_spmv_pair).
-// RUNS: runs per chunk record of the pattern ids (8: 16 bytes, 16: 32 bytes; CsrView::pair_rle_runs)
+// RUNS: runs per chunk record of the pattern ids (8: 16 bytes, 16: 32 bytes; CsrView::pair_rle_runs); 0: planes that
+// are not whole 512-row chunks (PL % 512 != 0, round 3): the bands of a plane no longer coincide with the chunks
+// the records describe, so a lane reads its pair's pattern id as a byte (one coalesced load per 512 rows, requested
+// a plane ahead like the record), and the last band of a plane is partial: its lanes beyond the plane's end repeat
+// the band's last pair -- same loads, same value stored to the same address -- and add nothing to the sums.
 // (The three-positions-ahead halo schedule that pays in the fused direction launch below was measured here too,
 // with a third halo slot: no gain on 256- and 512-wide planes, where the p halo already hits L2 -- r is a
 // non-temporal stream in this launch and does not evict it --, and a loss wherever the larger ring costs a
@@ -654,6 +658,8 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
     const int4 sg = A.sweep_seg[blockIdx.x];
     const int64_t PL = A.sweep_pl;
     const int band = sg.x, z0 = sg.y, z1 = sg.z;  // chain positions z0 <= z < z1
+    constexpr bool GEN = RUNS == 0;
+    const int blen = GEN ? sg.w : T;               // rows of the band inside the plane (even)
     const int64_t gmax = A.ncols - 2;
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
     typedef const unsigned __attribute__((address_space(4))) *const_words;
@@ -699,15 +705,19 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
         };
         struct Ahead {
             pvd2 r, d;
-            unsigned w[RUNS / 2];
+            unsigned w[GEN ? 1 : RUNS / 2];
         };
         auto fetch = [&](int base, int h) -> Ahead {
             Ahead f;
             const int row0 = base + h * kPairRows;
-            const int ra = row0 + 2 * tid;
-            const const_words q = (const_words)(uintptr_t)(A.pair_rle + (row0 / kPairRows) * (RUNS / 8));
+            const int ra = GEN ? base + min(h * kPairRows + 2 * tid, blen - 2) : row0 + 2 * tid;
+            if (GEN) {
+                f.w[0] = A.pair_id[ra >> 1];
+            } else {
+                const const_words q = (const_words)(uintptr_t)(A.pair_rle + (row0 / kPairRows) * ((RUNS ? RUNS : 8) / 8));
 #pragma unroll
-            for (int k = 0; k < RUNS / 2; ++k) f.w[k] = q[k];
+                for (int k = 0; k < (GEN ? 1 : RUNS / 2); ++k) f.w[k] = q[k];
+            }
             f.r = __builtin_nontemporal_load(reinterpret_cast<const pvd2u *>(r_in + ra));
             if (DIAGVEC) f.d = __builtin_nontemporal_load(reinterpret_cast<const pvd2 *>(a.dinv + ra));
             return f;
@@ -761,10 +771,12 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
 #pragma unroll
             for (int h = 0; h < NH; ++h) {
                 const Ahead f = rr[h];
-                const int i0 = h * kPairRows + 2 * tid;  // position inside the band
+                const int i0u = h * kPairRows + 2 * tid;  // position inside the band
+                const bool valid = !GEN || i0u < blen;
+                const int i0 = GEN ? min(i0u, blen - 2) : i0u;
                 const int ra = brow[1] + i0;
                 // the id of the last run that starts at or before this lane's pair
-                int pid = (int)((f.w[0] >> 8) & 0xffu);
+                int pid = GEN ? (int)f.w[0] : (int)((f.w[0] >> 8) & 0xffu);
 #pragma unroll
                 for (int k = 1; k < RUNS; ++k) {
                     const unsigned e = (f.w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
@@ -799,12 +811,20 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
                 // r -= alpha q ; z = D^-1 r ; partial r.z and r.r  (kSpmvCgUpdate's epilogue, x deferred)
                 const double r0 = INIT ? f.r.x - s0 : f.r.x - cg_alpha * s0;
                 const double zz0 = a.diag_mode ? (DIAGVEC ? f.d.x : a.diag_uniform) * r0 : r0;
-                acc0 += r0 * zz0;
-                acc1 += r0 * r0;
                 const double r1 = INIT ? f.r.y - s1 : f.r.y - cg_alpha * s1;
                 const double zz1 = a.diag_mode ? (DIAGVEC ? f.d.y : a.diag_uniform) * r1 : r1;
-                acc0 += r1 * zz1;
-                acc1 += r1 * r1;
+                if (GEN) {
+                    const double t00 = r0 * zz0, t01 = r0 * r0, t10 = r1 * zz1, t11 = r1 * r1;
+                    acc0 += valid ? t00 : 0.0;
+                    acc1 += valid ? t01 : 0.0;
+                    acc0 += valid ? t10 : 0.0;
+                    acc1 += valid ? t11 : 0.0;
+                } else {
+                    acc0 += r0 * zz0;
+                    acc1 += r0 * r0;
+                    acc0 += r1 * zz1;
+                    acc1 += r1 * r1;
+                }
                 if (DUAL) {
                     const double q0 = r0 * r0, q1 = r1 * r1;
                     acc2 += plain_pos ? q0 : 0.0;
@@ -891,6 +911,8 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
     const int4 sg = A.sweep_seg_dir[blockIdx.x];  // (its own table: the band height may differ from the update launch's)
     const int64_t PL = A.sweep_pl;
     const int band = sg.x, z0 = sg.y, z1 = sg.z;
+    constexpr bool GEN = RUNS == 0;          // planes that are not whole chunks: byte ids, partial last band (see above)
+    const int blen = GEN ? sg.w : T;
     const int64_t gmax = A.ncols - 2;
     const pvd2 du = {a.diag_uniform, a.diag_uniform};
     double acc0 = 0.0;
@@ -919,10 +941,12 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
         struct Halo {
             pvd2 r[NHL], p[NHL];
         };
+        // (GEN: pieces beyond the band's rows inside the plane repeat its last piece)
+        auto piece_of = [&](int k) -> int { return GEN ? min(tid + k * kBlock, blen / 2 - 1) : tid + k * kBlock; };
         auto load_own = [&](int base, Own &o) {
 #pragma unroll
             for (int k = 0; k < NH; ++k) {
-                const int g = clampg(base + 2 * (tid + k * kBlock));
+                const int g = clampg(base + 2 * piece_of(k));
                 if (SCHWZ_DD & 4)
                     o.r[k] = *reinterpret_cast<const pvd2 *>(a.cg_r + g);
                 else
@@ -943,9 +967,9 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
                 *reinterpret_cast<pvd2 *>(slot_p + 2 * (tid + k * kBlock)) = v;
                 if (out) {
                     if (SCHWZ_DD & 1)
-                        __builtin_nontemporal_store(v, reinterpret_cast<pvd2 *>(a.y + base + 2 * (tid + k * kBlock)));
+                        __builtin_nontemporal_store(v, reinterpret_cast<pvd2 *>(a.y + base + 2 * piece_of(k)));
                     else
-                        __builtin_memcpy(a.y + base + 2 * (tid + k * kBlock), &v, 16);
+                        __builtin_memcpy(a.y + base + 2 * piece_of(k), &v, 16);
                 }
             }
         };
@@ -972,13 +996,17 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
             }
         };
         struct Rle {
-            unsigned w[RUNS / 2];
+            unsigned w[GEN ? 1 : RUNS / 2];
         };
         auto fetch_rle = [&](int base, int h) -> Rle {
-            const const_words q = (const_words)(uintptr_t)(A.pair_rle + ((base + h * kPairRows) / kPairRows) * (RUNS / 8));
             Rle f;
+            if (GEN) {
+                f.w[0] = A.pair_id[(base + min(h * kPairRows + 2 * tid, blen - 2)) >> 1];
+            } else {
+                const const_words q = (const_words)(uintptr_t)(A.pair_rle + ((base + h * kPairRows) / kPairRows) * ((RUNS ? RUNS : 8) / 8));
 #pragma unroll
-            for (int k = 0; k < RUNS / 2; ++k) f.w[k] = q[k];
+                for (int k = 0; k < (GEN ? 1 : RUNS / 2); ++k) f.w[k] = q[k];
+            }
             return f;
         };
         Own own_a, own_b;
@@ -1037,8 +1065,10 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
 #pragma unroll
             for (int h = 0; h < NH; ++h) {
                 const Rle f = rl[h];
-                const int i0 = h * kPairRows + 2 * tid;
-                int pid = (int)((f.w[0] >> 8) & 0xffu);
+                const int i0u = h * kPairRows + 2 * tid;
+                const bool valid = !GEN || i0u < blen;
+                const int i0 = GEN ? min(i0u, blen - 2) : i0u;
+                int pid = GEN ? (int)f.w[0] : (int)((f.w[0] >> 8) & 0xffu);
 #pragma unroll
                 for (int k = 1; k < RUNS; ++k) {
                     const unsigned e = (f.w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
@@ -1061,8 +1091,14 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
 #pragma unroll
                 for (int k = 0; k < 4; ++k) add(k, t[k]);
                 if (far & 0xc0) add(4, *reinterpret_cast<const pvd2 *>(fa1 + i0));
-                acc0 += t[0].x * s0;
-                acc0 += t[0].y * s1;
+                if (GEN) {
+                    const double u0 = t[0].x * s0, u1 = t[0].y * s1;
+                    acc0 += valid ? u0 : 0.0;
+                    acc0 += valid ? u1 : 0.0;
+                } else {
+                    acc0 += t[0].x * s0;
+                    acc0 += t[0].y * s1;
+                }
                 rl[h] = fetch_rle(rbase, h);
             }
 #pragma unroll
@@ -1130,6 +1166,11 @@ static bool launch_sweep_instance(const CsrView &A, const SpmvArgs &b, size_t ld
 template <int L_, int H_, bool DV, bool INIT, bool DUAL>
 static bool launch_sweep_variant(const CsrView &A, const SpmvArgs &b, size_t lds, hipStream_t s)
 {
+    if (A.sweep_gen_mode) {
+        // planes that are not whole chunks (byte ids, partial last band); no dual form there
+        if (DUAL) return false;
+        return launch_sweep_instance<L_, H_, DV, INIT, false, 0>(A, b, lds, s);
+    }
     return A.pair_rle_runs == 16 ? launch_sweep_instance<L_, H_, DV, INIT, DUAL, 16>(A, b, lds, s)
                                  : launch_sweep_instance<L_, H_, DV, INIT, DUAL, 8>(A, b, lds, s);
 }
@@ -1208,7 +1249,15 @@ int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hi
             set_error("launch_spmv_pair: the z-sweep kernels cannot have 96 KiB of dynamic LDS on this device");         \
             return SCHWZ_ERR_HIP;                                                                                        \
         }                                                                                                                \
-        if (A.pair_rle_runs == 16) {                                                                                     \
+        if (A.sweep_gen_mode) {                                                                                          \
+            static const hipError_t e3 = hipFuncSetAttribute((const void *)spmv_pair_dirdot_sweep_kernel<L_, H_, true, 0>, \
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);      \
+            if (e3 != hipSuccess) {                                                                                      \
+                set_error("launch_spmv_pair: the z-sweep kernels cannot have 96 KiB of dynamic LDS on this device");     \
+                return SCHWZ_ERR_HIP;                                                                                    \
+            }                                                                                                            \
+            hipLaunchKernelGGL((spmv_pair_dirdot_sweep_kernel<L_, H_, true, 0>), dim3(A.sweep_nslots_dir), dim3(kBlock), lds, s, A, b); \
+        } else if (A.pair_rle_runs == 16) {                                                                              \
             static const hipError_t e2 = hipFuncSetAttribute((const void *)spmv_pair_dirdot_sweep_kernel<L_, H_, true, 16>, \
                                                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);      \
             if (e2 != hipSuccess) {                                                                                      \
@@ -1296,7 +1345,15 @@ int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hi
             set_error("launch_spmv_pair: the z-sweep kernels cannot have 96 KiB of dynamic LDS on this device");         \
             return SCHWZ_ERR_HIP;                                                                                        \
         }                                                                                                                \
-        if (A.pair_rle_runs == 16) {                                                                                     \
+        if (A.sweep_gen_mode) {                                                                                          \
+            static const hipError_t e3 = hipFuncSetAttribute((const void *)spmv_pair_dirdot_sweep_kernel<L_, H_, false, 0>, \
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);      \
+            if (e3 != hipSuccess) {                                                                                      \
+                set_error("launch_spmv_pair: the z-sweep kernels cannot have 96 KiB of dynamic LDS on this device");     \
+                return SCHWZ_ERR_HIP;                                                                                    \
+            }                                                                                                            \
+            hipLaunchKernelGGL((spmv_pair_dirdot_sweep_kernel<L_, H_, false, 0>), dim3(A.sweep_nslots_dir), dim3(kBlock), lds, s, A, b); \
+        } else if (A.pair_rle_runs == 16) {                                                                              \
             static const hipError_t e2 = hipFuncSetAttribute((const void *)spmv_pair_dirdot_sweep_kernel<L_, H_, false, 16>, \
                                                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);      \
             if (e2 != hipSuccess) {                                                                                      \
@@ -1393,8 +1450,14 @@ static int build_sweep(schwz_csr *A, int64_t nrows, const PairTable &tb, const P
     const int sw_mode = sw_env ? std::atoi(sw_env) : 1;
     const int *cn = A->v.pair_canon;
     const int64_t NX = cn[5], PL = cn[6];
-    const bool shape_ok = cn[7] && cn[0] == -PL && cn[1] == -NX && NX >= 2 && PL > NX && NX % 2 == 0 && PL % kPairRows == 0 &&
-                          NX <= 1024;
+    // Planes of whole 512-row chunks: a band's sub-bands ARE chunks and the pattern ids come from the chunk's
+    // run-length record.  Any other even plane size (200 x 200, 300 x 300, ...; round 3): "gen mode" -- byte ids, a
+    // partial last band per plane, and the walk must cover the whole matrix (no companion launch: its unit is the
+    // chunk, and chunks straddle planes there).  SCHWZ_SWEEP_GEN=0: whole-chunk planes only.
+    const char *gen_env = std::getenv("SCHWZ_SWEEP_GEN");
+    const bool gen_mode = PL % kPairRows != 0;
+    const bool shape_ok = cn[7] && cn[0] == -PL && cn[1] == -NX && NX >= 2 && PL > NX && NX % 2 == 0 && PL % 2 == 0 &&
+                          NX <= 1024 && (!gen_mode || (!(gen_env && gen_env[0] == '0') && nrows % PL == 0 && PL >= kPairRows));
     if (sw_mode == 0 || !shape_ok || !(nrows >= (int64_t(1) << 20) || sw_mode == 2) || nrows < 3 * PL || nrows % 2 ||
         A->v.ncols != nrows || rle.empty())
         return SCHWZ_OK;
@@ -1418,7 +1481,9 @@ static int build_sweep(schwz_csr *A, int64_t nrows, const PairTable &tb, const P
     std::vector<std::vector<int>> plane_pats((size_t)nplanes);
     for (int k = 0; k < nplanes; ++k) {
         std::vector<uint8_t> used((size_t)tb.npat, 0);
-        for (int c = k * cpp; c < (k + 1) * cpp && plane_ok[(size_t)k]; ++c) {
+        if (gen_mode)  // the patterns of the plane's pairs, from the byte ids
+            for (int64_t pr = (int64_t)k * PL / 2; pr < (int64_t)(k + 1) * PL / 2; ++pr) used[(size_t)pair_id[(size_t)pr]] = 1;
+        for (int c = k * cpp; !gen_mode && c < (k + 1) * cpp && plane_ok[(size_t)k]; ++c) {
             const int R = A->v.pair_rle_runs;
             if (rle[(size_t)c * R] == 0xffffu) {  // ids must run-length code (scalar loads only)
                 plane_ok[(size_t)k] = 0;
@@ -1573,14 +1638,15 @@ static int build_sweep(schwz_csr *A, int64_t nrows, const PairTable &tb, const P
     const char *t_env = std::getenv("SCHWZ_SWEEP_T"), *l_env = std::getenv("SCHWZ_SWEEP_L");
     int T = t_env ? std::atoi(t_env) : (NX >= 512 ? 1024 : 512);
     if (T != 512 && T != 1024) T = 512;
-    if (PL % T) T = 512;
+    if (PL % T && !gen_mode) T = 512;
+    if (gen_mode && PL < T) T = 512;
     // dynamic LDS of the update / start walk: the ring (4 T own + 4 NX halo doubles) and the nine-slot tables of
     // every pattern; the launches raise the kernels' limit to 96 KiB.  Too many patterns for the tall band: the
     // short one; still too much: no walk (the chunk-by-chunk launches take the matrix).
     auto walk_lds = [&](int t) { return (size_t)(4 * t + 4 * NX) * sizeof(double) + (size_t)tb.npat * (9 * 16 + 4); };
     if (walk_lds(T) > (size_t)(96 << 10) && T == 1024 && PL % 512 == 0) T = 512;
     if (walk_lds(T) > (size_t)(96 << 10)) return SCHWZ_OK;
-    const int bands = (int)(PL / T);
+    const int bands = (int)((PL + T - 1) / T);  // (gen mode: the last band of a plane is partial)
     const int grid = (int)((std::min<int64_t>(ntiles, kMaxGrid) + kXcds - 1) / kXcds) * kXcds;
     struct Run { int p0, p1; };
     std::vector<Run> runs;
@@ -1601,12 +1667,19 @@ static int build_sweep(schwz_csr *A, int64_t nrows, const PairTable &tb, const P
     }
     if (runs.empty()) return SCHWZ_OK;
     std::vector<uint8_t> covered((size_t)nchunks, 0);
-    for (const Run &r : runs)
-        for (int p = r.p0; p < r.p1; ++p)
-            for (int c = 0; c < cpp; ++c) covered[(size_t)chain_plane[(size_t)p] * cpp + c] = 1;
     std::vector<schwz_idx> gen;
-    for (int c = 0; c < nchunks; ++c)
-        if (!covered[(size_t)c]) gen.push_back(c);
+    if (gen_mode) {
+        // every plane must be walked: nothing can be left to the chunk-by-chunk companion launch
+        int64_t walked = 0;
+        for (const Run &r : runs) walked += r.p1 - r.p0;
+        if (walked != nplanes) return SCHWZ_OK;
+    } else {
+        for (const Run &r : runs)
+            for (int p = r.p0; p < r.p1; ++p)
+                for (int c = 0; c < cpp; ++c) covered[(size_t)chain_plane[(size_t)p] * cpp + c] = 1;
+        for (int c = 0; c < nchunks; ++c)
+            if (!covered[(size_t)c]) gen.push_back(c);
+    }
     // segment length: about three segments per CU (two for bands of 1024 rows, which keep twice the loads
     // in flight) in ONE round of workgroups (measured on MI355X, 256^3 and 512 x 512 x 64; tools/sweep_ab.sh)
     int cus = 256;
@@ -1632,7 +1705,7 @@ static int build_sweep(schwz_csr *A, int64_t nrows, const PairTable &tb, const P
     struct Seg { int band, p0, p1; };
     // workgroup slots for bands of Tq rows and segments of about Lq chain positions
     auto make_slots = [&](int Tq, int Lq) -> std::vector<int4> {
-        const int bands_q = (int)(PL / Tq);
+        const int bands_q = (int)((PL + Tq - 1) / Tq);
         std::vector<Seg> segs;
         for (const Run &r : runs) {
             const int nseg = (r.p1 - r.p0 + Lq - 1) / Lq, len = (r.p1 - r.p0 + nseg - 1) / nseg;
@@ -1648,7 +1721,7 @@ static int build_sweep(schwz_csr *A, int64_t nrows, const PairTable &tb, const P
             v.x = sgm.band;
             v.y = sgm.p0;
             v.z = sgm.p1;
-            v.w = 0;
+            v.w = (int)std::min<int64_t>(Tq, PL - (int64_t)sgm.band * Tq);  // rows of the band inside the plane
             size_t x;
             if (bands_q >= 2 * kXcds) {
                 x = (size_t)((int64_t)sgm.band * kXcds / bands_q);
@@ -1684,12 +1757,12 @@ static int build_sweep(schwz_csr *A, int64_t nrows, const PairTable &tb, const P
     // 0.681 ms with 2048-row bands, 0.640 ms with 1024 (step 16.5 -> 16.0 ms; profiles/r03_c5slab_ab.txt).
     const char *td_env = std::getenv("SCHWZ_SWEEP_TDIR");
     int T_dir = td_env ? std::atoi(td_env) : (T == 512 ? 1024 : T);
-    if ((T_dir != 512 && T_dir != 1024 && T_dir != 2048) || PL % T_dir ||
+    if ((T_dir != 512 && T_dir != 1024 && T_dir != 2048) || (PL % T_dir && !gen_mode) || (gen_mode && PL < T_dir) ||
         (size_t)(4 * T_dir + ((SCHWZ_DD & 2) ? 3 : 2) * NX) * sizeof(double) + (size_t)tb.npat * 84 > (size_t)(96 << 10))
         T_dir = T;
     std::vector<int4> slots_dir;
     if (T_dir != T) {
-        const int bands_d = (int)(PL / T_dir);
+        const int bands_d = (int)((PL + T_dir - 1) / T_dir);
         int64_t steps_d = 0;
         for (const Run &r : runs) steps_d += (int64_t)(r.p1 - r.p0) * bands_d;
         const int per_cu_d = T_dir >= 2048 ? 1 : (T_dir == 1024 ? 2 : 3);
@@ -1731,6 +1804,7 @@ static int build_sweep(schwz_csr *A, int64_t nrows, const PairTable &tb, const P
         A->v.canon_sym_val = (const double *)A->d_canon_sym_val;
         A->v.canon_sym_mask = (const int *)A->d_canon_sym_mask;
     }
+    A->v.sweep_gen_mode = gen_mode ? 1 : 0;
     A->v.sweep_T = T;
     A->v.sweep_nx = (int)NX;
     A->v.sweep_pl = PL;
@@ -2210,7 +2284,7 @@ int pair_set_dual_split(schwz_csr *A, const schwz_idx *h_rp, const schwz_idx *h_
     A->v.chain_dual = nullptr;
     A->v.dual_chunks = nullptr;
     A->v.dual_nchunks = A->v.dual_blocks = 0;
-    if (A->v.sweep_nslots > 0 && !A->h_chain_plane.empty() && A->v.sweep_pl > 0) {
+    if (A->v.sweep_nslots > 0 && !A->h_chain_plane.empty() && A->v.sweep_pl > 0 && !A->v.sweep_gen_mode) {
         const int cpp = (int)(A->v.sweep_pl / kPairRows);
         std::vector<int> cdual(A->h_chain_plane.size(), 0);
         std::vector<schwz_idx> list;

@@ -1093,10 +1093,14 @@ void SchwarzBase<V, I, M>::run(std::shared_ptr<gko::matrix::Dense<V>> &solution)
     if (me == 0)
         std::cout << " [schwz] outer loop: " << m.iter_count << " iterations in " << elapsed << " s, cg flavour "
                   << schwz_ras_cg_flavour(im.sd) << std::endl;
-    if (!converged) {
-        std::cout << "Rank " << me << " did not converge in " << m.iter_count << " iterations." << std::endl;
-    } else {
-        std::cout << " Rank " << me << " converged in " << m.iter_count << " iterations " << std::endl;
+    {
+        // one write per rank: the ranks of a node share the terminal and a line must not be cut by another rank's
+        std::ostringstream line;
+        if (!converged)
+            line << "Rank " << me << " did not converge in " << m.iter_count << " iterations.\n";
+        else
+            line << " Rank " << me << " converged in " << m.iter_count << " iterations \n";
+        std::cout << line.str() << std::flush;
     }
     exchange();
     double part = 0.0, res_sq = 0.0, rhs_sq_loc = im.rhs_sq_interior, rhs_sq = 0.0;

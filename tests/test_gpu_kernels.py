@@ -1045,6 +1045,27 @@ def test_z_sweep_walk_on_random_grid_shapes(schwz, oracle, torch_cuda, monkeypat
     rng = np.random.default_rng(1000 + seed)
     nx = int(rng.choice([256, 256, 512, 1024]))
     ny = int(rng.choice({256: [4, 6, 8], 512: [4, 5, 6], 1024: [4, 5]}[nx]))  # whole chunks of 512 rows per plane
+    _walk_fuzz_case(schwz, oracle, torch, monkeypatch, rng, nx, ny)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SCHWZ_FUZZ_SEEDS", "10"))))
+def test_z_sweep_walk_on_planes_that_are_not_whole_chunks(schwz, oracle, torch_cuda, monkeypatch, seed):
+    """The same walk on planes whose size is not a multiple of the 512-row chunk (x lines of 96 ... 600 entries,
+    e.g. 200 x 9): the bands of a plane no longer coincide with the chunks, pattern ids are read as bytes, the
+    last band of every plane is partial (round 3, CsrView::sweep_gen_mode).  Same checks: bit identity of one CG
+    iteration with the chunk-by-chunk kernels, the solve that starts in the walk, 12 iterations against the
+    oracle; cubes and slabs with overlap."""
+    torch = torch_cuda
+    rng = np.random.default_rng(5000 + seed)
+    while True:
+        nx = int(rng.choice([96, 120, 200, 250, 300, 320, 384, 600]))
+        ny = int(rng.integers(3, 12))
+        if (nx * ny) % 512 != 0 and nx * ny >= 1024:
+            break
+    _walk_fuzz_case(schwz, oracle, torch, monkeypatch, rng, nx, ny, expect_gen=True)
+
+
+def _walk_fuzz_case(schwz, oracle, torch, monkeypatch, rng, nx, ny, expect_gen=False):
     nz = int(rng.integers(9, 30))
     P = int(rng.integers(1, 5))
     me = int(rng.integers(0, P))
@@ -1060,6 +1081,7 @@ def test_z_sweep_walk_on_random_grid_shapes(schwz, oracle, torch_cuda, monkeypat
     A = schwz.Csr(rp, col, val)
     assert A.format() == 3
     if A.sweep_slots() == 0:
+        assert not (expect_gen and P == 1), "a cube of even planes must walk: %dx%dx%d" % (nx, ny, nz)
         pytest.skip("no walk for %dx%dx%d, P=%d me=%d overlap=%d" % (nx, ny, nz, P, me, overlap))
     b = rng.standard_normal(n)
     x0 = 0.1 * rng.standard_normal(n)
