@@ -421,6 +421,7 @@ int schwz_csr_create(int64_t nrows, int64_t ncols, const schwz_idx *h_rp, const 
     // 0.379 -> 0.387 ms, 512 x 512 x 64 0.3955 -> 0.394 ms: like the BFS order, it saves bytes, not time --
     // the launch is not bound by the x lines it re-fetches.
     int brick_sh = -1;
+    int64_t plane_rows = 0, uniform_tiles = 0;  // (for the stream kernel's sequence on wide planes, below)
     {
         const bool brick_env = ord_env && ord_env[0] == '3';
         int64_t uniform = 0;
@@ -446,6 +447,8 @@ int schwz_csr_create(int64_t nrows, int64_t ncols, const schwz_idx *h_rp, const 
             }
             if (best * 2 > far.size()) PL = far[at];
         }
+        plane_rows = PL;
+        uniform_tiles = uniform;
         const int grid8 = std::max(1, (int)std::min<int64_t>(((int64_t)ntl + kXcds - 1) / kXcds * kXcds, kMaxGrid) / kXcds);
         if (brick_env && order.empty() && nrows == ncols && ntl >= 4 * kMaxGrid && uniform * 100 >= (int64_t)ntl * 95 &&
             PL >= 4 * kTileRows && PL % kTileRows == 0) {
@@ -543,6 +546,45 @@ int schwz_csr_create(int64_t nrows, int64_t ncols, const schwz_idx *h_rp, const 
     A->v.tile_row = (const schwz_idx *)A->d_tile;
     A->v.tile_nz = (const schwz_idx *)A->d_tile_nz;
     A->v.stream_cap = stream_cap;
+    // Wide planes (more than 2048 tiles = 512 K rows per plane, e.g. 1024 x 1024): with the block-cyclic deal an XCD
+    // sweeps its share of a whole plane before it comes back to the same in-plane position of the next one -- 512
+    // tiles = 12 MB of matrix stream later, long after the shared x lines have left its 4 MiB L2 (PMC traffic of the
+    // plain-CSR SpMV on 1024 x 1024 x 128: 1.17 x the CSR bytes, x lines fetched three times).  The sequence of every
+    // XCD is therefore laid out explicitly: its in-plane share in sub-stripes of 128 tiles, each sub-stripe through
+    // ALL planes before the next one, so that the +-plane neighbours of a tile are 128 positions away -- in flight
+    // together with it.  SCHWZ_STREAM_ORDER=0: the block-cyclic deal.
+    {
+        const char *so_env = std::getenv("SCHWZ_STREAM_ORDER");
+        const int ntl_s = (int)tiles.size() - 1;
+        const int64_t tpp = plane_rows > 0 && plane_rows % kTileRows == 0 ? plane_rows / kTileRows : 0;
+        if (stream_cap && !(so_env && so_env[0] == '0') && nrows == ncols && tpp > kMaxGrid && tpp % kXcds == 0 &&
+            ntl_s >= 4 * kMaxGrid && uniform_tiles * 100 >= (int64_t)ntl_s * 95) {
+            const int nplanes_s = (int)((ntl_s + tpp - 1) / tpp);
+            const int64_t w = tpp / kXcds;
+            const int64_t S = std::min<int64_t>(128, w);
+            std::vector<std::vector<schwz_idx>> seq((size_t)kXcds);
+            for (int x = 0; x < kXcds; ++x)
+                for (int64_t s0 = x * w; s0 < (x + 1) * w; s0 += S)
+                    for (int z = 0; z < nplanes_s; ++z)
+                        for (int64_t y = s0; y < std::min<int64_t>(s0 + S, (x + 1) * w); ++y) {
+                            const int64_t t = (int64_t)z * tpp + y;
+                            if (t < ntl_s) seq[(size_t)x].push_back((schwz_idx)t);
+                        }
+            size_t nper = 0, total = 0;
+            for (const auto &l : seq) {
+                nper = std::max(nper, l.size());
+                total += l.size();
+            }
+            if (total == (size_t)ntl_s) {
+                std::vector<schwz_idx> flat((size_t)kXcds * nper, -1);
+                for (int x = 0; x < kXcds; ++x) std::copy(seq[(size_t)x].begin(), seq[(size_t)x].end(), flat.begin() + (size_t)x * nper);
+                if (upload(flat.data(), flat.size(), &A->d_stream_order) == SCHWZ_OK) {
+                    A->v.stream_order = (const schwz_idx *)A->d_stream_order;
+                    A->v.stream_nper = (int)nper;
+                }
+            }
+        }
+    }
     if (stream_cap && (int)tiles.size() - 1 > kMaxGrid) {
         // scratch for the per-workgroup partial sums of the short-lived workgroups of spmv_stream.hip
         const int cap = (int)tiles.size() + 8 * kXcds;
@@ -602,6 +644,7 @@ void schwz_csr_destroy(schwz_csr *A)
     (void)hipFree(A->d_tile);
     (void)hipFree(A->d_tile_nz);
     (void)hipFree(A->d_stream_part);
+    (void)hipFree(A->d_stream_order);
     (void)hipFree(A->d_wtile);
     (void)hipFree(A->d_order);
     (void)hipFree(A->d_tile_dual);

@@ -141,6 +141,10 @@ struct CsrView {
     // fold (2 banks of stream_part_cap doubles; one launch at a time per matrix)
     double *stream_part = nullptr;
     int stream_part_cap = 0;
+    // spmv_stream.hip on wide planes: the tile sequence of every XCD, laid out explicitly (entry [xcd * stream_nper + j],
+    // -1 past the end) so that a tile's +-plane neighbours are close in the sequence; null: the block-cyclic deal
+    const schwz_idx *stream_order = nullptr;
+    int stream_nper = 0;
     int xcd_block = 0;  // tiles are dealt to the 8 XCDs block-cyclically in runs of this many (a power of two)
     int xcd_shift = 0;  // log2(xcd_block)
     // kSpmvResidDual: 1 where the tile's rows or columns reach past `dual_split` (where x2 may
@@ -374,6 +378,7 @@ struct schwz_csr {
     void *d_rp = nullptr, *d_col = nullptr, *d_val = nullptr, *d_tile = nullptr, *d_wtile = nullptr, *d_order = nullptr;
     void *d_tile_nz = nullptr;
     void *d_stream_part = nullptr;
+    void *d_stream_order = nullptr;
     void *d_code = nullptr, *d_vptr = nullptr, *d_dptr = nullptr, *d_vdict = nullptr, *d_ddict = nullptr;
     void *d_pat_id = nullptr, *d_tile_table = nullptr, *d_tbl_desc = nullptr, *d_tbl_len = nullptr, *d_tbl_val = nullptr,
          *d_tbl_delta = nullptr;

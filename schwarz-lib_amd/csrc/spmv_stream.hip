@@ -58,9 +58,19 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(CsrView A, SpmvArgs
     const int xcd = blockIdx.x % kXcds;
     const int slot = blockIdx.x / kXcds;
     const int per_xcd = gridDim.x / kXcds;
-    const int nslots = xcd_slots(A);
+    // an XCD's tile sequence: block-cyclic, or the explicit one of wide planes (CsrView::stream_order: entries past
+    // the end are -1, mapped to ntiles = "no tile" here); read through the scalar cache
+    typedef const int __attribute__((address_space(4))) *const_order;
+    const const_order sorder = (const_order)(uintptr_t)A.stream_order;
+    const int nslots = sorder ? A.stream_nper : xcd_slots(A);
     const int sh = A.xcd_shift;
-    auto tile_at = [&](int j) -> int { return ((j >> sh) << (sh + 3)) + (xcd << sh) + (j & (A.xcd_block - 1)); };
+    auto tile_at = [&](int j) -> int {
+        if (sorder) {
+            const int t = sorder[(int64_t)xcd * A.stream_nper + j];
+            return t < 0 ? A.ntiles : t;
+        }
+        return ((j >> sh) << (sh + 3)) + (xcd << sh) + (j & (A.xcd_block - 1));
+    };
     // tiles of this workgroup: k = 0 .. ntw - 1 (past-the-end slots only occur at the tail of the deal)
     // a.seq > 0: a workgroup takes a.seq CONSECUTIVE slots of its XCD's sequence and ends; the grid covers the
     // matrix once and the dispatch order keeps the active rows a compact window
@@ -264,7 +274,7 @@ int launch_spmv_stream_ablate(const CsrView &A, const SpmvArgs &a, int abl, hipS
     b.seq = se ? std::max(0, std::atoi(se)) : 0;
     if (b.seq) {
         const int sh = A.xcd_shift;
-        const int nslots = ((A.ntiles + (kXcds << sh) - 1) >> (sh + 3)) << sh;
+        const int nslots = A.stream_order ? A.stream_nper : ((A.ntiles + (kXcds << sh) - 1) >> (sh + 3)) << sh;
         g = kXcds * ((nslots + b.seq - 1) / b.seq);
     }
     switch (abl) {
@@ -343,7 +353,7 @@ int launch_spmv_stream(const CsrView &A, int mode, const SpmvArgs &a, int grid, 
     const int seq = stream_seq_max();
     if (seq && A.ntiles >= 4 * kMaxGrid) {
         const int sh = A.xcd_shift;
-        const int nslots = ((A.ntiles + (kXcds << sh) - 1) >> (sh + 3)) << sh;
+        const int nslots = A.stream_order ? A.stream_nper : ((A.ntiles + (kXcds << sh) - 1) >> (sh + 3)) << sh;
         const int g = kXcds * ((nslots + seq - 1) / seq);
         if (mode == kSpmvPlain || (A.stream_part && g <= A.stream_part_cap)) {
             b.seq = seq;

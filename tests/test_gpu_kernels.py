@@ -155,6 +155,44 @@ def test_plain_csr_stream_kernel_is_bit_identical_to_the_tiled_kernel(schwz, ora
     assert np.abs(got - exp).max() <= RTOL_CG * np.abs(exp).max()
 
 
+def test_plain_csr_stream_kernel_on_wide_planes(schwz, torch_cuda, monkeypatch):
+    """Planes of more than 2048 tiles (1024 x 1024): the stream kernel walks an explicit per-XCD tile sequence
+    (sub-stripes of 128 tiles through all planes, CsrView::stream_order) instead of the block-cyclic deal, in
+    short-lived workgroups.  Every tile exactly once: y bit for bit the tiled kernel's (variant 9), with the
+    sequence switched off as well, and the fused modes through three CG iterations on plain CSR."""
+    torch = torch_cuda
+    for k in ("SCHWZ_SPMV_PAIR", "SCHWZ_SPMV_PATTERN", "SCHWZ_SPMV_DICT"):
+        monkeypatch.setenv(k, "0")
+    shape = (1024, 1024, 9)
+    prob = schwz.Problem.laplacian(3, *shape)
+    sd = schwz.Subdomain(prob, 1, 0, 2, schwz.partition_regular(prob.N, 1))
+    rp, col, val = sd.local_matrix()
+    n = len(rp) - 1
+    x = torch.randn(n, dtype=torch.float64, device="cuda")
+    b = torch.randn(n, dtype=torch.float64, device="cuda")
+    ys, sols = {}, {}
+    for order in ("1", "0"):
+        monkeypatch.setenv("SCHWZ_STREAM_ORDER", order)
+        A = schwz.Csr(rp, col, val)
+        assert A.format() == 0
+        for variant in (6, 9):
+            y = torch.zeros(n, dtype=torch.float64, device="cuda")
+            A.spmv(x.data_ptr(), y.data_ptr(), 1.0, 0.0, variant=variant)
+            torch.cuda.synchronize()
+            ys[(order, variant)] = y
+        # start residual + q = A p with the fused dots (per-workgroup partial sums folded in another order)
+        cg = schwz.Pcg(A, 1)
+        xs = torch.zeros(n, dtype=torch.float64, device="cuda")
+        it, rn = cg.solve(b.data_ptr(), xs.data_ptr(), 0.0, 3)
+        assert it == 3
+        sols[order] = xs
+        del cg, A
+    ref = ys[("1", 9)]
+    for k, y in ys.items():
+        assert torch.equal(y, ref), k
+    assert float((sols["1"] - sols["0"]).abs().max()) <= 1e-12 * float(sols["0"].abs().max())
+
+
 def test_spmv_is_reproducible(schwz, oracle, torch_cuda):
     torch = torch_cuda
     rp, col, val = oracle.laplacian3d(40)
