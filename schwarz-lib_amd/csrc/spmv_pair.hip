@@ -1449,14 +1449,20 @@ static int build_sweep(schwz_csr *A, int64_t nrows, const PairTable &tb, const P
     const char *sw_env = std::getenv("SCHWZ_SPMV_SWEEP");
     const int sw_mode = sw_env ? std::atoi(sw_env) : 1;
     const int *cn = A->v.pair_canon;
-    const int64_t NX = cn[5], PL = cn[6];
+    // A 5-point (2-D) stencil {-N, -1, 0, +1, +N} in natural order is the same walk with the x LINE in the role of the
+    // plane: the canonical layout then repeats its outer offsets (cn[0] == cn[1] == -N, cn[5] == cn[6] == N), the
+    // +-N neighbours sit at the same position of the previous / next line (the far slots), and nothing couples rows
+    // +-NX apart inside a "plane" -- NX is only the width of the halo the kernels load around a band, 2 rows: the
+    // band's left and right neighbour.
+    const bool two_d = cn[7] && cn[5] == cn[6] && cn[0] == cn[1] && cn[6] > 2;
+    const int64_t NX = two_d ? 2 : cn[5], PL = cn[6];
     // Planes of whole 512-row chunks: a band's sub-bands ARE chunks and the pattern ids come from the chunk's
     // run-length record.  Any other even plane size (200 x 200, 300 x 300, ...; round 3): "gen mode" -- byte ids, a
     // partial last band per plane, and the walk must cover the whole matrix (no companion launch: its unit is the
     // chunk, and chunks straddle planes there).  SCHWZ_SWEEP_GEN=0: whole-chunk planes only.
     const char *gen_env = std::getenv("SCHWZ_SWEEP_GEN");
     const bool gen_mode = PL % kPairRows != 0;
-    const bool shape_ok = cn[7] && cn[0] == -PL && cn[1] == -NX && NX >= 2 && PL > NX && NX % 2 == 0 && PL % 2 == 0 &&
+    const bool shape_ok = cn[7] && cn[0] == -PL && (two_d || cn[1] == -NX) && NX >= 2 && PL > NX && NX % 2 == 0 && PL % 2 == 0 &&
                           NX <= 1024 && (!gen_mode || (!(gen_env && gen_env[0] == '0') && nrows % PL == 0 && PL >= kPairRows));
     if (sw_mode == 0 || !shape_ok || !(nrows >= (int64_t(1) << 20) || sw_mode == 2) || nrows < 3 * PL || nrows % 2 ||
         A->v.ncols != nrows || rle.empty())
@@ -1636,7 +1642,7 @@ static int build_sweep(schwz_csr *A, int64_t nrows, const PairTable &tb, const P
     }
     // ---- segments -----------------------------------------------------------------------------------
     const char *t_env = std::getenv("SCHWZ_SWEEP_T"), *l_env = std::getenv("SCHWZ_SWEEP_L");
-    int T = t_env ? std::atoi(t_env) : (NX >= 512 ? 1024 : 512);
+    int T = t_env ? std::atoi(t_env) : ((NX >= 512 || (two_d && PL % 1024 == 0)) ? 1024 : 512);
     if (T != 512 && T != 1024) T = 512;
     if (PL % T && !gen_mode) T = 512;
     if (gen_mode && PL < T) T = 512;

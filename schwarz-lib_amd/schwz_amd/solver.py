@@ -361,6 +361,17 @@ class SolverRAS:
             return core.rhs_random(ids)
         return np.ones(len(ids), dtype=np.float64)
 
+    def _rhs_is_ones(self):
+        return self._user_rhs is None and not (self.settings.enable_random_rhs and self.settings.explicit_laplacian
+                                                and self.settings.matrix_filename == "null")
+
+    def _rhs_first_rows(self, sd, count):
+        """rhs of the first `count` local rows of a subdomain; the all-ones default needs no global ids (the
+        local-to-global list of a 16.8 M-row subdomain is 134 MB to copy out of the library)."""
+        if self._rhs_is_ones():
+            return np.ones(int(count), dtype=np.float64)
+        return np.ascontiguousarray(self._rhs(sd.local_to_global[:count]), dtype=np.float64)
+
     def initialize(self, matrix=None, rhs=None):
         """SchwarzBase::initialize (schwarz_base.cpp:128-271).  `matrix` = (row_ptr, col, val) of
         the global system and `rhs` (ones when None), the same on every rank: the analogue of
@@ -390,7 +401,7 @@ class SolverRAS:
                 sd.add_put_list(q, ids)
         self.send_buf, self.recv_buf = {}, {}
         for me, sd in self.subdomains.items():
-            sd.to_device(sd.local_rhs(self._rhs), local_solver=solver_code, precond=precond_code,
+            sd.to_device(self._rhs_first_rows(sd, sd.local_size_x), local_solver=solver_code, precond=precond_code,
                          local_tol=m.local_solver_tolerance, local_max_iters=m.local_max_iters,
                          natural_factor_ordering=s.naturally_ordered_factor,
                          spmv_variant=s.spmv_variant, precond_block_size=m.precond_max_block_size,
@@ -1003,7 +1014,7 @@ class SolverRAS:
         parts = {me: sd.true_residual_sq(stream) for me, sd in locals_}
         res_sq = sum(comm.allgather_scalars(parts))
         rhs_sq = sum(comm.allgather_scalars(
-            {me: float(np.sum(self._rhs(sd.local_to_global[:sd.local_size]) ** 2))
+            {me: float(np.sum(self._rhs_first_rows(sd, sd.local_size) ** 2))
              for me, sd in locals_}))
         out["residual_norm"] = float(np.sqrt(res_sq))
         out["rhs_norm"] = float(np.sqrt(rhs_sq))
