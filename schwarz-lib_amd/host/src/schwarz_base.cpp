@@ -302,6 +302,11 @@ void SchwarzBase<V, I, M>::initialize()
                 SCHWZ_CALL(schwz_partition_regular2d((int64_t)std::llround(std::sqrt((double)N)), P, part.data()));
             else
                 SCHWZ_CALL(schwz_partition_graph(im.problem, P, part.data()));
+            if (s.write_debug_out && me == 0) {  // partition_tools.hpp:96-106
+                std::ofstream file("part_indices.csv");
+                file << "idx,subd\n";
+                for (int64_t i = 0; i < N; ++i) file << i << "," << part[(size_t)i] << "\n";
+            }
             std::vector<int64_t> perm((size_t)N);
             schwz_problem *permuted = nullptr;
             SCHWZ_CALL(schwz_problem_permute(im.problem, P, part.data(), perm.data(), first_row.data(), &permuted));
@@ -521,7 +526,49 @@ void SchwarzBase<V, I, M>::initialize()
     {
         const char *pm = std::getenv("SCHWZ_PUBLIC_MEMBERS");
         const bool never = pm && pm[0] == '0', always = pm && pm[0] == '1';
-        if (!never && (always || im.sizes[4] <= (int64_t(1) << 24))) materialize_public_members();
+        const bool dumps = s.print_matrices || s.write_perm_data || s.debug_print;
+        if (dumps || (!never && (always || im.sizes[4] <= (int64_t(1) << 24)))) materialize_public_members();
+    }
+    // The reference's debug output (executors other than "cuda": schwarz_base.cpp:252-257, solve.cpp:401-450):
+    // matrices as "row,col,value" lines with 1-based indices (utils.cpp:94-108), the factor permutation and its
+    // inverse one index per line, and the permutation check.
+    auto dump_matrix = [&](const std::shared_ptr<gko::matrix::Csr<V, I>> &mat, const char *name) {
+        if (!mat) return;
+        std::ofstream file(std::string(name) + "_" + std::to_string(me) + ".csv");
+        for (gko::size_type row = 0; row < mat->get_size()[0]; ++row)
+            for (auto j = mat->get_const_row_ptrs()[row]; j < mat->get_const_row_ptrs()[row + 1]; ++j)
+                file << row + 1 << "," << mat->get_const_col_idxs()[j] + 1 << "," << mat->get_const_values()[j] << "\n";
+    };
+    if (s.print_matrices) {
+        dump_matrix(local_matrix, "local_mat");
+        dump_matrix(interface_matrix, "int_mat");
+        dump_matrix(triangular_factor_u, "U_mat");
+        dump_matrix(triangular_factor_l, "L_mat");
+    }
+    if (local_perm && local_inv_perm) {
+        auto is_permutation = [](const gko::matrix::Permutation<I> &pm) {  // Utils::assert_correct_permutation
+            std::vector<char> seen(pm.get_permutation_size(), 0);
+            for (gko::size_type i = 0; i < pm.get_permutation_size(); ++i) {
+                const auto v = pm.get_const_permutation()[i];
+                if (v < 0 || (gko::size_type)v >= seen.size() || seen[(size_t)v]) return false;
+                seen[(size_t)v] = 1;
+            }
+            return true;
+        };
+        if (s.debug_print) {
+            std::ostringstream line;
+            line << " Rank " << me << " Permutation is " << (is_permutation(*local_perm) ? "correct" : "incorrect") << "\n"
+                 << " Rank " << me << " Inverse Permutation is " << (is_permutation(*local_inv_perm) ? "correct" : "incorrect")
+                 << "\n";
+            std::cout << line.str() << std::flush;
+        }
+        if (s.write_perm_data) {
+            std::ofstream fp("perm_" + std::to_string(me) + ".csv"), fi("inv_perm_" + std::to_string(me) + ".csv");
+            for (gko::size_type i = 0; i < local_perm->get_permutation_size(); ++i) {
+                fp << local_perm->get_const_permutation()[i] << "\n";
+                fi << local_inv_perm->get_const_permutation()[i] << "\n";
+            }
+        }
     }
 }
 

@@ -338,6 +338,11 @@ class SolverRAS:
                         raise capi.SchwzError(capi.ERR_INVALID,
                                               "partition_vector must hold one part id in [0, %d) per row "
                                               "(%d rows)" % (P, prob.N))
+            if P > 1 and s.write_debug_out and self.comm.is_root and part is not None:
+                # partition_tools.hpp:96-106
+                with open("part_indices.csv", "w") as f:
+                    f.write("idx,subd\n")
+                    f.writelines("%d,%d\n" % (i, p) for i, p in enumerate(np.asarray(part)))
             if P > 1:
                 prob, perm, first_row = prob.permute(part, P)
         else:
@@ -409,6 +414,8 @@ class SolverRAS:
             # use_mixed_precision (MixedValueType = float): halos travel as fp32
             self.send_buf[me] = be.empty(sd.num_send, s.use_mixed_precision)
             self.recv_buf[me] = be.empty(sd.num_recv, s.use_mixed_precision)
+        if s.print_matrices or s.write_perm_data or s.debug_print:
+            self._debug_dumps(solver_code)
         first = self.subdomains[comm.local_ranks[0]]
         m.local_size, m.local_size_x = first.local_size, first.local_size_x
         m.overlap_size, m.local_size_o = first.overlap_size, m.global_size
@@ -441,6 +448,40 @@ class SolverRAS:
             self._print(" Local max iters %d with restart iter %d" % (lmi, s.restart_iter))
         else:
             self._print(" Local direct solve with HIP TRS")
+
+    def _debug_dumps(self, solver_code):
+        """The reference's debug output for executors other than "cuda" (schwarz_base.cpp:252-257, solve.cpp:401-450,
+        utils.cpp:94-108): print_matrices -> local_mat_<rank>.csv / int_mat_<rank>.csv (and L_mat / U_mat of the
+        direct local solver) as 1-based "row,col,value" lines; write_perm_data -> perm_<rank>.csv / inv_perm_<rank>.csv
+        of the factor ordering; debug_print -> the permutation check."""
+        s = self.settings
+
+        def dump(name, me, rp, col, val):
+            rows = np.repeat(np.arange(len(rp) - 1), np.diff(rp))
+            with open("%s_%d.csv" % (name, me), "w") as f:
+                f.writelines("%d,%d,%.17g\n" % (r + 1, c + 1, v) for r, c, v in zip(rows, col, val))
+
+        for me, sd in self.subdomains.items():
+            rp, col, val = sd.local_matrix()
+            if s.print_matrices:
+                dump("local_mat", me, rp, col, val)
+                dump("int_mat", me, *sd.interface_matrix())
+            if solver_code != capi.SOLVER_DIRECT:
+                continue
+            f = core.cholesky(rp, col, val, s.naturally_ordered_factor)
+            if s.print_matrices:
+                dump("U_mat", me, f["u_rp"], f["u_col"], f["u_val"])
+                dump("L_mat", me, f["l_rp"], f["l_col"], f["l_val"])
+            perm = np.asarray(f["perm"])
+            inv = np.empty_like(perm)
+            inv[perm] = np.arange(len(perm), dtype=perm.dtype)
+            if s.debug_print:
+                ok = np.array_equal(np.sort(perm), np.arange(len(perm)))
+                self._print(" Rank %d Permutation is %s\n Rank %d Inverse Permutation is %s" %
+                            (me, "correct" if ok else "incorrect", me, "correct" if ok else "incorrect"))
+            if s.write_perm_data:
+                np.savetxt("perm_%d.csv" % me, perm, fmt="%d")
+                np.savetxt("inv_perm_%d.csv" % me, inv, fmt="%d")
 
     # -------------------------------------------------------------------- run
     def _log_local_solve(self, locals_):

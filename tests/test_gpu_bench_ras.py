@@ -393,3 +393,32 @@ def test_mirror_and_python_host_run_the_same_cg_launch_structure(schwz, torch_cu
     solver.run(gather_solution=False)
     flav = solver.subdomains[0].cg_flavour()
     assert flav == int(m.group(3)) and flav != 0, (flav, m.group(3))
+
+
+def test_bench_ras_debug_dumps(oracle, tmp_path):
+    """--print_matrices / --write_perm_data through the unchanged driver (schwarz_base.cpp:252-257, solve.cpp:401-450,
+    utils.cpp:94-108): local_mat_<rank>.csv / int_mat_<rank>.csv as 1-based "row,col,value" lines, L_mat / U_mat and
+    the factor permutation files of the direct local solver."""
+    n, P = 12, 2
+    _run(P, "--explicit_laplacian", "--set_1d_laplacian_size=%d" % n, "--enable_global_check", "--num_iters=200",
+         "--set_tol=1e-7", "--local_solver=direct-ginkgo", "--print_matrices", "--write_perm_data", cwd=str(tmp_path))
+    rp, col, val = oracle.laplacian2d(n)
+    N = n * n
+    for rank in range(P):
+        osd = oracle.Subdomain(rp, col, val, P, rank, 2, oracle.first_rows_regular(N, P).astype(np.int32))
+        lrp, lcol, lval = osd.local_matrix()
+        rows = [l.split(",") for l in (tmp_path / ("local_mat_%d.csv" % rank)).read_text().splitlines()]
+        assert len(rows) == len(lcol)
+        got_r = np.array([int(r[0]) for r in rows]) - 1
+        got_c = np.array([int(r[1]) for r in rows]) - 1
+        got_v = np.array([float(r[2]) for r in rows])
+        assert np.array_equal(got_r, np.repeat(np.arange(len(lrp) - 1), np.diff(lrp)))
+        assert np.array_equal(got_c, lcol) and np.allclose(got_v, lval)
+        assert (tmp_path / ("int_mat_%d.csv" % rank)).read_text().count("\n") == osd.nnz_interface
+        perm = np.array([int(t) for t in (tmp_path / ("perm_%d.csv" % rank)).read_text().split()])
+        inv = np.array([int(t) for t in (tmp_path / ("inv_perm_%d.csv" % rank)).read_text().split()])
+        assert sorted(perm) == list(range(len(lrp) - 1)) and np.array_equal(inv[perm], np.arange(len(perm)))
+        L = (tmp_path / ("L_mat_%d.csv" % rank)).read_text().splitlines()
+        U = (tmp_path / ("U_mat_%d.csv" % rank)).read_text().splitlines()
+        assert len(L) == len(U) >= len(lrp) - 1
+        assert all(int(l.split(",")[0]) >= int(l.split(",")[1]) for l in L)   # lower triangular

@@ -982,3 +982,29 @@ def test_lazy_last_iteration_and_restriction_by_the_solver_are_bit_identical(sch
     assert runs["eager"][4] == runs["lazy"][4] and all(f & 4 for f in runs["lazy"][4])   # deferred x: the path in question
     for (it_e, rn_e), (it_l, rn_l) in zip(runs["eager"][3], runs["lazy"][3]):
         assert it_e == it_l == K and rn_e == rn_l
+
+
+def test_debug_dumps_of_the_python_host(schwz, oracle, torch_cuda, tmp_path, monkeypatch):
+    """print_matrices / write_perm_data / debug_print (schwarz_base.cpp:252-257, solve.cpp:401-450): the files the
+    reference writes for executors other than "cuda", from the Python host, against the oracle's subdomains."""
+    monkeypatch.chdir(tmp_path)
+    n, P = 12, 2
+    s = schwz.Settings(print_matrices=True, write_perm_data=True, local_solver=schwz.SOLVER_DIRECT_GINKGO)
+    m = schwz.Metadata(oned_laplacian_size=n, num_subdomains=P, tolerance=1e-7, max_iters=200)
+    solver = schwz.SolverRAS(s, m, comm=schwz.InProcessComm(P), quiet=True)
+    solver.initialize()
+    rp, col, val = oracle.laplacian2d(n)
+    for rank in range(P):
+        osd = oracle.Subdomain(rp, col, val, P, rank, 2, oracle.first_rows_regular(n * n, P).astype(np.int32))
+        lrp, lcol, lval = osd.local_matrix()
+        rows = np.loadtxt(tmp_path / ("local_mat_%d.csv" % rank), delimiter=",")
+        assert np.array_equal(rows[:, 0] - 1, np.repeat(np.arange(len(lrp) - 1), np.diff(lrp)))
+        assert np.array_equal(rows[:, 1] - 1, lcol) and np.array_equal(rows[:, 2], lval)
+        assert (tmp_path / ("int_mat_%d.csv" % rank)).read_text().count("\n") == osd.nnz_interface
+        perm = np.loadtxt(tmp_path / ("perm_%d.csv" % rank), dtype=np.int64)
+        inv = np.loadtxt(tmp_path / ("inv_perm_%d.csv" % rank), dtype=np.int64)
+        assert np.array_equal(inv[perm], np.arange(len(perm)))
+        L = np.loadtxt(tmp_path / ("L_mat_%d.csv" % rank), delimiter=",")
+        assert (L[:, 0] >= L[:, 1]).all()
+    out = solver.run()
+    assert out["converged"]

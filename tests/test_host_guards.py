@@ -65,3 +65,25 @@ def test_onesided_run_says_which_protocol_runs(schwz, capsys):
     solver.run()
     out = capsys.readouterr().out
     assert "RMA flavour flags" in out and "without node windows" in out
+
+
+def test_partition_debug_file(tmp_path, monkeypatch):
+    """write_debug_out (partition_tools.hpp:96-106): part_indices.csv of a permuting partition, written before any
+    device is touched."""
+    import numpy as np
+    import schwz_amd as S
+    monkeypatch.chdir(tmp_path)
+    s = S.Settings(partition=S.PARTITION_REGULAR2D, write_debug_out=True)
+    m = S.Metadata(oned_laplacian_size=8, num_subdomains=4)
+
+    class _NoGpu:
+        problem_laplacian = staticmethod(S.Problem.laplacian)
+        partition_regular = staticmethod(S.partition_regular)
+        partition_regular2d = staticmethod(S.partition_regular2d)
+
+    solver = S.SolverRAS(s, m, comm=S.InProcessComm(4), backend=_NoGpu(), quiet=True)
+    prob = solver._partition(solver._setup_global_matrix())
+    lines = (tmp_path / "part_indices.csv").read_text().splitlines()
+    assert lines[0] == "idx,subd" and len(lines) == 65
+    part = np.array([int(l.split(",")[1]) for l in lines[1:]])
+    assert np.array_equal(np.bincount(part), [16, 16, 16, 16]) and prob.N == 64
