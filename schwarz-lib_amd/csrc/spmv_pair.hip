@@ -1446,6 +1446,15 @@ int upv(const std::vector<T> &h, void **d)
 static int build_sweep(schwz_csr *A, int64_t nrows, const PairTable &tb, const PairTable *ts,
                        const std::vector<uint8_t> &pair_id, const std::vector<uint16_t> &rle, int64_t ntiles)
 {
+    // SCHWZ_SWEEP_WHY=1: says on stderr why a matrix gets no z-sweep walk
+    auto no_walk = [](const char *why) {
+        static const bool say = [] {
+            const char *e = std::getenv("SCHWZ_SWEEP_WHY");
+            return e && e[0] == '1';
+        }();
+        if (say) std::fprintf(stderr, "[schwz] no z-sweep walk: %s\n", why);
+        return SCHWZ_OK;
+    };
     const char *sw_env = std::getenv("SCHWZ_SPMV_SWEEP");
     const int sw_mode = sw_env ? std::atoi(sw_env) : 1;
     const int *cn = A->v.pair_canon;
@@ -1464,9 +1473,12 @@ static int build_sweep(schwz_csr *A, int64_t nrows, const PairTable &tb, const P
     const bool gen_mode = PL % kPairRows != 0;
     const bool shape_ok = cn[7] && cn[0] == -PL && (two_d || cn[1] == -NX) && NX >= 2 && PL > NX && NX % 2 == 0 && PL % 2 == 0 &&
                           NX <= 1024 && (!gen_mode || (!(gen_env && gen_env[0] == '0') && nrows % PL == 0 && PL >= kPairRows));
-    if (sw_mode == 0 || !shape_ok || !(nrows >= (int64_t(1) << 20) || sw_mode == 2) || nrows < 3 * PL || nrows % 2 ||
-        A->v.ncols != nrows || rle.empty())
-        return SCHWZ_OK;
+    if (sw_mode == 0) return no_walk("switched off (SCHWZ_SPMV_SWEEP=0)");
+    if (!cn[7]) return no_walk("no canonical stencil layout (the patterns do not share one set of offsets)");
+    if (!shape_ok) return no_walk("offsets are not those of an x-y-z (or x-y) numbering with even line and plane sizes");
+    if (!(nrows >= (int64_t(1) << 20) || sw_mode == 2)) return no_walk("below 2^20 rows (SCHWZ_SPMV_SWEEP=2 walks anyway)");
+    if (nrows < 3 * PL || nrows % 2 || A->v.ncols != nrows) return no_walk("fewer than three planes, or not square");
+    if (rle.empty()) return no_walk("chunks have no run-length records");
     const int nchunks = (int)((nrows + kPairRows - 1) / kPairRows);
     const int nplanes = (int)(nrows / PL), cpp = (int)(PL / kPairRows);
     // ---- per plane: the far offsets its rows use -------------------------------------------------
@@ -1651,7 +1663,8 @@ static int build_sweep(schwz_csr *A, int64_t nrows, const PairTable &tb, const P
     // short one; still too much: no walk (the chunk-by-chunk launches take the matrix).
     auto walk_lds = [&](int t) { return (size_t)(4 * t + 4 * NX) * sizeof(double) + (size_t)tb.npat * (9 * 16 + 4); };
     if (walk_lds(T) > (size_t)(96 << 10) && T == 1024 && PL % 512 == 0) T = 512;
-    if (walk_lds(T) > (size_t)(96 << 10)) return SCHWZ_OK;
+    if (walk_lds(T) > (size_t)(96 << 10)) return no_walk("ring and pattern tables exceed 96 KiB of LDS");
+    if (NX > T) return no_walk("x line longer than a band");  // the halo of a band is NX rows either side: a band holds at least one x line
     const int bands = (int)((PL + T - 1) / T);  // (gen mode: the last band of a plane is partial)
     const int grid = (int)((std::min<int64_t>(ntiles, kMaxGrid) + kXcds - 1) / kXcds) * kXcds;
     struct Run { int p0, p1; };
@@ -1671,14 +1684,14 @@ static int build_sweep(schwz_csr *A, int64_t nrows, const PairTable &tb, const P
         }
         p = e;
     }
-    if (runs.empty()) return SCHWZ_OK;
+    if (runs.empty()) return no_walk("no chain of two or more walkable planes");
     std::vector<uint8_t> covered((size_t)nchunks, 0);
     std::vector<schwz_idx> gen;
     if (gen_mode) {
         // every plane must be walked: nothing can be left to the chunk-by-chunk companion launch
         int64_t walked = 0;
         for (const Run &r : runs) walked += r.p1 - r.p0;
-        if (walked != nplanes) return SCHWZ_OK;
+        if (walked != nplanes) return no_walk("planes that are not whole chunks: some plane cannot be walked (and nothing can be left to the chunk launches)");
     } else {
         for (const Run &r : runs)
             for (int p = r.p0; p < r.p1; ++p)
@@ -1792,7 +1805,8 @@ static int build_sweep(schwz_csr *A, int64_t nrows, const PairTable &tb, const P
     // --ttr-subdomains): +13 % time at 2.2 M rows, +2 % at 4.3 M, -18 % at 16.8 M; without left-out rows the
     // walk wins from 1 M rows on.
     const bool worth = gen.empty() || nrows >= 6000000 || sw_mode == 2;
-    if (!worth || (int64_t)slots_v.size() + gen_blocks > grid || steps * T * 2 < nrows) return SCHWZ_OK;
+    if (!worth || (int64_t)slots_v.size() + gen_blocks > grid || steps * T * 2 < nrows)
+        return no_walk("rows left to the companion launch on a small matrix, more segments than partial-sum slots, or less than half of the rows walkable");
     int rc;
     if (!slots_dir.empty() && (rc = upv(slots_dir, &A->d_sweep_seg_dir))) return rc;
     if ((rc = upv(slots_v, &A->d_sweep_seg)) || (rc = upv(gen, &A->d_sweep_gen)) || (rc = upv(cval, &A->d_canon_val)) ||

@@ -1134,7 +1134,9 @@ def _walk_fuzz_case(schwz, oracle, torch, monkeypatch, rng, nx, ny, expect_gen=F
         rp, col, val = oracle.laplacian3d(nx, ny, nz)
     else:
         rp, col, val = _slab_local_matrix(schwz, (nx, ny, nz * P), P, me, overlap=overlap)
-    _walk_checks(schwz, oracle, torch, monkeypatch, rng, rp, col, val, must_walk=expect_gen and P == 1,
+    # three lines per plane: two thirds of the rows sit on a y face, the commonest row pattern lacks a +-NX entry and the
+    # matrix gets no canonical 7-slot layout (spmv_pair.hip, "canonical stencil layout") -- the chunk kernels serve it
+    _walk_checks(schwz, oracle, torch, monkeypatch, rng, rp, col, val, must_walk=expect_gen and P == 1 and ny >= 4,
                  tag=(nx, ny, nz, P, me, overlap))
 
 
