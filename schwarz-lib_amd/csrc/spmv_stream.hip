@@ -248,8 +248,10 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_kernel(CsrView A, SpmvArgs
         if (acc0 == 123.456) a.y[tid] = acc0;  // keeps the sums alive
     }
     if (MODE != kSpmvPlain) {
+        // (one partial sum per WAVE instead -- no barrier at the end of a short-lived workgroup's life, four times
+        // the slots to fold -- measured the same step time, round 3)
         const double s0 = block_sum(acc0, red);
-        const double s1 = block_sum(acc1, red);
+        const double s1 = MODE == kSpmvDot ? 0.0 : block_sum(acc1, red);
         if (tid == 0) {
             a.partials[blockIdx.x] = s0;
             a.partials[a.part_stride + blockIdx.x] = s1;
@@ -292,8 +294,12 @@ int launch_spmv_stream_ablate(const CsrView &A, const SpmvArgs &a, int abl, hipS
 
 #endif  // SCHWZ_WITH_PROBES
 
-// Folds the per-workgroup partial sums of a launch of `nin` workgroups (two banks, `nin` apart) into the `nout`
-// slots per bank the consumers read: slot i = the sum of the workgroups i, i + nout, ... in that order.
+// Folds the partial sums of a launch (`nin` per bank: one per workgroup or per wave, two banks `nin` apart) into
+// the `nout` slots per bank the consumers read.  Slot i takes the partial sums i, i + nout, i + 2 nout, ...; eight
+// adjacent lanes share a slot (lane l sums every eighth of them, four loads in flight, then a fixed xor tree), so the
+// launch is a few dependent L2 round trips long whatever `nin` is.  Fixed order: reproducible bit for bit.
+constexpr int kFoldSub = 8;
+
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void spmv_stream_fold_kernel(const double *__restrict__ in, int nin,
                                                                   double *__restrict__ out, int nout,
@@ -302,19 +308,40 @@ __global__ __launch_bounds__(kBlock) void spmv_stream_fold_kernel(const double *
     if (MODE == kSpmvDot || MODE == kSpmvResidInit) {
         if (stop_iter && it >= *stop_iter) return;
     }
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= nout) return;
-    double s0 = 0.0, s1 = 0.0;
-    for (int j = i; j < nin; j += nout) {
-        s0 += in[j];
-        s1 += in[nin + j];
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    const int i = min(t / kFoldSub, nout - 1), l = t % kFoldSub;  // surplus lanes repeat the last slot (whole groups of 8)
+    constexpr bool two = MODE != kSpmvDot;                        // the p.q launch fills one bank
+    const int64_t step = (int64_t)nout * kFoldSub;
+    double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t j = i + (int64_t)nout * l; j < nin; j += 4 * step) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t ju = j + u * step;
+            const bool in_range = ju < nin;
+            const double a0 = in[in_range ? ju : j];
+            s0[u] += in_range ? a0 : 0.0;
+            if (two) {
+                const double a1 = in[nin + (in_range ? ju : j)];
+                s1[u] += in_range ? a1 : 0.0;
+            }
+        }
     }
-    out[i] = s0;
-    out[nout + i] = s1;
+    double v0 = (s0[0] + s0[1]) + (s0[2] + s0[3]);
+    double v1 = (s1[0] + s1[1]) + (s1[2] + s1[3]);
+#pragma unroll
+    for (int m = 1; m < kFoldSub; m <<= 1) {
+        v0 += __shfl_xor(v0, m, 64);
+        if (two) v1 += __shfl_xor(v1, m, 64);
+    }
+    if (l == 0 && t / kFoldSub < nout) {
+        out[i] = v0;
+        out[nout + i] = two ? v1 : 0.0;
+    }
 }
 
 // tiles per short-lived workgroup (SCHWZ_STREAM_SEQ; 0: the persistent form) and whether y leaves with
-// non-temporal stores (SCHWZ_STREAM_NTY: 0 never, 1 y = A x only, 2 the q = A p of the CG iteration as well)
+// non-temporal stores (SCHWZ_STREAM_NTY: 0 never, 1 y = A x only, 2 the q = A p of the CG iteration as well -- the
+// default: 0.5-1 % of the plain-CSR step on two boxes, profiles/r03_plainloop_ab.txt)
 static int stream_seq_max()
 {
     static const int v = [] {
@@ -328,7 +355,7 @@ static int stream_nty()
 {
     static const int v = [] {
         const char *e = std::getenv("SCHWZ_STREAM_NTY");
-        return e ? std::atoi(e) : 1;
+        return e ? std::atoi(e) : 2;
     }();
     return v;
 }
@@ -373,8 +400,8 @@ int launch_spmv_stream(const CsrView &A, int mode, const SpmvArgs &a, int grid, 
         else                                                                                                      \
             hipLaunchKernelGGL((spmv_stream_kernel<M, C, 0, false>), dim3(launch_grid), dim3(kBlock), 0, s, A, b); \
         if (fold)                                                                                                 \
-            hipLaunchKernelGGL((spmv_stream_fold_kernel<M>), dim3((grid + kBlock - 1) / kBlock), dim3(kBlock), 0, s, \
-                               (const double *)b.partials, launch_grid, a.partials, grid, a.stop_iter, a.it);    \
+            hipLaunchKernelGGL((spmv_stream_fold_kernel<M>), dim3((grid * kFoldSub + kBlock - 1) / kBlock), dim3(kBlock), 0, s, \
+                               (const double *)b.partials, b.part_stride, a.partials, grid, a.stop_iter, a.it);  \
     }
 #define SCHWZ_STREAM_MODE(M)                                  \
     if (A.stream_cap <= 8) SCHWZ_STREAM_CASE(M, 8)            \
