@@ -589,6 +589,29 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
     }
 }
 
+// SCHWZ_WALK_ZEROCOEF (build-time switch, round 3): the walks stage the slot tables into LDS with a coefficient of
+// +0.0 wherever a pattern has no entry and sum EVERY slot's product, instead of selecting +0.0 for the absent ones
+// by a mask bit (two bit tests and two 64-bit selects per slot and row pair: a third of the vector instructions of a
+// step).  The same bits: a sum that began at +0.0 is never -0.0, so adding the +-0.0 that (+0.0 x a finite operand)
+// yields leaves it unchanged, exactly like adding the selected +0.0.  The operands of absent slots are loaded vector
+// data (clamped addresses, windows of real planes), finite whenever the vector is; a vector holding Inf / NaN has a
+// NaN p.(A p) either way.  0 restores the masked sums.
+#ifndef SCHWZ_WALK_ZEROCOEF
+#define SCHWZ_WALK_ZEROCOEF 1
+#endif
+
+// SCHWZ_WALK_HINTS (build-time switch): 1 = the update walk's r is a non-temporal load and store and p' leaves the
+// fused launch with non-temporal stores; 0 = plain loads and stores.  On vectors of 135 MB (256^3, 512 x 512 x 64) the
+// hints win: in-box a plain r load in the update launch costs the FOLLOWING fused launch 4 us of 74, a plain r store
+// the update launch 3 us of 69.  Where r, p and p' fit the 256 MiB Infinity Cache together (192^3: 3 x 57 MB) they
+// LOSE 5 % of the step -- they give up the on-die copy the next launch would have read (profiles/r03_cache_hints.txt).
+// A per-launch choice was built and dropped: as a workgroup-uniform branch around the three accesses it cost 2.5 % of
+// the 256^3 step (the loop body is no longer one block), as a template parameter it doubles ~100 instantiations; no
+// configuration of BASELINE.json has vectors that small.
+#ifndef SCHWZ_WALK_HINTS
+#define SCHWZ_WALK_HINTS 1
+#endif
+
 // ---------------------------------------------------------------------------------------------------
 // z-sweep ("brick") walk of the q-free CG update launch for matrices in the canonical 3-D stencil layout
 // {-PL, -NX, -1, 0, +1, +NX, +PL} (CsrView::sweep_*).  tools/probes/brick_probe.hip priced the memory
@@ -646,7 +669,14 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
     typedef double pvd2u __attribute__((ext_vector_type(2), aligned(8)));
     const double *const r_in = INIT ? a.b : a.cg_r;
     double *const r_out = INIT ? a.y : a.cg_r;
-    for (int i = tid; i < A.canon_npat * 9; i += kBlock) cpv[i] = PairVal{A.canon_val[2 * i], A.canon_val[2 * i + 1]};
+    for (int i = tid; i < A.canon_npat * 9; i += kBlock) {
+        if (SCHWZ_WALK_ZEROCOEF) {
+            const int m = A.canon_mask[i / 9], k = i % 9;
+            cpv[i] = PairVal{((m >> k) & 1) ? A.canon_val[2 * i] : 0.0, ((m >> (16 + k)) & 1) ? A.canon_val[2 * i + 1] : 0.0};
+        } else {
+            cpv[i] = PairVal{A.canon_val[2 * i], A.canon_val[2 * i + 1]};
+        }
+    }
     if (tid < A.canon_npat) cmask[tid] = A.canon_mask[tid];
     // partial-sum slots no workgroup of this launch or of its companion writes
     if (blockIdx.x == 0)
@@ -718,7 +748,10 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
 #pragma unroll
                 for (int k = 0; k < (GEN ? 1 : RUNS / 2); ++k) f.w[k] = q[k];
             }
-            f.r = __builtin_nontemporal_load(reinterpret_cast<const pvd2u *>(r_in + ra));
+            if (SCHWZ_WALK_HINTS)
+                f.r = __builtin_nontemporal_load(reinterpret_cast<const pvd2u *>(r_in + ra));
+            else
+                f.r = *reinterpret_cast<const pvd2u *>(r_in + ra);
             if (DIAGVEC) f.d = __builtin_nontemporal_load(reinterpret_cast<const pvd2 *>(a.dinv + ra));
             return f;
         };
@@ -782,7 +815,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
                     const unsigned e = (f.w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
                     if ((unsigned)tid >= (e & 0xffu)) pid = (int)(e >> 8);
                 }
-                const int mask = cmask[pid];
+                const int mask = SCHWZ_WALK_ZEROCOEF ? 0 : cmask[pid];
                 pvd2 t[8];
                 t[4] = *reinterpret_cast<const pvd2 *>(cur + i0);
                 t[3].x = i0 > 0 ? cur[i0 - 1] : hlo[NX - 1];
@@ -800,8 +833,13 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
                 auto add = [&](int k, pvd2 tv) {
                     const PairVal v = cpv[pid * 9 + k];
                     const double p0 = v.a * tv.x, p1 = v.b * tv.y;
-                    s0 += ((mask >> k) & 1) ? p0 : 0.0;
-                    s1 += ((mask >> (16 + k)) & 1) ? p1 : 0.0;
+                    if (SCHWZ_WALK_ZEROCOEF) {
+                        s0 += p0;
+                        s1 += p1;
+                    } else {
+                        s0 += ((mask >> k) & 1) ? p0 : 0.0;
+                        s1 += ((mask >> (16 + k)) & 1) ? p1 : 0.0;
+                    }
                 };
                 add(0, t[0]);
                 if (far & 0x0c) add(1, *reinterpret_cast<const pvd2 *>(fb1 + i0));
@@ -831,7 +869,10 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
                     acc2 += plain_pos ? q1 : 0.0;
                 }
                 const pvd2 rn = {r0, r1};
-                __builtin_nontemporal_store(rn, reinterpret_cast<pvd2 *>(r_out + ra));
+                if (SCHWZ_WALK_HINTS)
+                    __builtin_nontemporal_store(rn, reinterpret_cast<pvd2 *>(r_out + ra));
+                else
+                    *reinterpret_cast<pvd2 *>(r_out + ra) = rn;
                 rr[h] = fetch(rbase, h);
             }
 #pragma unroll
@@ -902,7 +943,14 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
         cg_beta = cg_rho_new / a.cg_state->rho[a.it & 1];
     }
     const int tid = threadIdx.x;
-    for (int i = tid; i < A.canon_npat * 5; i += kBlock) cpv[i] = PairVal{A.canon_sym_val[2 * i], A.canon_sym_val[2 * i + 1]};
+    for (int i = tid; i < A.canon_npat * 5; i += kBlock) {
+        if (SCHWZ_WALK_ZEROCOEF) {
+            const int m = A.canon_sym_mask[i / 5], k = i % 5;
+            cpv[i] = PairVal{((m >> k) & 1) ? A.canon_sym_val[2 * i] : 0.0, ((m >> (16 + k)) & 1) ? A.canon_sym_val[2 * i + 1] : 0.0};
+        } else {
+            cpv[i] = PairVal{A.canon_sym_val[2 * i], A.canon_sym_val[2 * i + 1]};
+        }
+    }
     if (tid < A.canon_npat) cmask[tid] = A.canon_sym_mask[tid];
     if (blockIdx.x == 0)
         for (int i = (int)gridDim.x + a.part_offset + tid; i < a.part_stride; i += kBlock)
@@ -966,7 +1014,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
                 const pvd2 v = newp(o.r[k], o.p[k]);
                 *reinterpret_cast<pvd2 *>(slot_p + 2 * (tid + k * kBlock)) = v;
                 if (out) {
-                    if (SCHWZ_DD & 1)
+                    if ((SCHWZ_DD & 1) && SCHWZ_WALK_HINTS)
                         __builtin_nontemporal_store(v, reinterpret_cast<pvd2 *>(a.y + base + 2 * piece_of(k)));
                     else
                         __builtin_memcpy(a.y + base + 2 * piece_of(k), &v, 16);
@@ -1074,7 +1122,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
                     const unsigned e = (f.w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
                     if ((unsigned)tid >= (e & 0xffu)) pid = (int)(e >> 8);
                 }
-                const int mask = cmask[pid];
+                const int mask = SCHWZ_WALK_ZEROCOEF ? 0 : cmask[pid];
                 pvd2 t[4];
                 t[0] = *reinterpret_cast<const pvd2 *>(cur + i0);
                 t[1].x = t[0].y;
@@ -1085,8 +1133,13 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
                 auto add = [&](int k, pvd2 tv) {
                     const PairVal v = cpv[pid * 5 + k];
                     const double p0 = v.a * tv.x, p1 = v.b * tv.y;
-                    s0 += ((mask >> k) & 1) ? p0 : 0.0;
-                    s1 += ((mask >> (16 + k)) & 1) ? p1 : 0.0;
+                    if (SCHWZ_WALK_ZEROCOEF) {
+                        s0 += p0;
+                        s1 += p1;
+                    } else {
+                        s0 += ((mask >> k) & 1) ? p0 : 0.0;
+                        s1 += ((mask >> (16 + k)) & 1) ? p1 : 0.0;
+                    }
                 };
 #pragma unroll
                 for (int k = 0; k < 4; ++k) add(k, t[k]);
