@@ -437,6 +437,12 @@ int schwz_ras_last_inner_stats(schwz_subdomain *sd, int *h_iters, double *h_resn
  * one matrix read), the norm's device->host copy is queued right behind it and
  * the CG iterations behind that.  Follow with schwz_ras_local_residual_wait. */
 int schwz_ras_check_and_solve_launch(schwz_subdomain *sd, schwz_stream stream);
+/* The input of a DEVICE-side all-gather of the residual norms (the MPI_Allgather of source/solve.cpp:890-891 as
+ * an RCCL collective): makes `stream` wait for the norm of the last schwz_ras_local_residual_launch /
+ * schwz_ras_check_and_solve_launch -- for that scalar only, not for the local solve enqueued behind the check --
+ * and writes its SQUARE to d_norm_sq[0] (device memory) on that stream.  The host value stays available through
+ * schwz_ras_local_residual_wait. */
+int schwz_ras_norm_sq_to_device(schwz_subdomain *sd, double *d_norm_sq, schwz_stream stream);
 /* step 4: x~[interior] = y[0:local_size] (Communicate::local_to_global_vector,
  * source/communicate.cpp:65-94) */
 int schwz_ras_restrict(schwz_subdomain *sd, schwz_stream stream);

@@ -30,7 +30,7 @@ void set_error(const std::string &msg) { g_last_error = msg; }
 bool csr_is_well_formed(int64_t nrows, int64_t ncols, const schwz_idx *rp, const schwz_idx *col)
 {
     bool ok = true;
-#pragma omp parallel for schedule(static) reduction(&& : ok)
+#pragma omp parallel for schedule(static) reduction(&& : ok) num_threads(schwz::setup_threads())
     for (int64_t i = 0; i < nrows; ++i) {
         bool row_ok = rp[i + 1] >= rp[i];
         for (schwz_idx j = rp[i]; row_ok && j < rp[i + 1]; ++j) row_ok = col[j] >= 0 && col[j] < ncols;
@@ -46,7 +46,7 @@ bool csr_is_symmetric(int64_t nrows, int64_t ncols, const schwz_idx *rp, const s
     if (nrows != ncols) return false;
     bool ok = true;
     int64_t upper = 0, lower = 0;
-#pragma omp parallel for schedule(static) reduction(&& : ok) reduction(+ : upper, lower)
+#pragma omp parallel for schedule(static) reduction(&& : ok) reduction(+ : upper, lower) num_threads(schwz::setup_threads())
     for (int64_t i = 0; i < nrows; ++i) {
         if (!ok) continue;
         for (schwz_idx j = rp[i]; j < rp[i + 1]; ++j) {
@@ -1008,31 +1008,54 @@ int schwz_subdomain_setup(const schwz_problem *p, int P, int me, int overlap, co
     std::vector<double> v((size_t)mr);
     auto &l2g = sd->l2g;
     // interior ids are implicit; l2g stores them anyway for the callers
-    l2g.resize((size_t)sd->local_size);
-    std::iota(l2g.begin(), l2g.end(), lo);
+    l2g.reserve((size_t)sd->local_size + (size_t)(sd->local_size / 8) + 1024);  // (room for the overlap and halo ids)
+    l2g.resize((size_t)sd->local_size);  // no value-initialisation: the threads below touch the pages first
+#pragma omp parallel for schedule(static) num_threads(schwz::setup_threads())
+    for (int64_t i = 0; i < sd->local_size; ++i) l2g[(size_t)i] = lo + i;
     // overlap-1 BFS layers in discovery order (:166-180).  The candidates of a layer -- columns outside the
     // interior range -- are collected by all threads over contiguous blocks of the layer's rows and visited block
     // after block, i.e. in row order then column order like the sequential loop: the same discovery order.
     StageTimer t_bfs("  setup: overlap layers");
     int64_t old = 0;
+    // An analytic stencil knows its bandwidth (nx, or nx * ny): an interior row can only reach outside [lo, hi) from
+    // the first or the last `band` rows of the range, so the scan of the interior skips everything between them
+    // (16.6 of 16.8 M rows at 256^3, where the scan used to be a quarter of this function's time).
+    const int64_t band = p->kind == 2 ? p->nx : (p->kind == 3 ? p->nx * p->ny : -1);
     auto grow_layer = [&](int64_t from, int64_t to) {
-        int nthreads = 1;
-#pragma omp parallel
-        {
-#pragma omp single
-            nthreads = omp_get_num_threads();
+        // the rows to scan, as up to three ascending ranges of local indices
+        int64_t rb[3][2];
+        int nr = 0;
+        const int64_t ie = std::min(to, sd->local_size);  // end of the interior part of [from, to)
+        if (from < ie) {
+            if (band >= 0 && ie - from > 2 * band) {
+                const int64_t low_end = std::max(from, std::min(ie, band));
+                const int64_t high_begin = std::max(low_end, sd->local_size - band);
+                if (from < low_end) rb[nr][0] = from, rb[nr][1] = low_end, ++nr;
+                if (high_begin < ie) rb[nr][0] = high_begin, rb[nr][1] = ie, ++nr;
+            } else {
+                rb[nr][0] = from, rb[nr][1] = ie, ++nr;
+            }
         }
-        if (to - from < 4096) nthreads = 1;
+        if (std::max(from, ie) < to) rb[nr][0] = std::max(from, ie), rb[nr][1] = to, ++nr;
+        int64_t total = 0;
+        for (int k = 0; k < nr; ++k) total += rb[k][1] - rb[k][0];
+        auto row_at = [&](int64_t pos) {
+            int k = 0;
+            while (k + 1 < nr && pos >= rb[k][1] - rb[k][0]) pos -= rb[k][1] - rb[k][0], ++k;
+            return rb[k][0] + pos;
+        };
+        int nthreads = schwz::setup_threads();
+        if (total < 4096) nthreads = 1;
         std::vector<std::vector<int64_t>> cand((size_t)nthreads);
 #pragma omp parallel num_threads(nthreads)
         {
             const int t = omp_get_thread_num();
-            const int64_t a = from + (to - from) * t / nthreads, b = from + (to - from) * (t + 1) / nthreads;
+            const int64_t a = total * t / nthreads, b = total * (t + 1) / nthreads;
             std::vector<int64_t> cc((size_t)mr);
             std::vector<double> vv((size_t)mr);
             auto &mine = cand[(size_t)t];
-            for (int64_t i = a; i < b; ++i) {
-                const int len = p->row(l2g[(size_t)i], cc.data(), vv.data());
+            for (int64_t q = a; q < b; ++q) {
+                const int len = p->row(l2g[(size_t)row_at(q)], cc.data(), vv.data());
                 for (int j = 0; j < len; ++j)
                     if (cc[j] < lo || cc[j] >= hi) mine.push_back(cc[j]);
             }
@@ -1058,15 +1081,17 @@ int schwz_subdomain_setup(const schwz_problem *p, int P, int me, int overlap, co
     // local / interface split (:194-284).  Entries of interior rows whose column
     // is unmapped ("invalid edge", only possible for overlap == 1) are dropped
     // like the reference does.
-    sd->l_rp.assign((size_t)n + 1, 0);
-    sd->i_rp.assign((size_t)n + 1, 0);
+    sd->l_rp.resize((size_t)n + 1);
+    sd->i_rp.resize((size_t)n + 1);
+#pragma omp parallel for schedule(static) num_threads(schwz::setup_threads())
+    for (int64_t r = 0; r <= n; ++r) sd->l_rp[(size_t)r] = sd->i_rp[(size_t)r] = 0;
     std::vector<schwz_idx> lc((size_t)mr);
     std::vector<double> lv((size_t)mr);
     int64_t nnz_l = 0;
     {
         // entries per row (all threads), then the running sum
         std::vector<int> cnt((size_t)n, 0);
-#pragma omp parallel for schedule(static) firstprivate(c, v)
+#pragma omp parallel for schedule(static) firstprivate(c, v) num_threads(schwz::setup_threads())
         for (int64_t r = 0; r < n; ++r) {
             const int len = p->row(l2g[(size_t)r], c.data(), v.data());
             int k = 0;
@@ -1087,7 +1112,7 @@ int schwz_subdomain_setup(const schwz_problem *p, int P, int me, int overlap, co
     StageTimer t_fill("  setup: local matrix fill");
     sd->l_col.resize((size_t)nnz_l);
     sd->l_val.resize((size_t)nnz_l);
-#pragma omp parallel for schedule(static) firstprivate(c, v)
+#pragma omp parallel for schedule(static) firstprivate(c, v) num_threads(schwz::setup_threads())
     for (int64_t r = 0; r < n; ++r) {
         const int len = p->row(l2g[(size_t)r], c.data(), v.data());
         int64_t pos = sd->l_rp[(size_t)r];
@@ -1448,7 +1473,7 @@ int schwz_isai(int64_t n, const schwz_idx *rp, const schwz_idx *col, const doubl
         return (it != e && *it == c) ? val[it - col] : 0.0;
     };
     bool singular = false;
-#pragma omp parallel for schedule(dynamic, 1024) reduction(|| : singular)
+#pragma omp parallel for schedule(dynamic, 1024) reduction(|| : singular) num_threads(schwz::setup_threads())
     for (int64_t i = 0; i < n; ++i) {
         const schwz_idx s0 = rp[i], k = rp[i + 1] - rp[i];
         const schwz_idx *S = col + s0;

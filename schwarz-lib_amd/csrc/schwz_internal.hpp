@@ -14,6 +14,7 @@
 #include <functional>
 #include <memory>
 #include <string>
+#include <sys/mman.h>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -37,24 +38,85 @@ struct NoInitAlloc : std::allocator<T> {
     void construct(U *p) { ::new ((void *)p) U; }
     template <typename U, typename... Args>
     void construct(U *p, Args &&...args) { ::new ((void *)p) U(std::forward<Args>(args)...); }
+    // Large blocks (the local matrix: 1.4 GB at 256^3) come 2 MiB-aligned and marked for transparent huge pages:
+    // their first touch is then one fault per 2 MiB instead of 512 -- on a kernel in `madvise` mode the setup's
+    // page faults were a third of its time (SCHWZ_SETUP_HUGEPAGES=0: plain operator new).
+    static bool huge_pages()
+    {
+        static const bool v = [] {
+            const char *e = std::getenv("SCHWZ_SETUP_HUGEPAGES");
+            return !(e && e[0] == '0');
+        }();
+        return v;
+    }
+    static constexpr size_t kHugeMin = size_t(8) << 20, kHugeAlign = size_t(2) << 20;
+    T *allocate(size_t n)
+    {
+        const size_t bytes = n * sizeof(T);
+        if (bytes >= kHugeMin && huge_pages()) {
+            void *p = nullptr;
+            const size_t padded = (bytes + kHugeAlign - 1) / kHugeAlign * kHugeAlign;
+            if (posix_memalign(&p, kHugeAlign, padded) == 0) {
+                (void)madvise(p, padded, MADV_HUGEPAGE);
+                return static_cast<T *>(p);
+            }
+        }
+        return static_cast<T *>(::operator new(bytes));
+    }
+    void deallocate(T *p, size_t n)
+    {
+        if (n * sizeof(T) >= kHugeMin && huge_pages())
+            std::free(p);
+        else
+            ::operator delete(p);
+    }
 };
 
+// Threads for the host-side setup loops: SCHWZ_SETUP_THREADS, else the smallest of the CPUs this process may run on,
+// its cgroup CPU quota (a GPU box shows all 256 hardware threads of the host to a job that may use 16 of them:
+// an OpenMP team of 256 on that quota made every setup stage 2-5 x slower and erratic) and 32.
+inline int setup_threads()
+{
+    static const int v = [] {
+        const char *e = std::getenv("SCHWZ_SETUP_THREADS");
+        int n = e ? std::atoi(e) : 0;
+        if (n > 0) return n > 256 ? 256 : n;
+        cpu_set_t set;
+        n = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
+        auto quota = [](const char *path_quota, const char *path_period) -> double {
+            // cgroup v2: "cpu.max" holds "<quota|max> <period>"; v1: two files
+            double q = -1.0, per = -1.0;
+            if (FILE *f = std::fopen(path_quota, "r")) {
+                char word[64] = {0};
+                if (path_period == nullptr) {
+                    if (std::fscanf(f, "%63s %lf", word, &per) == 2 && word[0] != 'm') q = std::atof(word);
+                } else if (std::fscanf(f, "%lf", &q) != 1) {
+                    q = -1.0;
+                }
+                std::fclose(f);
+            }
+            if (path_period)
+                if (FILE *f = std::fopen(path_period, "r")) {
+                    if (std::fscanf(f, "%lf", &per) != 1) per = -1.0;
+                    std::fclose(f);
+                }
+            return q > 0.0 && per > 0.0 ? q / per : -1.0;
+        };
+        double cpus = quota("/sys/fs/cgroup/cpu.max", nullptr);
+        if (cpus <= 0.0) cpus = quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+        if (cpus > 0.0) n = std::min(n, (int)(cpus + 0.999));
+        return n < 1 ? 1 : (n > 32 ? 32 : n);
+    }();
+    return v;
+}
+
 // Host-side setup loops of the .hip translation units (hipcc builds them without an OpenMP runtime): fn(t, nt,
-// begin, end) on nt threads over contiguous blocks of [0, n), thread t taking the t-th block.  nt = the
-// hardware threads available to the process, at most 32 (SCHWZ_SETUP_THREADS overrides), 1 below min_per_thread
-// items per thread.  Returns nt.
+// begin, end) on nt threads over contiguous blocks of [0, n), thread t taking the t-th block.  nt = setup_threads(),
+// 1 below min_per_thread items per thread.  Returns nt.
 template <typename F>
 inline int parallel_blocks(int64_t n, int64_t min_per_thread, F fn)
 {
-    static const int cap = [] {
-        const char *e = std::getenv("SCHWZ_SETUP_THREADS");
-        int v = e ? std::atoi(e) : 0;
-        if (v <= 0) {
-            cpu_set_t set;
-            v = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
-        }
-        return v < 1 ? 1 : (v > 32 ? 32 : v);
-    }();
+    const int cap = setup_threads();
     int nt = (int)std::min<int64_t>(cap, n / std::max<int64_t>(min_per_thread, 1));
     if (nt < 1) nt = 1;
     if (nt == 1) {
@@ -534,14 +596,14 @@ struct schwz_subdomain {
     int64_t N = 0;
     std::vector<int64_t> first_row;
     int64_t local_size = 0, local_size_x = 0, overlap_size = 0, halo_size = 0;
-    std::vector<int64_t> l2g;                      // local_size_x + halo
+    std::vector<int64_t, schwz::NoInitAlloc<int64_t>> l2g;  // local_size_x + halo (interior part filled by all threads)
     std::unordered_map<int64_t, schwz_idx> g2l_x;  // non-interior global -> local
     // (col / val: no value-initialisation on resize -- every entry is written by the threads that fill the matrix,
     // which also places the pages near them)
-    std::vector<schwz_idx> l_rp;
+    std::vector<schwz_idx, schwz::NoInitAlloc<schwz_idx>> l_rp;
     std::vector<schwz_idx, schwz::NoInitAlloc<schwz_idx>> l_col;
     std::vector<double, schwz::NoInitAlloc<double>> l_val;
-    std::vector<schwz_idx> i_rp;       // interface rows (local_size_x+1)
+    std::vector<schwz_idx, schwz::NoInitAlloc<schwz_idx>> i_rp;  // interface rows (local_size_x+1)
     std::vector<int64_t> i_col_global;
     std::vector<double> i_val;
     std::vector<int> nbr_in, nbr_out;

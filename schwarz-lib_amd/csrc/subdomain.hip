@@ -355,6 +355,28 @@ int schwz_ras_local_residual_wait(schwz_subdomain *sd, double *h_resnorm)
     return SCHWZ_OK;
 }
 
+namespace schwz {
+__global__ void copy_scalar_kernel(const double *src, double *dst)
+{
+    dst[0] = src[0];  // src: mapped pinned host memory, final once the norm's event has fired
+}
+}  // namespace schwz
+
+int schwz_ras_norm_sq_to_device(schwz_subdomain *sd, double *d_norm_sq, schwz_stream stream)
+{
+    REQUIRE_DEVICE(sd, "schwz_ras_norm_sq_to_device");
+    SCHWZ_REQUIRE(d_norm_sq, "schwz_ras_norm_sq_to_device: null output");
+    hipStream_t st = (hipStream_t)stream;
+    if (sd->local_size_x == 0) {
+        SCHWZ_HIP_TRY(hipMemsetAsync(d_norm_sq, 0, sizeof(double), st));
+        return SCHWZ_OK;
+    }
+    SCHWZ_HIP_TRY(hipStreamWaitEvent(st, sd->ev_scalar, 0));
+    hipLaunchKernelGGL(schwz::copy_scalar_kernel, dim3(1), dim3(1), 0, st, (const double *)sd->d_h_scalar, d_norm_sq);
+    SCHWZ_HIP_TRY(hipGetLastError());
+    return SCHWZ_OK;
+}
+
 int schwz_ras_local_residual(schwz_subdomain *sd, double *h_resnorm, schwz_stream stream)
 {
     int rc = schwz_ras_local_residual_launch(sd, stream);

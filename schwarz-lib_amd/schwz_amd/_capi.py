@@ -54,6 +54,7 @@ SYMBOLS = [
     "schwz_ras_local_residual_wait", "schwz_ras_local_solve", "schwz_ras_set_local_max_iters",
     "schwz_ras_last_inner_stats",
     "schwz_ras_check_and_solve_launch",
+    "schwz_ras_norm_sq_to_device",
     "schwz_ras_restrict", "schwz_ras_vector", "schwz_ras_local_csr", "schwz_ras_jacobi_form", "schwz_ras_cg_flavour", "schwz_ras_get_interior",
     "schwz_ras_true_residual_sq", "schwz_ras_algorithmic_bytes",
 ]
@@ -187,6 +188,7 @@ _sig("schwz_ras_local_residual", i32, [vp, C.POINTER(dbl), vp])
 _sig("schwz_ras_local_residual_launch", i32, [vp, vp])
 _sig("schwz_ras_local_residual_wait", i32, [vp, C.POINTER(dbl)])
 _sig("schwz_ras_check_and_solve_launch", i32, [vp, vp])
+_sig("schwz_ras_norm_sq_to_device", i32, [vp, vp, vp])
 _sig("schwz_ras_local_solve", i32, [vp, C.POINTER(C.c_int), vp])
 _sig("schwz_ras_set_local_max_iters", i32, [vp, i32])
 _sig("schwz_ras_last_inner_stats", i32, [vp, C.POINTER(C.c_int), C.POINTER(dbl)])

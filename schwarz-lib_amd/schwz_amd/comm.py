@@ -11,6 +11,8 @@ Two implementations with the same interface:
   * TorchDistComm  -- one subdomain per process / GPU over torch.distributed;
     backend "nccl" is RCCL over xGMI on MI355X, "gloo" is used by the CPU tests.
 """
+import os
+
 import numpy as np
 
 
@@ -116,6 +118,13 @@ class TorchDistComm:
         self.stage_through_host = self.backend == "gloo" and self.device.type != "cpu"
         self._stage = {}
         self._side = None
+        # the P residual norms per iteration as an RCCL all-gather on device buffers (SCHWZ_NORM_ALLGATHER=host:
+        # over the gloo group as in rounds 1-2).  A communicator of its own: its collectives are issued on a side
+        # stream while halo sends / receives of the same iteration may be in flight on the default group.
+        self.device_norms = (self.backend == "nccl" and self.device.type == "cuda"
+                             and os.environ.get("SCHWZ_NORM_ALLGATHER", "device") != "host")
+        self.norm_group = dist.new_group(backend="nccl") if self.device_norms else None
+        self._norm = None
 
     def handshake(self, get_lists):
         """Counts and ids travel as int64 host tensors (tags 1 and 2 of the reference become
@@ -245,6 +254,30 @@ class TorchDistComm:
         out = [torch.zeros(1, dtype=torch.float64) for _ in range(self.size)]
         dist.all_gather(out, mine, group=self.host_group)
         return [float(t[0]) for t in out]
+
+    def start_allgather_norm_sq(self, fill):
+        """Device-side all-gather of the squared residual norms (solve.cpp:890-891).  `fill(ptr, raw_stream)`
+        enqueues, on that stream, the write of this rank's value to the device double at `ptr` as soon as it is
+        final (Subdomain.norm_sq_to_device); the collective and the copy of the P values to pinned host memory follow
+        on the same side stream -- beside the local solve the compute stream is already running."""
+        torch, dist = self._torch, self._dist
+        if self._norm is None:
+            self._norm = dict(stream=torch.cuda.Stream(device=self.device, priority=-1),
+                              mine=torch.zeros(1, dtype=torch.float64, device=self.device),
+                              all=torch.zeros(self.size, dtype=torch.float64, device=self.device),
+                              host=torch.zeros(self.size, dtype=torch.float64).pin_memory(),
+                              event=torch.cuda.Event())
+        nb = self._norm
+        with torch.cuda.stream(nb["stream"]):
+            fill(nb["mine"].data_ptr(), nb["stream"].cuda_stream)
+            dist.all_gather_into_tensor(nb["all"], nb["mine"], group=self.norm_group)
+            nb["host"].copy_(nb["all"], non_blocking=True)
+            nb["event"].record()
+        return nb
+
+    def finish_allgather_norm_sq(self, handle):
+        handle["event"].synchronize()
+        return [float(v) for v in handle["host"]]
 
     def gather_vectors(self, pieces):
         dist = self._dist

@@ -551,6 +551,11 @@ class Subdomain:
     def check_and_solve_launch(self, stream=0):
         check(lib.schwz_ras_check_and_solve_launch(self.h, _stream_arg(stream)))
 
+    def norm_sq_to_device(self, d_ptr, stream=0):
+        """Square of the last check residual norm to the device double at `d_ptr`, on `stream`, as soon as that
+        scalar is final (the solve enqueued behind the check is not waited for)."""
+        check(lib.schwz_ras_norm_sq_to_device(self.h, C.c_void_p(int(d_ptr)), _stream_arg(stream)))
+
     def local_residual_wait(self):
         out = C.c_double(0.0)
         check(lib.schwz_ras_local_residual_wait(self.h, C.byref(out)))

@@ -964,6 +964,16 @@ class SolverRAS:
         if tol >= 0.0 and spec:
             for _, sd in locals_:
                 sd.check_and_solve_launch(stream)
+        iter_cond = ((it > m.max_iters * 0.05) or m.max_iters < 1000) \
+            if cv.enable_global_check_iter_offset else True
+        # the P norms of the global test as a device-side all-gather (RCCL), enqueued on a side stream behind the
+        # norm's own event: it runs beside the local solve, and the host then waits for ONE event instead of its own
+        # scalar plus a gloo collective (every rank takes this branch or none: the conditions are global settings)
+        norm_handle = None
+        if (tol > 0.0 and spec and iter_cond and cv.enable_global_check and not cs.enable_onesided
+                and getattr(comm, "device_norms", False) and len(locals_) == 1):
+            sd0 = locals_[0][1]
+            norm_handle = comm.start_allgather_norm_sq(lambda ptr, raw: sd0.norm_sq_to_device(ptr, raw))
         lres = {}
         for me, sd in locals_:
             if tol < 0.0:
@@ -981,11 +991,12 @@ class SolverRAS:
                 lres[me] / self._lres0[me] if self._lres0[me] != 0 else float("nan"))
             m.current_residual_norm = lres[me]
             m.min_residual_norm = lres[me] if it == 0 else min(lres[me], m.min_residual_norm)
-        iter_cond = ((it > m.max_iters * 0.05) or m.max_iters < 1000) \
-            if cv.enable_global_check_iter_offset else True
         if tol > 0.0 and iter_cond:
             if cv.enable_global_check and not cs.enable_onesided:
-                allres = comm.allgather_scalars(lres)  # solve.cpp:890-891
+                if norm_handle is not None:  # solve.cpp:890-891 on the device
+                    allres = [float(np.sqrt(v)) for v in comm.finish_allgather_norm_sq(norm_handle)]
+                else:
+                    allres = comm.allgather_scalars(lres)  # solve.cpp:890-891
                 gres = 0.0
                 for j in range(P):
                     ppd["global_residual_vector_out"][j].append(allres[j])

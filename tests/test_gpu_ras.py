@@ -658,8 +658,9 @@ def test_ras_mixed_precision_halo(schwz, oracle, torch_cuda):
 def test_torchdist_comm_on_the_nccl_backend_single_rank(schwz, oracle, torch_cuda, tmp_path):
     """The product N > 1 host path -- TorchDistComm over the `nccl` (= RCCL) process group with its
     gloo side group for host data -- brought up with the one rank a 1-GPU box allows: process
-    group creation, index handshake, norm all-gather, solution gather and barrier all run for
-    real, and the grouped device-buffer send/recv of the halo exchange is exercised from rank 0 to
+    group creation, index handshake, the device-side all-gather of the residual norms (an RCCL collective on a
+    communicator of its own, fed by schwz_ras_norm_sq_to_device; compared with the gloo all-gather of rounds 1-2),
+    solution gather and barrier all run for real, and the grouped device-buffer send/recv of the halo exchange is exercised from rank 0 to
     itself on the compute stream and on the side stream of the overlapped mode (true peer-to-peer
     needs a second GPU: gloo tests and the driver's multi-GPU run).  Run in a subprocess: process groups are per process."""
     import subprocess
@@ -681,6 +682,9 @@ def test_torchdist_comm_on_the_nccl_backend_single_rank(schwz, oracle, torch_cud
         "solver.initialize()\n"
         "out = solver.run()\n"
         "comm.barrier()\n"
+        "# the norms of the global test travelled as an RCCL all-gather on device buffers (or, second run, over gloo)\n"
+        "want_dev = os.environ.get('SCHWZ_NORM_ALLGATHER', 'device') != 'host'\n"
+        "assert comm.device_norms == want_dev and (comm._norm is not None) == want_dev\n"
         "# the grouped send/recv mechanics on device buffers, rank 0 to itself: on the compute\n"
         "# stream and on the side stream of the overlapped mode\n"
         "src = torch.arange(4096, dtype=torch.float64, device='cuda') * 0.5\n"
@@ -712,6 +716,11 @@ def test_torchdist_comm_on_the_nccl_backend_single_rank(schwz, oracle, torch_cud
     assert p.returncode == 0, p.stdout + p.stderr
     import json
     got = json.loads(p.stdout.strip().splitlines()[-1])
+    # the same run with the norms all-gathered over the gloo group (rounds 1-2): the same numbers, bit for bit
+    p2 = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300,
+                        env=dict(os.environ, SCHWZ_NORM_ALLGATHER="host"))
+    assert p2.returncode == 0, p2.stdout + p2.stderr
+    assert json.loads(p2.stdout.strip().splitlines()[-1]) == got
     rp, col, val = oracle.laplacian3d(20, 18, 16)
     N = len(rp) - 1
     ref = oracle.ras_run(rp, col, val, np.ones(N), 1, oracle.first_rows_regular(N, 1),
