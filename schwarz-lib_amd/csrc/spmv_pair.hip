@@ -661,30 +661,38 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
     const int tid = threadIdx.x;
     if (!INIT) {
         if (a.it >= a.cg_state->stop_iter) return;
-        cg_alpha = a.cg_state->rho[a.it & 1] / fold_partials(a.pq_partials, a.pq_nparts, red);
-        if (blockIdx.x == 0 && tid == 0 && a.alpha_out) *a.alpha_out = cg_alpha;
     }
     // INIT reads the right-hand side where the update launch reads r (the caller's b need only be 8-byte
     // aligned) and stores r to a.y
     typedef double pvd2u __attribute__((ext_vector_type(2), aligned(8)));
     const double *const r_in = INIT ? a.b : a.cg_r;
     double *const r_out = INIT ? a.y : a.cg_r;
-    for (int i = tid; i < A.canon_npat * 9; i += kBlock) {
-        if (SCHWZ_WALK_ZEROCOEF) {
-            const int m = A.canon_mask[i / 9], k = i % 9;
-            cpv[i] = PairVal{((m >> k) & 1) ? A.canon_val[2 * i] : 0.0, ((m >> (16 + k)) & 1) ? A.canon_val[2 * i + 1] : 0.0};
-        } else {
-            cpv[i] = PairVal{A.canon_val[2 * i], A.canon_val[2 * i + 1]};
+    // What a workgroup needs before its first step besides its windows -- the slot tables in LDS and the step
+    // length alpha (every workgroup folds the partial sums of the previous launch itself) -- is fetched AFTER the
+    // first windows have been requested (round 3): the two latencies overlap instead of adding up at the start of
+    // every workgroup's life.
+    auto tables_and_alpha = [&]() {
+        for (int i = tid; i < A.canon_npat * 9; i += kBlock) {
+            if (SCHWZ_WALK_ZEROCOEF) {
+                const int m = A.canon_mask[i / 9], k = i % 9;
+                cpv[i] = PairVal{((m >> k) & 1) ? A.canon_val[2 * i] : 0.0, ((m >> (16 + k)) & 1) ? A.canon_val[2 * i + 1] : 0.0};
+            } else {
+                cpv[i] = PairVal{A.canon_val[2 * i], A.canon_val[2 * i + 1]};
+            }
         }
-    }
-    if (tid < A.canon_npat) cmask[tid] = A.canon_mask[tid];
+        if (tid < A.canon_npat) cmask[tid] = A.canon_mask[tid];
+        if (!INIT) {
+            cg_alpha = a.cg_state->rho[a.it & 1] / fold_partials(a.pq_partials, a.pq_nparts, red);
+            if (blockIdx.x == 0 && tid == 0 && a.alpha_out) *a.alpha_out = cg_alpha;
+        }
+        lds_barrier();
+    };
     // partial-sum slots no workgroup of this launch or of its companion writes
     if (blockIdx.x == 0)
         for (int i = (int)gridDim.x + a.part_offset + tid; i < a.part_stride; i += kBlock) {
             a.partials[i] = a.partials[a.part_stride + i] = 0.0;
             if (DUAL) a.partials[2 * a.part_stride + i] = 0.0;
         }
-    lds_barrier();
     const int4 sg = A.sweep_seg[blockIdx.x];
     const int64_t PL = A.sweep_pl;
     const int band = sg.x, z0 = sg.y, z1 = sg.z;  // chain positions z0 <= z < z1
@@ -778,6 +786,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
                 r_a[h] = fetch(brow[1], h);
                 r_b[h] = fetch(z0 + 1 < z1 ? brow[2] : brow[1], h);
             }
+            tables_and_alpha();
             store_own(z0 - 1, first);
             store_own(z0, second);
         }
@@ -885,6 +894,8 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
             step(z + 1, own_a, r_b);
         }
         if (z < z1) step(z, own_b, r_a);
+    } else if (!INIT && blockIdx.x == 0) {
+        tables_and_alpha();  // (an empty first slot still reports alpha)
     }
     const double s0 = block_sum(acc0, red);
     const double s1 = block_sum(acc1, red);
@@ -937,25 +948,29 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
     __shared__ double red[4];
     if (a.it >= a.cg_state->stop_iter) return;
     double cg_rho_new = 0.0, cg_rr = 0.0, cg_beta = 0.0;
-    if (!FIRST) {
-        cg_rho_new = fold_partials(a.pq_partials, a.pq_nparts, red);
-        cg_rr = fold_partials(a.pq_partials + a.pq_nparts, a.pq_nparts, red);
-        cg_beta = cg_rho_new / a.cg_state->rho[a.it & 1];
-    }
     const int tid = threadIdx.x;
-    for (int i = tid; i < A.canon_npat * 5; i += kBlock) {
-        if (SCHWZ_WALK_ZEROCOEF) {
-            const int m = A.canon_sym_mask[i / 5], k = i % 5;
-            cpv[i] = PairVal{((m >> k) & 1) ? A.canon_sym_val[2 * i] : 0.0, ((m >> (16 + k)) & 1) ? A.canon_sym_val[2 * i + 1] : 0.0};
-        } else {
-            cpv[i] = PairVal{A.canon_sym_val[2 * i], A.canon_sym_val[2 * i + 1]};
+    // the slot tables and beta (folded from the previous launch's partial sums by every workgroup): fetched after
+    // the first windows have been requested, like in the update walk above
+    auto tables_and_beta = [&]() {
+        for (int i = tid; i < A.canon_npat * 5; i += kBlock) {
+            if (SCHWZ_WALK_ZEROCOEF) {
+                const int m = A.canon_sym_mask[i / 5], k = i % 5;
+                cpv[i] = PairVal{((m >> k) & 1) ? A.canon_sym_val[2 * i] : 0.0, ((m >> (16 + k)) & 1) ? A.canon_sym_val[2 * i + 1] : 0.0};
+            } else {
+                cpv[i] = PairVal{A.canon_sym_val[2 * i], A.canon_sym_val[2 * i + 1]};
+            }
         }
-    }
-    if (tid < A.canon_npat) cmask[tid] = A.canon_sym_mask[tid];
+        if (tid < A.canon_npat) cmask[tid] = A.canon_sym_mask[tid];
+        if (!FIRST) {
+            cg_rho_new = fold_partials(a.pq_partials, a.pq_nparts, red);
+            cg_rr = fold_partials(a.pq_partials + a.pq_nparts, a.pq_nparts, red);
+            cg_beta = cg_rho_new / a.cg_state->rho[a.it & 1];
+        }
+        lds_barrier();
+    };
     if (blockIdx.x == 0)
         for (int i = (int)gridDim.x + a.part_offset + tid; i < a.part_stride; i += kBlock)
             a.partials[i] = a.partials[a.part_stride + i] = 0.0;
-    lds_barrier();
     const int4 sg = A.sweep_seg_dir[blockIdx.x];  // (its own table: the band height may differ from the update launch's)
     const int64_t PL = A.sweep_pl;
     const int band = sg.x, z0 = sg.y, z1 = sg.z;
@@ -1076,8 +1091,9 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
                 // halo of the first position goes to its slot now; the next two stay in flight like the own windows
                 load_halo(brow[2], hreg);    // position z0 + 1
                 load_halo(brow[3], hreg_b);  // position z0 + 2
-                store_halo(0, h0);
             }
+            tables_and_beta();
+            if (SCHWZ_DD & 2) store_halo(0, h0);
             store_own(z0 - 1, brow[0], before, false);
             store_own(z0, brow[1], first, true);
         }
@@ -1165,6 +1181,8 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
             step(z + 1, own_a, rle_b, hreg_b);
         }
         if (z < z1) step(z, own_b, rle_a, hreg);
+    } else if (!FIRST && blockIdx.x == 0) {
+        tables_and_beta();  // (an empty first slot still advances the CG state below)
     }
     const double s0 = block_sum(acc0, red);
     if (tid == 0) {
