@@ -276,9 +276,13 @@ __global__ __launch_bounds__(kBlock) void cg_flush_x_kernel(int64_t n, double *_
                                                             int64_t pair0, int64_t pair1, int tail, int fused,
                                                             int lazy_it, const double *pq_partials, int pq_nparts,
                                                             double *__restrict__ x2, int64_t x2_rows,
-                                                            const double *__restrict__ x2_src, int64_t x2_total)
+                                                            const double *__restrict__ x2_src, int64_t x2_total,
+                                                            double p0_scale)
 {
 #pragma clang fp contract(off)
+    // p0_scale: direction 0 of the solve is p0_scale x (slot 0 of the ring) -- 1.0 for a stored p0 (the product is
+    // exact), D^-1's uniform factor when slot 0 is r0 and p0 = D^-1 r0 was never stored (virtual first direction:
+    // the same rounded product the first-direction launch formed)
     __shared__ double alpha[kDeferDepth];
     __shared__ double red[4];
     const int stop = st->stop_iter;
@@ -301,8 +305,10 @@ __global__ __launch_bounds__(kBlock) void cg_flush_x_kernel(int64_t n, double *_
             vd2 pv[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (k0 + k < kmax)
+                if (k0 + k < kmax) {
                     pv[k] = __builtin_nontemporal_load(reinterpret_cast<const vd2 *>(ring.slot[(b0 + k0 + k) % kDeferDepth]) + i);
+                    if (b0 + k0 + k == 0) pv[k] = p0_scale * pv[k];
+                }
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (k0 + k < kmax) {
@@ -335,7 +341,8 @@ __global__ __launch_bounds__(kBlock) void cg_flush_x_kernel(int64_t n, double *_
     if (tail && (n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         double xv = x[n - 1];
         for (int k = 0; k < kmax; ++k) {
-            const double pk = ring.slot[(b0 + k) % kDeferDepth][n - 1];
+            double pk = ring.slot[(b0 + k) % kDeferDepth][n - 1];
+            if (b0 + k == 0) pk = p0_scale * pk;
             if (fused) {
                 xv = __builtin_fma(alpha[k], pk, xv);
             } else {
@@ -766,6 +773,7 @@ void schwz_pcg_destroy(schwz_pcg *s)
     if (!s) return;
     if (s->prio_event) (void)hipEventDestroy(s->prio_event);
     (void)hipFree(s->r);
+    (void)hipFree(s->r_alt);
     (void)hipFree(s->p);
     (void)hipFree(s->q);
     (void)hipFree(s->p_ring);
@@ -1034,6 +1042,27 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
     const int dot_mode = plan.dot_mode, flavour = plan.flavour;
     s->last_flavour = flavour | (deferx ? 4 : 0) | (sweep_on && deferx && s->diag.mode != 2 ? 8 : 0) |
                       (sweep_dirdot && fusedir ? 16 : 0) | (s->p_pending ? 32 : 0);
+    // Virtual first direction (round 3; SCHWZ_CG_P0VIRTUAL=0: stored as before).  A solve that started in the walk
+    // has p0 = D^-1 r0 with D^-1 uniform or absent, and r0 is in memory: the first-direction launch then stores
+    // nothing (windows and the sums of p0.(A p0) only), the first update walk builds its windows from r0 x D^-1 and
+    // writes r1 to the OTHER residual buffer, and r0 -- intact -- serves as p0 for the first fused direction launch
+    // and for the x update.  16 n bytes per solve less (the p0 store and one p0 read), the same bits: every reader
+    // forms the same rounded product D^-1 r0 the store would have held.
+    const char *p0_env = std::getenv("SCHWZ_CG_P0VIRTUAL");  // read per solve: tests switch it
+    bool p0_virtual = !(p0_env && p0_env[0] == '0') && s->p_pending && fusedir && plan.sweep_start && sweep_on &&
+                      sweep_dirdot && qfree && deferx && !general && max_iters >= 2 &&
+                      (s->diag.mode == 0 || s->diag.mode == 3);
+    if (p0_virtual && !s->r_alt) {
+        const size_t nb = (size_t)((n + 1) & ~int64_t(1)) * sizeof(double);
+        if (hipMalloc((void **)&s->r_alt, nb) != hipSuccess) {
+            (void)hipGetLastError();
+            s->r_alt = nullptr;
+            p0_virtual = false;  // no room for the second residual: the stored form
+        }
+    }
+    const double p0_scale = p0_virtual && s->diag.mode != 0 ? s->diag.uniform : 1.0;
+    if (p0_virtual) s->last_flavour |= 64;
+    double *const r0_vec = s->r;  // where the start launch left r0
     PRing ring;
     const int64_t n_pad = (n + 1) & ~int64_t(1);
     for (int k = 0; k < kDeferDepth; ++k)
@@ -1041,6 +1070,7 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
                                 : (!s->p_ring ? s->p
                                               : (s->ring_has_q ? (k == 1 ? s->q : s->p_ring + (int64_t)(k - 2) * n_pad)
                                                                : s->p_ring + (int64_t)(k - 1) * n_pad));
+    if (p0_virtual) ring.slot[0] = r0_vec;  // (a later direction 16, 32, ... simply lands there: r0 is done with by then)
     auto slot = [&](int it) -> double * { return const_cast<double *>(ring.slot[it % kDeferDepth]); };
     bool prio_recorded = false;
     const int fused_x = qfree ? 0 : 1;  // how the in-launch update of this iteration forms x + alpha p
@@ -1069,18 +1099,18 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
             const int64_t lo = std::min(s->prio_lo >> 1, n2), hi = std::max(std::min(s->prio_hi >> 1, n2), lo);
             if (lo > 0)
                 hipLaunchKernelGGL(cg_flush_x_kernel, dim3(grid_for(lo)), dim3(kBlock), 0, q, n, d_x, ring, s->alpha_hist,
-                                   s->state, b0, count, pending, (int64_t)0, lo, 0, fused_x, lz, lazy_pq, gs, x2, x2_rows, s->x2_src, s->x2_total);
+                                   s->state, b0, count, pending, (int64_t)0, lo, 0, fused_x, lz, lazy_pq, gs, x2, x2_rows, s->x2_src, s->x2_total, p0_scale);
             hipLaunchKernelGGL(cg_flush_x_kernel, dim3(grid_for(n2 - hi + 1)), dim3(kBlock), 0, q, n, d_x, ring,
-                               s->alpha_hist, s->state, b0, count, pending, hi, n2, 1, fused_x, lz, lazy_pq, gs, x2, x2_rows, s->x2_src, s->x2_total);
+                               s->alpha_hist, s->state, b0, count, pending, hi, n2, 1, fused_x, lz, lazy_pq, gs, x2, x2_rows, s->x2_src, s->x2_total, p0_scale);
             if (hipEventRecord(s->prio_event, q) == hipSuccess) prio_recorded = true;
             if (hi > lo)
                 hipLaunchKernelGGL(cg_flush_x_kernel, dim3(grid_for(hi - lo)), dim3(kBlock), 0, q, n, d_x, ring,
-                                   s->alpha_hist, s->state, b0, count, pending, lo, hi, 0, fused_x, lz, lazy_pq, gs, x2, x2_rows, s->x2_src, s->x2_total);
+                                   s->alpha_hist, s->state, b0, count, pending, lo, hi, 0, fused_x, lz, lazy_pq, gs, x2, x2_rows, s->x2_src, s->x2_total, p0_scale);
             if (x2) s->x2_written = true;
             return;
         }
         hipLaunchKernelGGL(cg_flush_x_kernel, dim3(gv), dim3(kBlock), 0, q, n, d_x, ring, s->alpha_hist, s->state, b0,
-                           count, pending, (int64_t)0, n2, 1, fused_x, lz, lazy_pq, gs, x2, x2_rows, s->x2_src, s->x2_total);
+                           count, pending, (int64_t)0, n2, 1, fused_x, lz, lazy_pq, gs, x2, x2_rows, s->x2_src, s->x2_total, p0_scale);
         if (x2) s->x2_written = true;
     };
     double *const pbuf[2] = {s->p, fusedir ? s->q : s->p};
@@ -1125,10 +1155,18 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
             u.dinv = s->dinv;
             u.partials = part_vec;
             u.it = it;
+            const bool first_virtual = p0_virtual && instrument && it == 0;
+            if (first_virtual) {
+                u.x = r0_vec;  // windows = ring_scale x r0 = p0
+                u.ring_scale = p0_scale;
+                u.cg_r_out = s->r_alt;
+                u.p0_virtual = 1;
+            }
             const bool lazy_now = instrument && it == lazy_it;
             const bool prof2 = !lazy_now && instrument && g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
             if (prof2) SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used], q));
             if (!lazy_now && (rc = launch_spmv(A, kSpmvCgUpdate, u, s->variant, q))) return rc;
+            if (first_virtual) std::swap(s->r, s->r_alt);  // r1 (and every later residual) lives in the other buffer
             if (prof2) {
                 SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used + 1], q));
                 g_prof.kind[g_prof.used / 2] = 1;
@@ -1152,6 +1190,11 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
                 f.partials = part_spmv;
                 f.it = it;
                 f.cg_rtol = rtol;
+                if (first_virtual) {
+                    f.x = r0_vec;  // p0 = p_scale x r0
+                    f.p_scale = p0_scale;
+                    f.p0_virtual = 1;
+                }
                 const bool prof3 = instrument && g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
                 if (prof3) SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used], q));
                 if ((rc = launch_spmv(A, s->diag.mode == 1 ? kSpmvDirDotSymVec : kSpmvDirDotSym, f, s->variant, q)))
@@ -1282,7 +1325,7 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
         int rc;
         if (s->p_pending) {
             // z-sweep start: p0 = D^-1 r0 is built here, from the r the launch reads anyway
-            a.y = slot(0);
+            a.y = p0_virtual ? nullptr : slot(0);
             a.cg_r = s->r;
             a.cg_state = s->state;
             a.diag_mode = s->diag.mode;

@@ -350,6 +350,15 @@ struct SpmvArgs {
     // spmv_stream.hip: consecutive tiles per workgroup of a grid that covers the matrix once (0: persistent
     // workgroups striding through their XCD's sequence, the form of round 2)
     int seq = 0;
+    // q-free CG on the walks, a solve that started in the walk (round 3, "virtual first direction"): p0 = D^-1 r0 is
+    // never stored -- the first update walk builds its windows from r0 (a.x = r0, windows x ring_scale) and writes
+    // r1 to cg_r_out, so r0 stays intact for the first fused direction launch (a.x = r0, p read as p_scale x a.x)
+    // and for the x update (slot 0 of the ring = r0 x the same factor).  p0_virtual = 1 marks such a launch: it must
+    // be served by the walk kernels (launch_spmv_pair fails loudly otherwise).
+    int p0_virtual = 0;
+    double ring_scale = 1.0;
+    double *cg_r_out = nullptr;
+    double p_scale = 1.0;
 };
 
 // launch grid of the streaming vector kernels: one lane per element up to kMaxGrid workgroups
@@ -466,6 +475,7 @@ struct schwz_pcg {
     int precond = 0;
     int64_t n = 0;
     double *r = nullptr, *p = nullptr, *q = nullptr, *dinv = nullptr;
+    double *r_alt = nullptr;  // second residual buffer of the virtual first direction (cg.hip: r1 goes there, r0 stays)
     // general preconditioners (block-Jacobi, ILU(0)): z = M^-1 r is a vector of its own
     double *z = nullptr;
     int block_size = 1;

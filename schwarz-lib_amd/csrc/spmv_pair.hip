@@ -666,7 +666,8 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
     // aligned) and stores r to a.y
     typedef double pvd2u __attribute__((ext_vector_type(2), aligned(8)));
     const double *const r_in = INIT ? a.b : a.cg_r;
-    double *const r_out = INIT ? a.y : a.cg_r;
+    double *const r_out = INIT ? a.y : (a.cg_r_out ? a.cg_r_out : a.cg_r);
+    const pvd2 ring_scale = {a.ring_scale, a.ring_scale};  // 1.0 except in the first update of a solve with a virtual p0
     // What a workgroup needs before its first step besides its windows -- the slot tables in LDS and the step
     // length alpha (every workgroup folds the partial sums of the previous launch itself) -- is fetched AFTER the
     // first windows have been requested (round 3): the two latencies overlap instead of adding up at the start of
@@ -721,7 +722,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
         auto store_own = [&](int z, const pvd2 (&reg)[NH]) {
             double *slot_p = own_ring + (size_t)(z & 3) * T;
 #pragma unroll
-            for (int k = 0; k < NH; ++k) *reinterpret_cast<pvd2 *>(slot_p + 2 * (tid + k * kBlock)) = reg[k];
+            for (int k = 0; k < NH; ++k) *reinterpret_cast<pvd2 *>(slot_p + 2 * (tid + k * kBlock)) = ring_scale * reg[k];
         };
         // halo of a plane: the NX rows below the band (pieces 0 .. NX/2) and the NX rows above it
         auto load_halo = [&](int base, pvd2 (&reg)[NHL]) {
@@ -738,7 +739,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
 #pragma unroll
             for (int k = 0; k < NHL; ++k) {
                 const int pc = min(tid + k * kBlock, NX - 1);
-                *reinterpret_cast<pvd2 *>(slot_p + 2 * pc) = reg[k];
+                *reinterpret_cast<pvd2 *>(slot_p + 2 * pc) = ring_scale * reg[k];
             }
         };
         struct Ahead {
@@ -990,12 +991,14 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
         };
         auto clampg = [&](int g) -> int { return g < 0 ? 0 : (g > (int)gmax ? (int)gmax : g); };
         // p' at one 16-byte piece: the expression of dir2 / cg_direction_kernel
+        const pvd2 p_scale = {a.p_scale, a.p_scale};  // 1.0 except where a.x is r0 and p0 = p_scale x r0 (virtual p0)
         auto newp = [&](pvd2 rv, pvd2 pv) -> pvd2 {
             const pvd2 zv = a.diag_mode ? du * rv : rv;
             if (FIRST) return zv;
+            const pvd2 ps = p_scale * pv;
             pvd2 o;
-            o.x = __builtin_fma(cg_beta, pv.x, zv.x);
-            o.y = __builtin_fma(cg_beta, pv.y, zv.y);
+            o.x = __builtin_fma(cg_beta, ps.x, zv.x);
+            o.y = __builtin_fma(cg_beta, ps.y, zv.y);
             return o;
         };
         struct Own {
@@ -1028,7 +1031,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
             for (int k = 0; k < NH; ++k) {
                 const pvd2 v = newp(o.r[k], o.p[k]);
                 *reinterpret_cast<pvd2 *>(slot_p + 2 * (tid + k * kBlock)) = v;
-                if (out) {
+                if (out && (!FIRST || a.y)) {  // (FIRST with a.y == nullptr: the virtual p0 -- windows and sums only)
                     if ((SCHWZ_DD & 1) && SCHWZ_WALK_HINTS)
                         __builtin_nontemporal_store(v, reinterpret_cast<pvd2 *>(a.y + base + 2 * piece_of(k)));
                     else
@@ -1446,6 +1449,11 @@ int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hi
                 return SCHWZ_OK;
             }
         }
+    }
+    if (a.p0_virtual) {
+        // (the chunk-by-chunk kernels read a stored p0; pcg_iterate only asks for the virtual one where the walks apply)
+        set_error("launch_spmv_pair: a launch on the virtual first direction was not served by the z-sweep walk");
+        return SCHWZ_ERR_INVALID;
     }
 #define SCHWZ_PAIR_LAUNCH(M)                                                                          \
     if (wide)                                                                                         \

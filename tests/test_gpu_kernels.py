@@ -1167,3 +1167,15 @@ def _walk_checks(schwz, oracle, torch, monkeypatch, rng, rp, col, val, must_walk
     assert np.abs(x_ref - x_st).max() <= 1e-13 * np.abs(x_ref).max()
     exp, _, _ = oracle.pcg(rp, col, val, b, x0, 1, 0.0, 12)
     assert np.abs(solve("1", 12, start="1")[1] - exp).max() <= RTOL_CG * np.abs(exp).max()
+    # the virtual first direction (p0 = D^-1 r0 never stored: rebuilt from r0 by its three readers, round 3) against
+    # the stored one: the same bits, also past the 16 slots of the direction ring (direction 16 lands on the r0 buffer)
+    for iters in (12, 19):
+        monkeypatch.setenv("SCHWZ_CG_P0VIRTUAL", "0")
+        rn_s, x_s = solve("1", iters, start="1")
+        assert cg.flavour() & 64 == 0
+        in_walk = cg.flavour() & 32 == 32  # the solve started in the walk (no rows left to the chunk launches)
+        monkeypatch.setenv("SCHWZ_CG_P0VIRTUAL", "1")
+        rn_v, x_v = solve("1", iters, start="1")
+        assert (cg.flavour() & 64 == 64) == in_walk, (cg.flavour(), tag)
+        assert np.array_equal(x_s, x_v) and rn_s == rn_v, (tag, iters)
+    monkeypatch.delenv("SCHWZ_CG_P0VIRTUAL")
