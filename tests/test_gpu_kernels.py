@@ -1151,13 +1151,13 @@ def _walk_checks(schwz, oracle, torch, monkeypatch, rng, rp, col, val, must_walk
     x0 = 0.1 * rng.standard_normal(n)
     cg = schwz.Pcg(A, 1)
 
-    def solve(sweep, iters, start="0"):
+    def solve(sweep, iters, start="0", rtol=0.0):
         monkeypatch.setenv("SCHWZ_CG_SWEEP", sweep)
         monkeypatch.setenv("SCHWZ_CG_DEFERX", "2")
         monkeypatch.setenv("SCHWZ_CG_SWEEPSTART", start)
         d_b, d_x = _dev(torch, b), _dev(torch, x0)
-        it, rn = cg.solve(d_b.data_ptr(), d_x.data_ptr(), 0.0, iters)
-        return rn, d_x.cpu().numpy()
+        it, rn = cg.solve(d_b.data_ptr(), d_x.data_ptr(), rtol, iters)
+        return (rn, it) if rtol > 0.0 else rn, d_x.cpu().numpy()
 
     rn0, x_ref = solve("0", 1)
     rn1, x_sw = solve("1", 1)
@@ -1178,4 +1178,10 @@ def _walk_checks(schwz, oracle, torch, monkeypatch, rng, rp, col, val, must_walk
         rn_v, x_v = solve("1", iters, start="1")
         assert (cg.flavour() & 64 == 64) == in_walk, (cg.flavour(), tag)
         assert np.array_equal(x_s, x_v) and rn_s == rn_v, (tag, iters)
+    # ... and a solve to a tolerance (the host polls the state, the x update takes the iterations carried out)
+    monkeypatch.setenv("SCHWZ_CG_P0VIRTUAL", "0")
+    st_s, x_s = solve("1", 300, start="1", rtol=1e-7)
+    monkeypatch.setenv("SCHWZ_CG_P0VIRTUAL", "1")
+    st_v, x_v = solve("1", 300, start="1", rtol=1e-7)
+    assert np.array_equal(x_s, x_v) and st_s == st_v and 1 < st_s[1] < 300, (tag, st_s, st_v)
     monkeypatch.delenv("SCHWZ_CG_P0VIRTUAL")
