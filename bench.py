@@ -519,6 +519,10 @@ def main():
             spmv_tag = "spmv_pair_dirdot_sweep_kernel<" if flav & 16 else "spmv_pair_kernel<8,"
             spmv_fmt_bytes = mat_bytes + 24 * n_rows
             csr_spmv_equiv = csr_spmv_bytes + 24 * n_rows
+            if flav & 128 and launches.value >= a.steps > 0:
+                # the last direction of a fixed-work solve is never stored: one fused launch per solve writes nothing
+                spmv_fmt_bytes -= int(8 * n_rows * a.steps / launches.value)
+                spmv_name += " [last launch of a solve: no store, 16n]"
     else:
         kernel_name, dom_tag, avg_ms, dom_launches = spmv_name, spmv_tag, spmv_avg_ms, launches.value
         dom_fmt_bytes, dom_csr_bytes = spmv_fmt_bytes, csr_spmv_bytes

@@ -247,6 +247,24 @@ __global__ __launch_bounds__(kBlock) void cg_state_advance_kernel(const double *
     }
 }
 
+// The last direction of a fixed-work solve is never stored (pcg_iterate, vlast_on): when somebody asks for the
+// statistics of the postponed last iteration after all, its update launch needs that direction in memory --
+// p = fma(beta, p_prev, D^-1 r), what the fused direction launch computed (the same operations: the same bits).
+__global__ __launch_bounds__(kBlock) void cg_rebuild_direction_kernel(int64_t n, const double *__restrict__ p_prev,
+                                                                      double prev_scale, const double *__restrict__ r,
+                                                                      int dmode, double dsc, const CgState *st, int it,
+                                                                      double *__restrict__ p_out)
+{
+#pragma clang fp contract(off)
+    const double beta = st->rho[it & 1] / st->rho[(it - 1) & 1];
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const double pp = prev_scale * p_prev[i];
+        const double zv = dmode ? dsc * r[i] : r[i];
+        p_out[i] = __builtin_fma(beta, pp, zv);
+    }
+}
+
 // Measured on MI355X (256^3): U = 2/4 and non-temporal stores change the PCG iteration time by
 // < 1 % (0.403 / 0.406 / 0.417 ms for U = 1 / 2 / 4): these kernels sit at the mixed
 // read+write HBM ceiling (~5.0-5.5 TB/s), so the plain shape is used.
@@ -277,12 +295,18 @@ __global__ __launch_bounds__(kBlock) void cg_flush_x_kernel(int64_t n, double *_
                                                             int lazy_it, const double *pq_partials, int pq_nparts,
                                                             double *__restrict__ x2, int64_t x2_rows,
                                                             const double *__restrict__ x2_src, int64_t x2_total,
-                                                            double p0_scale)
+                                                            double p0_scale, int vlast_it,
+                                                            const double *__restrict__ vlast_r, int vlast_dmode,
+                                                            double vlast_dsc)
 {
 #pragma clang fp contract(off)
     // p0_scale: direction 0 of the solve is p0_scale x (slot 0 of the ring) -- 1.0 for a stored p0 (the product is
     // exact), D^-1's uniform factor when slot 0 is r0 and p0 = D^-1 r0 was never stored (virtual first direction:
     // the same rounded product the first-direction launch formed)
+    // vlast_it >= 0: the direction of iteration vlast_it (the last one of the solve) was never stored either: it is
+    // p = fma(beta, p_prev, D^-1 r) with beta = rho_new / rho_old as the fused direction launch formed it (both rho
+    // slots still hold those values: the update launch of that iteration is the postponed one), p_prev the
+    // direction before it and r = vlast_r the current residual -- the same operations, the same bits.
     __shared__ double alpha[kDeferDepth];
     __shared__ double red[4];
     const int stop = st->stop_iter;
@@ -299,19 +323,41 @@ __global__ __launch_bounds__(kBlock) void cg_flush_x_kernel(int64_t n, double *_
     const int64_t n2 = pair1;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     vd2 *x2v = reinterpret_cast<vd2 *>(x);
+    const bool vlast = vlast_it >= b0 && vlast_it < b0 + kmax;  // workgroup-uniform
+    const double vbeta = vlast ? st->rho[vlast_it & 1] / st->rho[(vlast_it - 1) & 1] : 0.0;
+    const double *const vprev_slot = ring.slot[(vlast_it + kDeferDepth - 1) % kDeferDepth];
+    const double vprev_scale = vlast_it == 1 ? p0_scale : 1.0;
     for (int64_t i = pair0 + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
         vd2 xv = __builtin_nontemporal_load(x2v + i);
+        vd2 carry = {0.0, 0.0};  // direction of the iteration before the current group of four
         for (int k0 = 0; k0 < kmax; k0 += 4) {
             vd2 pv[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (k0 + k < kmax) {
-                    pv[k] = __builtin_nontemporal_load(reinterpret_cast<const vd2 *>(ring.slot[(b0 + k0 + k) % kDeferDepth]) + i);
-                    if (b0 + k0 + k == 0) pv[k] = p0_scale * pv[k];
+                    if (vlast && b0 + k0 + k == vlast_it) {
+                        pv[k] = __builtin_nontemporal_load(reinterpret_cast<const vd2 *>(vlast_r) + i);
+                    } else {
+                        pv[k] = __builtin_nontemporal_load(reinterpret_cast<const vd2 *>(ring.slot[(b0 + k0 + k) % kDeferDepth]) + i);
+                        if (b0 + k0 + k == 0) pv[k] = p0_scale * pv[k];
+                    }
                 }
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (k0 + k < kmax) {
+                    if (vlast && b0 + k0 + k == vlast_it) {
+                        vd2 pp;
+                        if (k > 0)
+                            pp = pv[k - 1];
+                        else if (k0 > 0)
+                            pp = carry;
+                        else
+                            pp = vprev_scale * __builtin_nontemporal_load(reinterpret_cast<const vd2 *>(vprev_slot) + i);
+                        const vd2 dsc2 = {vlast_dsc, vlast_dsc};
+                        const vd2 zv = vlast_dmode ? dsc2 * pv[k] : pv[k];
+                        pv[k].x = __builtin_fma(vbeta, pp.x, zv.x);
+                        pv[k].y = __builtin_fma(vbeta, pp.y, zv.y);
+                    }
                     if (fused) {  // the stored-q iteration's update: x = fma(alpha, p, x)
                         xv.x = __builtin_fma(alpha[k0 + k], pv[k].x, xv.x);
                         xv.y = __builtin_fma(alpha[k0 + k], pv[k].y, xv.y);
@@ -320,6 +366,7 @@ __global__ __launch_bounds__(kBlock) void cg_flush_x_kernel(int64_t n, double *_
                         xv = xv + inc;
                     }
                 }
+            carry = pv[3];
         }
         if (kmax > 0) __builtin_nontemporal_store(xv, x2v + i);
         if (x2) {
@@ -340,9 +387,18 @@ __global__ __launch_bounds__(kBlock) void cg_flush_x_kernel(int64_t n, double *_
             if (!((n & 1) && j == n - 1)) x2[j] = x2_src[j];
     if (tail && (n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         double xv = x[n - 1];
+        double pprev = vlast ? vprev_scale * vprev_slot[n - 1] : 0.0;
         for (int k = 0; k < kmax; ++k) {
-            double pk = ring.slot[(b0 + k) % kDeferDepth][n - 1];
-            if (b0 + k == 0) pk = p0_scale * pk;
+            double pk;
+            if (vlast && b0 + k == vlast_it) {
+                const double rv = vlast_r[n - 1];
+                const double zv = vlast_dmode ? vlast_dsc * rv : rv;
+                pk = __builtin_fma(vbeta, pprev, zv);
+            } else {
+                pk = ring.slot[(b0 + k) % kDeferDepth][n - 1];
+                if (b0 + k == 0) pk = p0_scale * pk;
+            }
+            pprev = pk;
             if (fused) {
                 xv = __builtin_fma(alpha[k], pk, xv);
             } else {
@@ -1086,6 +1142,14 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
     const bool lazy_last = lazy_on && rtol == 0.0 && deferx && !general && max_iters > 0 && !(ld_env0 && ld_env0[0] == '1');
     const int lazy_it = lazy_last ? max_iters - 1 : -1;
     const double *const lazy_pq = part_spmv;  // p.(A p) of the last iteration: SpMV bank 0, gs slots
+    // ... and the direction of that last iteration is never stored (round 3; SCHWZ_CG_PLASTVIRTUAL=0: stored): its
+    // only readers are the x update -- which rebuilds it from the direction before it, which it reads anyway, and
+    // the current residual: the same fma the fused direction launch performed -- and the postponed update launch,
+    // which gets it rebuilt first (cg_rebuild_direction_kernel).  8 n bytes of stores per solve less.
+    const char *pl_env = std::getenv("SCHWZ_CG_PLASTVIRTUAL");
+    const bool vlast_on = lazy_last && !(pl_env && pl_env[0] == '0') && max_iters >= 2 && fusedir && sweep_dirdot &&
+                          sweep_on && qfree && plan.sweep_start && (s->diag.mode == 0 || s->diag.mode == 3);
+    if (vlast_on) s->last_flavour |= 128;
     s->x2_written = false;
     auto flush_x = [&](int b0, int count, int pending, hipStream_t q, bool last = false) {
         const int64_t n2 = n >> 1;
@@ -1093,24 +1157,26 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
         double *const x2 = last ? s->x2_out : nullptr;
         const int64_t x2_rows = last ? s->x2_rows : 0;
         const int lz = last ? lazy_it : -1;
+        const int vl = last && vlast_on ? lazy_it : -1;  // the never-stored last direction (see vlast_on)
+        const double *const vlast_r = s->r;
         if (last && s->prio_on && s->prio_event && q == st && !prio_recorded) {
             // the caller's priority rows first, the event, then the rest (the same bits: every element is
             // updated by exactly one lane of exactly one of the launches)
             const int64_t lo = std::min(s->prio_lo >> 1, n2), hi = std::max(std::min(s->prio_hi >> 1, n2), lo);
             if (lo > 0)
                 hipLaunchKernelGGL(cg_flush_x_kernel, dim3(grid_for(lo)), dim3(kBlock), 0, q, n, d_x, ring, s->alpha_hist,
-                                   s->state, b0, count, pending, (int64_t)0, lo, 0, fused_x, lz, lazy_pq, gs, x2, x2_rows, s->x2_src, s->x2_total, p0_scale);
+                                   s->state, b0, count, pending, (int64_t)0, lo, 0, fused_x, lz, lazy_pq, gs, x2, x2_rows, s->x2_src, s->x2_total, p0_scale, vl, vlast_r, s->diag.mode, s->diag.uniform);
             hipLaunchKernelGGL(cg_flush_x_kernel, dim3(grid_for(n2 - hi + 1)), dim3(kBlock), 0, q, n, d_x, ring,
-                               s->alpha_hist, s->state, b0, count, pending, hi, n2, 1, fused_x, lz, lazy_pq, gs, x2, x2_rows, s->x2_src, s->x2_total, p0_scale);
+                               s->alpha_hist, s->state, b0, count, pending, hi, n2, 1, fused_x, lz, lazy_pq, gs, x2, x2_rows, s->x2_src, s->x2_total, p0_scale, vl, vlast_r, s->diag.mode, s->diag.uniform);
             if (hipEventRecord(s->prio_event, q) == hipSuccess) prio_recorded = true;
             if (hi > lo)
                 hipLaunchKernelGGL(cg_flush_x_kernel, dim3(grid_for(hi - lo)), dim3(kBlock), 0, q, n, d_x, ring,
-                                   s->alpha_hist, s->state, b0, count, pending, lo, hi, 0, fused_x, lz, lazy_pq, gs, x2, x2_rows, s->x2_src, s->x2_total, p0_scale);
+                                   s->alpha_hist, s->state, b0, count, pending, lo, hi, 0, fused_x, lz, lazy_pq, gs, x2, x2_rows, s->x2_src, s->x2_total, p0_scale, vl, vlast_r, s->diag.mode, s->diag.uniform);
             if (x2) s->x2_written = true;
             return;
         }
         hipLaunchKernelGGL(cg_flush_x_kernel, dim3(gv), dim3(kBlock), 0, q, n, d_x, ring, s->alpha_hist, s->state, b0,
-                           count, pending, (int64_t)0, n2, 1, fused_x, lz, lazy_pq, gs, x2, x2_rows, s->x2_src, s->x2_total, p0_scale);
+                           count, pending, (int64_t)0, n2, 1, fused_x, lz, lazy_pq, gs, x2, x2_rows, s->x2_src, s->x2_total, p0_scale, vl, vlast_r, s->diag.mode, s->diag.uniform);
         if (x2) s->x2_written = true;
     };
     double *const pbuf[2] = {s->p, fusedir ? s->q : s->p};
@@ -1195,6 +1261,10 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
                     f.p_scale = p0_scale;
                     f.p0_virtual = 1;
                 }
+                if (vlast_on && instrument && it + 1 == lazy_it) {
+                    f.y = nullptr;     // windows and sums only: nobody reads this direction from memory
+                    f.p0_virtual = 1;  // (walk kernels only)
+                }
                 const bool prof3 = instrument && g_prof.on && g_prof.used + 2 <= g_prof.ev.size();
                 if (prof3) SCHWZ_HIP_TRY(hipEventRecord(g_prof.ev[g_prof.used], q));
                 if ((rc = launch_spmv(A, s->diag.mode == 1 ? kSpmvDirDotSymVec : kSpmvDirDotSym, f, s->variant, q)))
@@ -1213,7 +1283,16 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
                     const CsrView Av = A;
                     const int variant = s->variant;
                     double *const pv = part_vec;
-                    s->lazy_run = [Av, u, variant, pv, gs, s, it, rtol](hipStream_t qq) -> int {
+                    const bool rebuild = vlast_on;
+                    const double *const p_prev = slot(it - 1 >= 0 ? it - 1 : 0);
+                    const double prev_scale = it == 1 ? p0_scale : 1.0;
+                    double *const p_last = slot(it);
+                    const int gvv = gv;
+                    const int64_t nn = n;
+                    s->lazy_run = [Av, u, variant, pv, gs, s, it, rtol, rebuild, p_prev, prev_scale, p_last, gvv, nn](hipStream_t qq) -> int {
+                        if (rebuild)
+                            hipLaunchKernelGGL(cg_rebuild_direction_kernel, dim3(gvv), dim3(kBlock), 0, qq, nn, p_prev, prev_scale,
+                                               (const double *)s->r, s->diag.mode, s->diag.uniform, (const CgState *)s->state, it, p_last);
                         const int rc2 = launch_spmv(Av, kSpmvCgUpdate, u, variant, qq);
                         if (rc2) return rc2;
                         hipLaunchKernelGGL(cg_state_advance_kernel, dim3(1), dim3(kBlock), 0, qq, pv, gs, s->state, it, rtol);

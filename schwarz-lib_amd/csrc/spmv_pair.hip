@@ -1031,7 +1031,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_dirdot_sweep_kernel(CsrView 
             for (int k = 0; k < NH; ++k) {
                 const pvd2 v = newp(o.r[k], o.p[k]);
                 *reinterpret_cast<pvd2 *>(slot_p + 2 * (tid + k * kBlock)) = v;
-                if (out && (!FIRST || a.y)) {  // (FIRST with a.y == nullptr: the virtual p0 -- windows and sums only)
+                if (out && a.y) {  // (a.y == nullptr: a direction nobody reads from memory -- windows and sums only)
                     if ((SCHWZ_DD & 1) && SCHWZ_WALK_HINTS)
                         __builtin_nontemporal_store(v, reinterpret_cast<pvd2 *>(a.y + base + 2 * piece_of(k)));
                     else

@@ -1178,6 +1178,18 @@ def _walk_checks(schwz, oracle, torch, monkeypatch, rng, rp, col, val, must_walk
         rn_v, x_v = solve("1", iters, start="1")
         assert (cg.flavour() & 64 == 64) == in_walk, (cg.flavour(), tag)
         assert np.array_equal(x_s, x_v) and rn_s == rn_v, (tag, iters)
+    # the last direction of a fixed-work solve is never stored either (rebuilt inside the x update; and, because this
+    # test asks for the residual norm, rebuilt in memory for the postponed last update launch)
+    for iters in (2, 10, 17):
+        monkeypatch.setenv("SCHWZ_CG_PLASTVIRTUAL", "0")
+        rn_s, x_s = solve("1", iters, start="1")
+        assert cg.flavour() & 128 == 0
+        in_walk = cg.flavour() & 32 == 32
+        monkeypatch.setenv("SCHWZ_CG_PLASTVIRTUAL", "1")
+        rn_v, x_v = solve("1", iters, start="1")
+        assert (cg.flavour() & 128 == 128) == in_walk, (cg.flavour(), tag)
+        assert np.array_equal(x_s, x_v) and rn_s == rn_v, (tag, iters)
+    monkeypatch.delenv("SCHWZ_CG_PLASTVIRTUAL")
     # ... and a solve to a tolerance (the host polls the state, the x update takes the iterations carried out)
     monkeypatch.setenv("SCHWZ_CG_P0VIRTUAL", "0")
     st_s, x_s = solve("1", 300, start="1", rtol=1e-3)
