@@ -1166,7 +1166,11 @@ int pcg_iterate(schwz_pcg *s, double *d_x, double rtol, int max_iters, hipStream
             if (lo > 0)
                 hipLaunchKernelGGL(cg_flush_x_kernel, dim3(grid_for(lo)), dim3(kBlock), 0, q, n, d_x, ring, s->alpha_hist,
                                    s->state, b0, count, pending, (int64_t)0, lo, 0, fused_x, lz, lazy_pq, gs, x2, x2_rows, s->x2_src, s->x2_total, p0_scale, vl, vlast_r, s->diag.mode, s->diag.uniform);
-            hipLaunchKernelGGL(cg_flush_x_kernel, dim3(grid_for(n2 - hi + 1)), dim3(kBlock), 0, q, n, d_x, ring,
+            // (this launch also copies the entries of x2 beyond the solve's vector -- the halo of x~, two planes of a
+            // slab --, element by element over its whole grid: sized for that too.  With one workgroup, which is what
+            // the upper priority range of a subdomain without an upper neighbour asks for, that copy took 0.44 ms.)
+            const int64_t tail_items = x2 ? std::max<int64_t>(s->x2_total - 2 * n2, 0) : 0;
+            hipLaunchKernelGGL(cg_flush_x_kernel, dim3(std::max(grid_for(n2 - hi + 1), grid_for(tail_items))), dim3(kBlock), 0, q, n, d_x, ring,
                                s->alpha_hist, s->state, b0, count, pending, hi, n2, 1, fused_x, lz, lazy_pq, gs, x2, x2_rows, s->x2_src, s->x2_total, p0_scale, vl, vlast_r, s->diag.mode, s->diag.uniform);
             if (hipEventRecord(s->prio_event, q) == hipSuccess) prio_recorded = true;
             if (hi > lo)
