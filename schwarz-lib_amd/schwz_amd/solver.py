@@ -973,7 +973,18 @@ class SolverRAS:
         if (tol > 0.0 and spec and iter_cond and cv.enable_global_check and not cs.enable_onesided
                 and getattr(comm, "device_norms", False) and len(locals_) == 1):
             sd0 = locals_[0][1]
-            norm_handle = comm.start_allgather_norm_sq(lambda ptr, raw: sd0.norm_sq_to_device(ptr, raw))
+            try:
+                norm_handle = comm.start_allgather_norm_sq(lambda ptr, raw: sd0.norm_sq_to_device(ptr, raw))
+            except Exception as e:  # e.g. the second RCCL communicator cannot be brought up: every rank sees that
+                if getattr(comm, "_norm_used", False):
+                    raise
+                import warnings
+                warnings.warn("device-side all-gather of the residual norms failed at its first use (%s: %s); "
+                              "the gloo group takes over" % (type(e).__name__, e))
+                comm.device_norms = False
+                norm_handle = None
+            else:
+                comm._norm_used = True
         lres = {}
         for me, sd in locals_:
             if tol < 0.0:
