@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <functional>
 #include <memory>
+#include <new>
 #include <string>
 #include <sys/mman.h>
 #include <thread>
@@ -60,6 +61,9 @@ struct NoInitAlloc : std::allocator<T> {
                 (void)madvise(p, padded, MADV_HUGEPAGE);
                 return static_cast<T *>(p);
             }
+            p = std::malloc(bytes);  // (deallocate() frees blocks of this size with std::free)
+            if (!p) throw std::bad_alloc();
+            return static_cast<T *>(p);
         }
         return static_cast<T *>(::operator new(bytes));
     }
@@ -74,7 +78,8 @@ struct NoInitAlloc : std::allocator<T> {
 
 // Threads for the host-side setup loops: SCHWZ_SETUP_THREADS, else the smallest of the CPUs this process may run on,
 // its cgroup CPU quota (a GPU box shows all 256 hardware threads of the host to a job that may use 16 of them:
-// an OpenMP team of 256 on that quota made every setup stage 2-5 x slower and erratic) and 32.
+// an OpenMP team of 256 on that quota made every setup stage 2-5 x slower and erratic) and 32 -- divided by the
+// ranks of this node when a launcher says how many there are.
 inline int setup_threads()
 {
     static const int v = [] {
@@ -105,6 +110,15 @@ inline int setup_threads()
         double cpus = quota("/sys/fs/cgroup/cpu.max", nullptr);
         if (cpus <= 0.0) cpus = quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");
         if (cpus > 0.0) n = std::min(n, (int)(cpus + 0.999));
+        // one rank per GPU of a node (torch.distributed.run / mpiexec set these): the ranks share those CPUs
+        for (const char *var : {"LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS"}) {
+            const char *w = std::getenv(var);
+            const int ranks = w ? std::atoi(w) : 0;
+            if (ranks > 1) {
+                n = std::max(1, n / ranks);
+                break;
+            }
+        }
         return n < 1 ? 1 : (n > 32 ? 32 : n);
     }();
     return v;
