@@ -14,3 +14,4 @@ for r in list(csv.DictReader(open(sys.argv[1])))[:16]:
     print("%-86s calls %5s avg %9.1f us  %5s%%" % (r["Name"][:86], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
 PY
 tail -2 $OUT/stats.log
+python3 $ROOT/tools/trace_outliers.py $OUT/stats
