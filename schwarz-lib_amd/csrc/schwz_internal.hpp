@@ -282,6 +282,9 @@ struct CsrView {
     // the update launch's unless SCHWZ_SWEEP_TDIR asks for taller bands
     int sweep_T_dir = 0, sweep_nslots_dir = 0;
     const int4 *sweep_seg_dir = nullptr;
+    // ... and the first-direction launch of a solve (one vector read, bound by latency: more, shorter workgroups)
+    int sweep_T_first = 0, sweep_nslots_first = 0;
+    const int4 *sweep_seg_first = nullptr;
     const schwz_idx *sweep_gen = nullptr;
     // per pattern of table 0: its entries in the nine slots [far before 0, far before 1, -NX, -1, 0, +1, +NX,
     // far after 0, far after 1] (9 PairVal) and the presence mask (bit k: row r has slot k, bit 16 + k: row r + 1)
@@ -469,6 +472,7 @@ struct schwz_csr {
          *d_tbl_delta = nullptr;
     void *d_pair_rle = nullptr;
     void *d_sweep_seg_dir = nullptr;
+    void *d_sweep_seg_first = nullptr;
     void *d_sweep_seg = nullptr, *d_sweep_gen = nullptr, *d_canon_val = nullptr, *d_canon_mask = nullptr,
          *d_canon_sym_val = nullptr, *d_canon_sym_mask = nullptr, *d_chain_plane = nullptr, *d_chain_far = nullptr;
     void *d_pair_id = nullptr, *d_tile_ptable = nullptr, *d_ptbl_desc = nullptr, *d_ptbl_len = nullptr,

@@ -1306,10 +1306,20 @@ int launch_spmv_pair(const CsrView &A, int mode, const SpmvArgs &a, int grid, hi
     }
     if (mode == kSpmvDirDotSym && a.sweep_first) {
         // first direction of such a solve: p' = D^-1 r and the partial sums of p'.(A p'), CgState untouched
+        const CsrView &A_in = A;
         if (!pair_sweep_start_ok(A, grid) || a.diag_mode == 1 || a.diag_mode == 2) {
             set_error("launch_spmv_pair: the z-sweep first-direction launch does not apply to this matrix");
             return SCHWZ_ERR_INVALID;
         }
+        // (the kernel reads its segments from sweep_seg_dir: this launch gets a view whose direction table IS the
+        // first-direction table)
+        CsrView Af = A_in;
+        if (A_in.sweep_seg_first && A_in.sweep_nslots_first <= grid) {
+            Af.sweep_T_dir = A_in.sweep_T_first;
+            Af.sweep_seg_dir = A_in.sweep_seg_first;
+            Af.sweep_nslots_dir = A_in.sweep_nslots_first;
+        }
+        const CsrView &A = Af;
         const int nhl = (A.sweep_nx / 2 + kBlock - 1) / kBlock, nh = A.sweep_T_dir / kPairRows;
         const size_t lds = (size_t)(4 * A.sweep_T_dir + ((SCHWZ_DD & 2) ? 3 : 2) * A.sweep_nx) * sizeof(double) + (size_t)A.canon_npat * (5 * 16 + 4);
         SpmvArgs b = a;
@@ -1886,8 +1896,35 @@ static int build_sweep(schwz_csr *A, int64_t nrows, const PairTable &tb, const P
     const bool worth = gen.empty() || nrows >= 6000000 || sw_mode == 2;
     if (!worth || (int64_t)slots_v.size() + gen_blocks > grid || steps * T * 2 < nrows)
         return no_walk("rows left to the companion launch on a small matrix, more segments than partial-sum slots, or less than half of the rows walkable");
+    // A table of its own for the first-direction launch of a solve (round 3).  That launch reads ONE vector and does
+    // little per row: its time is the latency of a workgroup's steps times the bytes it keeps in flight, and the
+    // fused launch's table gives it two workgroups per CU.  Bands of the update launch's height (512 rows where the
+    // plane allows) and about SCHWZ_SWEEP_FIRSTPERCU (6; 0: the fused launch's table) workgroups per CU.
+    std::vector<int4> slots_first;
+    int T_first = 0;
+    {
+        const char *fe = std::getenv("SCHWZ_SWEEP_FIRSTPERCU");
+        const int per_cu_f = fe ? std::atoi(fe) : 6;
+        const int Tf = T;  // (a height both walks have instantiations for)
+        if (per_cu_f > 0 && Tf <= (slots_dir.empty() ? T : T_dir)) {
+            const int bands_f = (int)((PL + Tf - 1) / Tf);
+            int64_t steps_f = 0;
+            for (const Run &r : runs) steps_f += (int64_t)(r.p1 - r.p0) * bands_f;
+            int Lf = (int)std::max<int64_t>(6, (steps_f + (int64_t)per_cu_f * cus - 1) / ((int64_t)per_cu_f * cus));
+            auto count_f = [&](int len) {
+                int64_t nq = 0;
+                for (const Run &r : runs) nq += (int64_t)((r.p1 - r.p0 + len - 1) / len) * bands_f;
+                return nq;
+            };
+            while (count_f(Lf) + kXcds > grid - gen_blocks && Lf < (1 << 20)) Lf += 2;
+            slots_first = make_slots(Tf, Lf);
+            if ((int64_t)slots_first.size() + gen_blocks > grid) slots_first.clear();
+            T_first = Tf;
+        }
+    }
     int rc;
     if (!slots_dir.empty() && (rc = upv(slots_dir, &A->d_sweep_seg_dir))) return rc;
+    if (!slots_first.empty() && (rc = upv(slots_first, &A->d_sweep_seg_first))) return rc;
     if ((rc = upv(slots_v, &A->d_sweep_seg)) || (rc = upv(gen, &A->d_sweep_gen)) || (rc = upv(cval, &A->d_canon_val)) ||
         (rc = upv(cmsk, &A->d_canon_mask)) || (rc = upv(chain_plane, &A->d_chain_plane)) ||
         (rc = upv(chain_far, &A->d_chain_far)))
@@ -1915,6 +1952,9 @@ static int build_sweep(schwz_csr *A, int64_t nrows, const PairTable &tb, const P
     A->v.sweep_T_dir = slots_dir.empty() ? T : T_dir;
     A->v.sweep_nslots_dir = slots_dir.empty() ? (int)slots_v.size() : (int)slots_dir.size();
     A->v.sweep_seg_dir = slots_dir.empty() ? A->v.sweep_seg : (const int4 *)A->d_sweep_seg_dir;
+    A->v.sweep_T_first = slots_first.empty() ? A->v.sweep_T_dir : T_first;
+    A->v.sweep_nslots_first = slots_first.empty() ? A->v.sweep_nslots_dir : (int)slots_first.size();
+    A->v.sweep_seg_first = slots_first.empty() ? A->v.sweep_seg_dir : (const int4 *)A->d_sweep_seg_first;
     return SCHWZ_OK;
 }
 
@@ -2412,6 +2452,10 @@ void free_spmv_pair(schwz_csr *A)
     (void)hipFree(A->d_sweep_seg);
     (void)hipFree(A->d_sweep_seg_dir);
     A->d_sweep_seg_dir = nullptr;
+    (void)hipFree(A->d_sweep_seg_first);
+    A->d_sweep_seg_first = nullptr;
+    A->v.sweep_seg_first = nullptr;
+    A->v.sweep_T_first = A->v.sweep_nslots_first = 0;
     A->v.sweep_seg_dir = nullptr;
     A->v.sweep_T_dir = A->v.sweep_nslots_dir = 0;
     (void)hipFree(A->d_sweep_gen);
