@@ -63,6 +63,55 @@ __global__ __launch_bounds__(kBlock) void dir(int64_t n2, vd2 *__restrict__ pn, 
     }
 }
 
+// "blocked" order: `gridDim.x` persistent workgroups, each walking its own contiguous 1/gridDim.x of the vectors from
+// its start upwards -- the temporal order of the z-sweep walks (every segment of the grid advances at the same time),
+// against the dispatch order of the short-lived workgroups above (one front moving through the vectors)
+template <bool NT>
+__global__ __launch_bounds__(kBlock) void upd_blocked(int64_t n2, vd2 *__restrict__ r, const vd2 *__restrict__ p, double a)
+{
+    const int64_t chunk = (n2 + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = blockIdx.x * chunk, hi = lo + chunk < n2 ? lo + chunk : n2;
+    for (int64_t base = lo + threadIdx.x; base < hi; base += kBlock * kPer) {
+        vd2 rv[kPer], pv[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int64_t i = base + (int64_t)k * kBlock;
+            if (i < hi) { rv[k] = r[i]; pv[k] = p[i]; }
+        }
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int64_t i = base + (int64_t)k * kBlock;
+            if (i < hi) {
+                vd2 v = rv[k] - a * pv[k];
+                if (NT) __builtin_nontemporal_store(v, r + i); else r[i] = v;
+            }
+        }
+    }
+}
+
+template <bool NT>
+__global__ __launch_bounds__(kBlock) void dir_blocked(int64_t n2, vd2 *__restrict__ pn, const vd2 *__restrict__ r, const vd2 *__restrict__ p, double bta)
+{
+    const int64_t chunk = (n2 + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = blockIdx.x * chunk, hi = lo + chunk < n2 ? lo + chunk : n2;
+    for (int64_t base = lo + threadIdx.x; base < hi; base += kBlock * kPer) {
+        vd2 rv[kPer], pv[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int64_t i = base + (int64_t)k * kBlock;
+            if (i < hi) { rv[k] = r[i]; pv[k] = p[i]; }
+        }
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int64_t i = base + (int64_t)k * kBlock;
+            if (i < hi) {
+                vd2 v = rv[k] + bta * pv[k];
+                if (NT) __builtin_nontemporal_store(v, pn + i); else pn[i] = v;
+            }
+        }
+    }
+}
+
 int main(int argc, char **argv)
 {
     const int64_t n = (int64_t)((argc > 1 ? std::atof(argv[1]) : 16.9) * 1e6) / 2 * 2;
@@ -141,6 +190,26 @@ int main(int argc, char **argv)
         }
         const double us_pair = best * 1e3 / iters;
         std::printf("nt stores, %-14s %7.1f us per pair   %.2f TB/s of 48n bytes\n", c.name, us_pair, 48.0 * n / us_pair / 1e6);
+    }
+    // blocked order (nt stores, plain loads), workgroups = 3, 4, 6, 8 per CU
+    for (int per_cu : {3, 4, 6, 8, 16}) {
+        const int g = 256 * per_cu;
+        float best = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {
+            CHECK(hipEventRecord(e0, 0));
+            for (int it = 0; it < iters; ++it) {
+                vd2 *pk = (vd2 *)p[it % ring], *pn = (vd2 *)p[(it + 1) % ring];
+                hipLaunchKernelGGL(upd_blocked<true>, dim3(g), dim3(kBlock), 0, 0, n2, (vd2 *)r, pk, 1e-3);
+                hipLaunchKernelGGL(dir_blocked<true>, dim3(g), dim3(kBlock), 0, 0, n2, pn, (const vd2 *)r, pk, 0.5);
+            }
+            CHECK(hipEventRecord(e1, 0));
+            CHECK(hipEventSynchronize(e1));
+            float ms;
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            best = ms < best ? ms : best;
+        }
+        const double us_pair = best * 1e3 / iters;
+        std::printf("blocked order, %2d workgroups per CU      %7.1f us per pair   %.2f TB/s of 48n bytes\n", per_cu, us_pair, 48.0 * n / us_pair / 1e6);
     }
     return 0;
 }
