@@ -64,6 +64,10 @@ enum schwz_precond {
 
 const char *schwz_last_error(void);
 const char *schwz_version(void);
+/* threads the host-side setup loops run on (restricted_schwarz.cpp:56-304 is serial in the reference): SCHWZ_SETUP_THREADS,
+ * else the smallest of the process's CPUs, its cgroup CPU quota and 32, divided among the ranks of a node when a
+ * launcher says how many there are (LOCAL_WORLD_SIZE, OMPI_COMM_WORLD_LOCAL_SIZE, MPI_LOCALNRANKS).  Fixed at first use. */
+int schwz_setup_threads(void);
 /* number of visible HIP devices (0 on a CPU-only host; never fails) */
 int schwz_device_count(void);
 /* device_guard (include/device_guard.hpp:47-101): bind the calling thread */

@@ -156,6 +156,7 @@ extern "C" {
 
 const char *schwz_last_error(void) { return g_last_error.c_str(); }
 const char *schwz_version(void) { return "schwz-hip 0.1 (gfx950)"; }
+int schwz_setup_threads(void) { return schwz::setup_threads(); }
 void schwz_free(void *p) { std::free(p); }
 
 int schwz_problem_laplacian(int dim, int64_t nx, int64_t ny, int64_t nz, schwz_problem **out)

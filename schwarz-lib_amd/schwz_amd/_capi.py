@@ -26,7 +26,7 @@ PRECOND_NONE, PRECOND_JACOBI, PRECOND_BLOCK_JACOBI, PRECOND_ILU, PRECOND_ISAI = 
 
 # every symbol include/schwz_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "schwz_last_error", "schwz_version", "schwz_device_count", "schwz_set_device",
+    "schwz_last_error", "schwz_version", "schwz_device_count", "schwz_set_device", "schwz_setup_threads",
     "schwz_gather", "schwz_scatter", "schwz_gather_typed", "schwz_scatter_typed",
     "schwz_csr_create", "schwz_csr_destroy", "schwz_csr_nnz", "schwz_csr_format", "schwz_csr_symmetric", "schwz_csr_matrix_bytes", "schwz_csr_sweep_slots", "schwz_csr_sweep_left_out", "schwz_csr_spmv",
     "schwz_pcg_create", "schwz_pcg_create_ex", "schwz_pcg_destroy", "schwz_pcg_flavour", "schwz_pcg_solve",
@@ -106,6 +106,7 @@ def _sig(name, restype, argtypes):
 _sig("schwz_last_error", C.c_char_p, [])
 _sig("schwz_version", C.c_char_p, [])
 _sig("schwz_device_count", i32, [])
+_sig("schwz_setup_threads", i32, [])
 _sig("schwz_set_device", i32, [i32])
 _sig("schwz_gather", i32, [i64, vp, vp, vp, i32, vp])
 _sig("schwz_scatter", i32, [i64, vp, vp, vp, i32, vp])

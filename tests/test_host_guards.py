@@ -87,3 +87,28 @@ def test_partition_debug_file(tmp_path, monkeypatch):
     assert lines[0] == "idx,subd" and len(lines) == 65
     part = np.array([int(l.split(",")[1]) for l in lines[1:]])
     assert np.array_equal(np.bincount(part), [16, 16, 16, 16]) and prob.N == 64
+
+
+def test_setup_threads_follow_the_environment(tmp_path):
+    """Threads of the host-side setup loops (schwz_setup_threads): the explicit setting wins; otherwise the CPUs of the
+    process, capped by its cgroup quota and 32, divided among the ranks of a node a launcher announces.  Fixed at first
+    use, so every case runs in a process of its own."""
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "schwarz-lib_amd")
+    code = ("import sys; sys.path.insert(0, %r); import schwz_amd._capi as c; print(c.lib.schwz_setup_threads())" % root)
+
+    def run(**env):
+        e = {k: v for k, v in os.environ.items() if k not in ("SCHWZ_SETUP_THREADS", "LOCAL_WORLD_SIZE",
+                                                              "OMPI_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS")}
+        e.update(env)
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=e, timeout=120)
+        assert p.returncode == 0, p.stderr
+        return int(p.stdout.strip().splitlines()[-1])
+
+    base = run()
+    assert 1 <= base <= 32 and base <= len(os.sched_getaffinity(0))
+    assert run(SCHWZ_SETUP_THREADS="5") == 5
+    assert run(LOCAL_WORLD_SIZE="2") == max(1, base // 2)
+    assert run(LOCAL_WORLD_SIZE="64") == max(1, base // 64)
+    assert run(SCHWZ_SETUP_THREADS="3", LOCAL_WORLD_SIZE="8") == 3
