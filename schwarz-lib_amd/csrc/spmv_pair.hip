@@ -611,6 +611,9 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_kernel(CsrView A, SpmvArgs a
 #ifndef SCHWZ_WALK_HINTS
 #define SCHWZ_WALK_HINTS 1
 #endif
+#ifndef SCHWZ_INIT_PLAIN_STORE
+#define SCHWZ_INIT_PLAIN_STORE 1  // start walk: r0 leaves with a plain store -- its next two readers (first direction, first update) follow at once and find part of it on die: -0.5 ... -0.75 % per step at 256^3 / 512 x 512 x 64, neutral on 1 GB vectors (profiles/r03_cache_hints.txt)
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // z-sweep ("brick") walk of the q-free CG update launch for matrices in the canonical 3-D stencil layout
@@ -879,7 +882,7 @@ __global__ __launch_bounds__(kBlock) void spmv_pair_sweep_kernel(CsrView A, Spmv
                     acc2 += plain_pos ? q1 : 0.0;
                 }
                 const pvd2 rn = {r0, r1};
-                if (SCHWZ_WALK_HINTS)
+                if (SCHWZ_WALK_HINTS && !(INIT && SCHWZ_INIT_PLAIN_STORE))
                     __builtin_nontemporal_store(rn, reinterpret_cast<pvd2 *>(r_out + ra));
                 else
                     *reinterpret_cast<pvd2 *>(r_out + ra) = rn;
